@@ -1,0 +1,69 @@
+/*
+ * sls_spec.h — numeric constants and buffer layouts of the spherical surfel
+ * rasterizer (SURVEY.md §8a decisions D1–D9).  Part of the
+ * public boundary: the HIP kernels, the C-ABI and any checker agree on
+ * these and nothing else.
+ */
+#ifndef SLS_SPEC_H
+#define SLS_SPEC_H
+
+/* D2 near cut on range; D7 near/far of the distortion mapping. */
+#define SLS_NEAR 0.2f
+#define SLS_FAR 100.0f
+/* D4: binning cutoff (sigma) and minimum pixel radius = cutoff * low-pass
+ * filter size sqrt(2)/2 (the filter is G2d = exp(-|dpix|^2), i.e.
+ * FilterInvSquare = 2). */
+#define SLS_CUTOFF 3.0f
+#define SLS_RMIN_PX 2.1213203435596424f
+#define SLS_FILTER_INV_SQUARE 2.0f
+/* blending thresholds */
+#define SLS_ALPHA_MAX 0.99f
+#define SLS_ALPHA_MIN (1.0f / 255.0f)
+#define SLS_T_MIN 1.0e-4f
+
+/* Per-surfel record written by preprocess, read by the tile kernels:
+ * 5 x float4 = 80 B.
+ *   q0: Hu.xyz , npv      Hu =  sigma (Tv x p)/su   (u = Hu.(d-dc)/nd)
+ *   q1: Hv.xyz , rho_c    Hv = -sigma (Tu x p)/sv   (v = Hv.(d-dc)/nd)
+ *   q2: n.xyz  , opacity  n = sigma*Tn faces the sensor, npv = n.p <= 0
+ *   q3: dc.xyz , 0        dc = p/|p|
+ *   q4: cpx, cpy, ex, ey  centre pixel; conservative support half-extent
+ *                         (ex, ey are a kernel-side culling aid only; they
+ *                          never change a result and are not checked).
+ */
+#define SLS_REC_STRIDE 20
+#define SLS_REC_HU 0
+#define SLS_REC_NPV 3
+#define SLS_REC_HV 4
+#define SLS_REC_RHOC 7
+#define SLS_REC_N 8
+#define SLS_REC_OPAC 11
+#define SLS_REC_DC 12
+#define SLS_REC_CPX 16
+#define SLS_REC_CPY 17
+#define SLS_REC_EX 18
+#define SLS_REC_EY 19
+
+/* Per-surfel gradient record accumulated by the tile backward kernel and
+ * consumed by preprocess-backward: 4 x float4 = 64 B.
+ *   g0: dL/dHu.xyz , dL/dnpv
+ *   g1: dL/dHv.xyz , dL/drho_c
+ *   g2: dL/dn.xyz  , dL/dopacity
+ *   g3: Su, Sv, dL/dcpx, dL/dcpy     (dL/ddc = -(Su*Hu + Sv*Hv))
+ */
+#define SLS_GREC_STRIDE 16
+
+/* Per-pixel state saved by the forward for the backward (the caller may
+ * overwrite allmap in place — gaussian_renderer/__init__.py:61-62,70-71 —
+ * so the backward never reads allmap):  float4 {T_final, M1, M2, 0} and
+ * uint2 {n_contrib, median_contrib}. */
+
+/* allmap channels (gaussian_renderer/__init__.py:51-79) */
+#define SLS_CH_DEPTH 0
+#define SLS_CH_ALPHA 1
+#define SLS_CH_NORMAL 2
+#define SLS_CH_MEDIAN 5
+#define SLS_CH_DIST 6
+#define SLS_NUM_CH 7
+
+#endif /* SLS_SPEC_H */
