@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward throughput of the spherical surfel rasterizer
+on MI355X (BASELINE.json: "fwd+bwd Msplats/s @ 500k Gaussians, 64x2048").
+
+One step = one mapping iteration of Splat-LOAM's hot loop (slam/mapper.py:150-204)
+for ONE keyframe per GPU on the synthetic scene of SURVEY.md §8d:
+    render()  [HIP: preprocess, scan, keys, radix sort, ranges, tile render]
+    + mapper loss + loss.backward()  [HIP: tile backward, preprocess backward]
+    + Adam step on the 4 parameter tensors  [HIP: fused Adam]
+with every input already resident in HBM.  Nothing is skipped inside the
+timed region.  At N GPUs every rank renders its own keyframe of the shared
+model and the 40 B/surfel gradients are all-reduced over RCCL (weak scaling:
+value = n_gpus * N / step time).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest
+total time in the step, from HIP events recorded on the launch stream inside
+the timed region; `cpu_baseline` times the CPU checker (oracle/, C + OpenMP) on
+the same workload on this host's cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(name, N, R, R_eff, P, n_sort_passes):
+    """Compulsory HBM bytes per launch (records 80 B, gradient
+    records 64 B, key/value pair 12 B, per-pixel outputs 52 B)."""
+    return {
+        "preprocess_fwd": N * (40 + 80 + 28),
+        "scan": N * 8,
+        "emit_keys": N * 28 + R * 12,
+        "sort_hist": R * 8,
+        "sort_rowscan": 0,
+        "sort_scatter": R * 24,
+        "tile_ranges": R * 8,
+        "render_fwd": R_eff * 84 + P * 52,
+        "grec_memset": N * 64,
+        "render_bwd": R_eff * (84 + 64) + P * (28 + 24),
+        "preprocess_bwd": N * (40 + 4 + 64 + 40),
+        "adam": N * 10 * 28,
+    }.get(name, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=500_000, help="surfels (BASELINE config 3: 500k)")
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from splat_loam_amd import _abi, synth
+    from splat_loam_amd.mapping import MappingConfig, optimize_step_sharded
+    from splat_loam_amd.scene import Camera, SurfelModel
+
+    lib = _abi.lib()
+    N, H, W = args.n, args.height, args.width
+    scene = synth.make_scene(N, H, W, seed=0)
+    poses = synth.keyframe_poses(max(world, 1))
+    depth, valid = synth.make_targets(H, W, scene)
+    cam = Camera(scene["K"], depth, None, valid, poses[rank], data_device=str(dev))
+    model = SurfelModel.from_activated(scene["means"], scene["scales"], scene["rots"], scene["opac"], device=str(dev))
+    model.training_setup(fused=True)
+    cfg = MappingConfig()
+
+    def step():
+        return optimize_step_sharded(model, cam, cfg)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timing = not args.no_timing
+    if timing:
+        lib.sls_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernels = {}
+    if timing:
+        ns = lib.sls_timing_slots()
+        tot = (C.c_double * ns)()
+        cnt = (C.c_int64 * ns)()
+        lib.sls_timing_collect(tot, cnt)
+        lib.sls_timing_enable(0)
+        for s in range(ns):
+            if cnt[s]:
+                kernels[lib.sls_timing_name(s).decode()] = (tot[s], int(cnt[s]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # workload statistics from one un-timed forward (R, R_eff)
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, rasterize_forward
+    with torch.no_grad():
+        st = rasterize_forward(GaussianRasterizationSettings(H, W, 1.0, cam.world_view_transform,
+                                                             cam.projection_matrix, False, False),
+                               model.get_xyz, model.get_opacity, model.get_scaling, model.get_rotation)
+        R = st.R
+        R_eff = int(st.tile_consumed.cpu().numpy().view(np.uint32).astype(np.int64).sum())
+    tw, th = _abi.tile_size()
+    T = ((W + tw - 1) // tw) * ((H + th - 1) // th)
+    n_pass = (32 + max(T - 1, 1).bit_length() + 7) // 8
+    P = H * W
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * N / (dt / args.steps) / 1e6
+
+    roofline = None
+    breakdown = {}
+    if kernels:
+        for name, (ms, c) in kernels.items():
+            avg_us = ms / c * 1e3
+            b = algorithmic_bytes(name, N, R, R_eff, P, n_pass)
+            breakdown[name] = {"launches_per_step": c / args.steps, "avg_us": round(avg_us, 2),
+                               "us_per_step": round(ms / args.steps * 1e3, 2),
+                               "alg_bytes_per_launch": int(b),
+                               "GBps": round(b / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, c = kernels[dom]
+        b = algorithmic_bytes(dom, N, R, R_eff, P, n_pass)
+        ach = b / (ms / c * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_us": round(ms / c * 1e3, 2), "alg_bytes_per_launch": int(b)}
+        fb_ms = sum(kernels[k][0] / kernels[k][1] for k in ("render_fwd", "render_bwd") if k in kernels)
+        if fb_ms > 0:
+            fb_b = algorithmic_bytes("render_fwd", N, R, R_eff, P, n_pass) + algorithmic_bytes("render_bwd", N, R, R_eff, P, n_pass)
+            roofline["tile_fwd_bwd_GBps"] = round(fb_b / (fb_ms * 1e-3) / 1e9, 2)
+            roofline["tile_fwd_bwd_us"] = round(fb_ms * 1e3, 2)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle.oracle import Oracle
+            o = Oracle(np.float32)
+            cores = o.max_threads()
+            view, proj = synth.camera_matrices(scene["K"], poses[0])
+            ocam = o.camera(H, W, view, proj, tile=(tw, th))
+            dL = np.random.default_rng(0).normal(size=(7, H, W)).astype(np.float32)
+            reps, tt = 0, 0.0
+            o.forward(ocam, scene["means"], scene["scales"], scene["rots"], scene["opac"], frag_tol=0.0)  # warm-up
+            while tt < 10.0 and reps < 8:
+                t1 = time.perf_counter()
+                ost = o.forward(ocam, scene["means"], scene["scales"], scene["rots"], scene["opac"], frag_tol=0.0)
+                o.backward(ost, dL, threads=cores, want_abs=False)
+                tt += time.perf_counter() - t1
+                reps += 1
+            cpu = {"value": round(N / (tt / reps) / 1e6, 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
+                   "sample": f"{reps} x full rasterizer forward+backward (no loss/Adam) of the same {N}-surfel "
+                             f"{H}x{W} scene, oracle/sls_oracle.c with OpenMP"}
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            cpu = {"value": None, "unit": "Msplats/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    out = {
+        "metric": "fwd+bwd Msplats/s", "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU: render fwd + mapper loss + bwd + fused Adam",
+                   "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff,
+                   "parallelism": f"keyframe-dp{world}"},
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * sls_abi.h — C-ABI of libsls_hip.so, the MI355X (gfx950) implementation of
+ * the hot path behind Splat-LOAM's renderer.
+ *
+ * Every entry point replaces one native call the reference makes through
+ * its (un-vendored) CUDA extensions; the Python binding a maintainer adds is
+ * shown in INTEGRATION.md and shipped in splat_loam_amd/_abi.py.
+ *
+ *   reference call site (file:line under /root/reference)      replaced by
+ *   ----------------------------------------------------------  -------------------------
+ *   GaussianRasterizer.forward, native forward                  sls_forward_stage1/2
+ *     gaussian_renderer/__init__.py:26,40-47
+ *   loss.backward() -> native backward  slam/mapper.py:201      sls_backward
+ *   optimizer.step() (Adam, 4 groups)   slam/mapper.py:204,     sls_adam_step
+ *     scene/gaussian_model.py:97-121
+ *   distCUDA2(points)  slam/mapper.py:113-115,                  sls_knn_dist2
+ *     scene/gaussian_model.py:77-81
+ *   GaussianRasterizer.markVisible (lineage API, unused in tree) sls_mark_visible
+ *
+ * Conventions
+ *   - plain C, no torch types; all pointers are DEVICE pointers to
+ *     contiguous float32/int32/uint32/uint64 arrays unless named *_host;
+ *   - the CALLER owns every buffer (torch's caching allocator stays the only
+ *     device allocator); the library never allocates device memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises unless stated;
+ *   - return 0 on success, a negative SLS_E_* code on failure; the message
+ *     is available from sls_last_error() (thread-local); nothing throws.
+ */
+#ifndef SLS_ABI_H
+#define SLS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLS_OK 0
+#define SLS_E_ARG (-1)      /* bad argument (null pointer, negative size, ...) */
+#define SLS_E_HIP (-2)      /* a HIP runtime call or kernel launch failed      */
+#define SLS_E_SCRATCH (-3)  /* scratch buffer too small                         */
+
+/* Camera of one LiDAR keyframe.  Filled by sls_camera_from_matrices from the
+ * two matrices the reference passes in GaussianRasterizationSettings
+ * (gaussian_renderer/__init__.py:16-24; conventions scene/cameras.py:43-50). */
+typedef struct SlsCamera {
+    int32_t H, W;           /* image_height, image_width                        */
+    int32_t wrap;           /* 1: azimuth wraps (360 deg image), D5             */
+    int32_t reserved;
+    float fx, fy, cx, cy;   /* K = projmatrix[:3,:3]^T : u = fx*az+cx, v = fy*el+cy */
+    float scale_modifier;
+    float near_cut, far_cut;
+    float pad;
+    float Rvw[9];           /* row-major: p_view = Rvw * p_world + tvw          */
+    float tvw[3];
+} SlsCamera;
+
+const char *sls_last_error(void);
+int sls_version(void);
+
+/* Compile-time tile size of the binning/render kernels (D8). */
+int sls_tile_w(void);
+int sls_tile_h(void);
+/* floats per surfel record / gradient record (include/sls_spec.h). */
+int sls_rec_stride(void);
+int sls_grec_stride(void);
+
+/* Host helper.  view/proj: row-major 4x4 float, exactly the tensors in
+ * GaussianRasterizationSettings.viewmatrix / .projmatrix. */
+int sls_camera_from_matrices(const float *view_host, const float *proj_host, int H, int W,
+                             float scale_modifier, SlsCamera *out);
+
+/* Host helper: per-column (cos az, sin az) and per-row (cos el, sin el) of the
+ * pixel rays, evaluated in double and rounded once.  col_cs_host: 2*W floats,
+ * row_cs_host: 2*H floats.  The caller uploads them (they depend on K only). */
+int sls_ray_tables(const SlsCamera *cam, float *col_cs_host, float *row_cs_host);
+
+/* ---- forward, stage 1: preprocess + scan -------------------------------
+ * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
+ * tiles_touched: N uint32, depth: N floats (range of the centre, the sort key),
+ * offsets: N uint32 (inclusive scan of tiles_touched),
+ * total_out: 1 uint32 on the DEVICE = number of tile instances R.
+ * The caller reads total_out (one D2H sync, as the lineage does) to size the
+ * stage-2 buffers. */
+size_t sls_stage1_scratch_bytes(int N);
+int sls_forward_stage1(const SlsCamera *cam, int N,
+                       const float *means3D, const float *scales, const float *rotations,
+                       const float *opacities,
+                       float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles_touched,
+                       float *depth, uint32_t *offsets, uint32_t *total_out,
+                       void *scratch, size_t scratch_bytes, void *stream);
+
+/* ---- forward, stage 2: keys, radix sort, ranges, per-tile render -------
+ * keys/keys_tmp: R uint64, vals/vals_tmp: R uint32 (ping-pong), ranges: T*2
+ * uint32 with T = ceil(W/tw)*ceil(H/th).  On return *sorted_in_tmp tells
+ * which pair holds the sorted list (0: keys/vals, 1: keys_tmp/vals_tmp).
+ * allmap: 7*H*W floats; pix_state: H*W float4 {T_final, M1, M2, 0};
+ * pix_contrib: H*W uint2 {n_contrib, median_contrib};
+ * tile_consumed: T uint32 (list entries consumed before the tile finished,
+ * the R_eff of SURVEY §8d). */
+size_t sls_sort_scratch_bytes(uint64_t R);
+int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
+                       const float *rec, const int32_t *rect, const uint32_t *tiles_touched,
+                       const float *depth, const uint32_t *offsets,
+                       uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
+                       void *sort_scratch, size_t sort_scratch_bytes, int *sorted_in_tmp,
+                       uint32_t *ranges, const float *col_cs, const float *row_cs,
+                       float *allmap, float *pix_state, uint32_t *pix_contrib,
+                       uint32_t *tile_consumed, void *stream);
+
+/* ---- backward ----------------------------------------------------------
+ * vals_sorted/ranges/rec/pix_* are the forward's buffers (never allmap: the
+ * caller may have overwritten it in place).  grec: N*16 floats of scratch
+ * (zeroed by the call).  Outputs: dL/dmeans3D (N*3), dL/dscales (N*2),
+ * dL/drotations (N*4, w.r.t. the normalised quaternion as passed in),
+ * dL/dopacities (N). */
+int sls_backward(const SlsCamera *cam, int N, uint64_t R,
+                 const float *means3D, const float *scales, const float *rotations,
+                 const int32_t *radii, const float *rec,
+                 const uint32_t *ranges, const uint32_t *vals_sorted,
+                 const float *col_cs, const float *row_cs,
+                 const float *pix_state, const uint32_t *pix_contrib,
+                 const float *dL_dallmap, float *grec,
+                 float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
+                 float *dL_dopacities, void *stream);
+
+/* ---- fused Adam over up to 8 parameter tensors in one launch ------------
+ * torch.optim.Adam semantics (no weight decay, no amsgrad); step is 1-based
+ * and shared by all groups. */
+typedef struct SlsAdamGroup {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t numel;
+    float lr;
+    float pad;
+} SlsAdamGroup;
+int sls_adam_step(const SlsAdamGroup *groups_host, int ngroups, float beta1, float beta2,
+                  float eps, int64_t step, void *stream);
+
+/* ---- simple-knn ---------------------------------------------------------
+ * out[i] = mean of squared distances from point i to its 3 nearest other
+ * points. */
+size_t sls_knn_scratch_bytes(int M);
+int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes,
+                  void *stream);
+
+/* visible[i] = 1 if surfel centre i survives the near cut (radii would be >0
+ * unless it is off-image). */
+int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t *visible,
+                     void *stream);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream
+ * (bench.py's roofline figures).  sls_timing_collect synchronises on the
+ * recorded events, fills total_ms[slot] / counts[slot] for slot <
+ * sls_timing_slots() and resets the recorder; returns 1 if the event pool ran
+ * out (later launches untimed). */
+int sls_timing_slots(void);
+const char *sls_timing_name(int slot);
+int sls_timing_enable(int on);
+int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
+
+/* Device self-test of the wave64 primitives (DPP reduction, ballot ranking).
+ * Returns 0 if they behave as the kernels assume.  Synchronises. */
+int sls_selftest(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLS_ABI_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libsls_hip.so (include/sls_abi.h).
+
+This is the stub a Splat-LOAM maintainer adds to reach the HIP library
+(INTEGRATION.md shows it in context).  There is NO fallback: if the shared
+library is missing the import of any product entry point raises, and device
+entry points refuse CPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsls_hip.so")
+
+SLS_OK = 0
+
+
+class SlsCamera(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("wrap", C.c_int32), ("reserved", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("scale_modifier", C.c_float), ("near_cut", C.c_float), ("far_cut", C.c_float), ("pad", C.c_float),
+        ("Rvw", C.c_float * 9), ("tvw", C.c_float * 3),
+    ]
+
+
+class SlsAdamGroup(C.Structure):
+    _fields_ = [
+        ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("numel", C.c_int64), ("lr", C.c_float), ("pad", C.c_float),
+    ]
+
+
+_VP = C.c_void_p
+_PROTOS = {
+    # name: (restype, argtypes)
+    "sls_last_error": (C.c_char_p, []),
+    "sls_version": (C.c_int, []),
+    "sls_tile_w": (C.c_int, []),
+    "sls_tile_h": (C.c_int, []),
+    "sls_rec_stride": (C.c_int, []),
+    "sls_grec_stride": (C.c_int, []),
+    "sls_camera_from_matrices": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.POINTER(SlsCamera)]),
+    "sls_ray_tables": (C.c_int, [C.POINTER(SlsCamera), _VP, _VP]),
+    "sls_stage1_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 11 + [_VP, C.c_size_t, _VP]),
+    "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),
+    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 9 +
+                           [_VP, C.c_size_t, C.POINTER(C.c_int)] + [_VP] * 7 + [_VP]),
+    "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP]),
+    "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_float, C.c_float, C.c_float, C.c_int64, _VP]),
+    "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),
+    "sls_timing_slots": (C.c_int, []),
+    "sls_timing_name": (C.c_char_p, [C.c_int]),
+    "sls_timing_enable": (C.c_int, [C.c_int]),
+    "sls_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "sls_selftest": (C.c_int, [_VP]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+def lib():
+    """Load libsls_hip.so once.  torch must be imported first so that the HIP
+    runtime the process already uses (torch's libamdhip64) is the one our
+    kernels launch on."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        import torch  # noqa: F401  (loads libamdhip64 first)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != SLS_OK:
+        msg = lib().sls_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def tile_size() -> tuple[int, int]:
+    l = lib()
+    return int(l.sls_tile_w()), int(l.sls_tile_h())

@@ -1,0 +1,392 @@
+// sls_api.hip — the extern "C" boundary (include/sls_abi.h), host helpers,
+// fused Adam (P6) and the device self-test.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "sls_common.hpp"
+
+namespace sls {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// per-kernel timing (HIP events on the launch stream)
+// ---------------------------------------------------------------------------
+static const char *kTimerNames[T_COUNT] = {
+    "preprocess_fwd", "scan", "emit_keys", "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges",
+    "render_fwd", "grec_memset", "render_bwd", "preprocess_bwd", "adam", "knn", "consumer"
+};
+constexpr int kTimerPool = 8192;
+struct TimerState {
+    bool enabled = false;
+    int used = 0;
+    int created = 0;
+    hipEvent_t start[kTimerPool], stop[kTimerPool];
+    int slot[kTimerPool];
+};
+static TimerState g_timer;
+
+void timer_begin(int slot, hipStream_t st)
+{
+    if (!g_timer.enabled || g_timer.used >= g_timer.created) return;
+    g_timer.slot[g_timer.used] = slot;
+    (void)hipEventRecord(g_timer.start[g_timer.used], st);
+}
+void timer_end(int slot, hipStream_t st)
+{
+    (void)slot;
+    if (!g_timer.enabled || g_timer.used >= g_timer.created) return;
+    (void)hipEventRecord(g_timer.stop[g_timer.used], st);
+    ++g_timer.used;
+}
+
+// launchers implemented in the other translation units
+int launch_preprocess_fwd(const DevCam &, int, const float *, const float *, const float *, const float *, float *,
+                          int32_t *, int32_t *, uint32_t *, float *, uint32_t *, uint32_t *, uint32_t *, hipStream_t);
+int launch_preprocess_bwd(const DevCam &, int, const float *, const float *, const float *, const int32_t *,
+                          const float *, float *, float *, float *, float *, hipStream_t);
+int launch_mark_visible(const DevCam &, int, const float *, uint8_t *, hipStream_t);
+size_t sort_scratch_bytes(uint64_t R);
+int launch_bin_sort(const DevCam &, int, uint64_t, const int32_t *, const uint32_t *, const float *,
+                    const uint32_t *, uint64_t *, uint32_t *, uint64_t *, uint32_t *, void *, size_t, int *,
+                    uint32_t *, hipStream_t);
+int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
+                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
+int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
+                      const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
+size_t knn_scratch_bytes(int M);
+int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// P6 fused Adam: every parameter tensor of the model in ONE launch.
+// HBM-bound: 16 B read + 12 B written per element.
+// ---------------------------------------------------------------------------
+constexpr int kMaxAdamGroups = 8;
+struct AdamArgs {
+    SlsAdamGroup g[kMaxAdamGroups];
+    int64_t unit_end[kMaxAdamGroups];   // prefix of ceil(numel/4) units
+    int ngroups;
+    float w1, b2, w2, eps, bc2_sqrt, bc1;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float step_size, const AdamArgs &a)
+{
+    m = m + (g - m) * a.w1;
+    v = v * a.b2 + (a.w2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units)
+{
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * 256) {
+        int gi = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxAdamGroups - 1; ++k)
+            if (k < a.ngroups - 1 && u >= a.unit_end[k]) gi = k + 1;
+        const SlsAdamGroup grp = a.g[gi];
+        const int64_t e0 = (u - (gi ? a.unit_end[gi - 1] : 0)) * 4;
+        const float step_size = grp.lr / a.bc1;
+        const bool vec = (e0 + 4 <= grp.numel) &&
+                         ((((uintptr_t)grp.param | (uintptr_t)grp.grad | (uintptr_t)grp.exp_avg | (uintptr_t)grp.exp_avg_sq) & 15) == 0);
+        if (vec) {
+            float4 p = *reinterpret_cast<float4 *>(grp.param + e0);
+            const float4 g = *reinterpret_cast<const float4 *>(grp.grad + e0);
+            float4 m = *reinterpret_cast<float4 *>(grp.exp_avg + e0);
+            float4 v = *reinterpret_cast<float4 *>(grp.exp_avg_sq + e0);
+            adam_one(p.x, g.x, m.x, v.x, step_size, a);
+            adam_one(p.y, g.y, m.y, v.y, step_size, a);
+            adam_one(p.z, g.z, m.z, v.z, step_size, a);
+            adam_one(p.w, g.w, m.w, v.w, step_size, a);
+            *reinterpret_cast<float4 *>(grp.param + e0) = p;
+            *reinterpret_cast<float4 *>(grp.exp_avg + e0) = m;
+            *reinterpret_cast<float4 *>(grp.exp_avg_sq + e0) = v;
+        } else {
+            for (int64_t e = e0; e < e0 + 4 && e < grp.numel; ++e) {
+                float p = grp.param[e], m = grp.exp_avg[e], v = grp.exp_avg_sq[e];
+                adam_one(p, grp.grad[e], m, v, step_size, a);
+                grp.param[e] = p; grp.exp_avg[e] = m; grp.exp_avg_sq[e] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// device self-test of the wave64 primitives the kernels rely on
+// ---------------------------------------------------------------------------
+__global__ void selftest_kernel(int *out)
+{
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    // DPP sum: lanes hold (lane+1) * 0.5 -> total 1040 at lane 63
+    const float tot = wave_sum_to_lane63(0.5f * (float)(lane + 1));
+    if (lane == 63 && tot != 1040.0f) bad |= 1;
+    // asymmetric pattern: only lanes 5 and 40 non-zero
+    const float t2 = wave_sum_to_lane63(lane == 5 ? 3.0f : (lane == 40 ? 11.0f : 0.0f));
+    if (lane == 63 && t2 != 14.0f) bad |= 2;
+    // ballot / popcount ranking
+    const uint64_t bal = __ballot((lane % 3) == 0);
+    if (__popcll(bal) != 22) bad |= 4;
+    if (lane_id() != lane) bad |= 8;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if ((lane % 3) == 0 && (int)__popcll(bal & lt) != lane / 3) bad |= 16;
+    if (bad) atomicOr(out, bad);
+}
+
+}  // namespace sls
+
+using namespace sls;
+
+extern "C" {
+
+const char *sls_last_error(void) { return g_err; }
+int sls_version(void) { return 100; }
+int sls_tile_w(void) { return kTileW; }
+int sls_tile_h(void) { return kTileH; }
+int sls_rec_stride(void) { return SLS_REC_STRIDE; }
+int sls_grec_stride(void) { return SLS_GREC_STRIDE; }
+
+int sls_camera_from_matrices(const float *view, const float *proj, int H, int W, float scale_modifier,
+                             SlsCamera *out)
+{
+    SLS_REQUIRE(view && proj && out, "null pointer");
+    SLS_REQUIRE(H > 0 && W > 0, "image size must be positive");
+    memset(out, 0, sizeof(*out));
+    out->H = H; out->W = W;
+    // K = proj[:3,:3]^T  (scene/cameras.py:47-50), row-major proj[r*4+c]
+    const float k01 = proj[1 * 4 + 0], k10 = proj[0 * 4 + 1];
+    SLS_REQUIRE(k01 == 0.0f && k10 == 0.0f, "skewed intrinsics are not supported");
+    out->fx = proj[0 * 4 + 0];
+    out->fy = proj[1 * 4 + 1];
+    out->cx = proj[2 * 4 + 0];
+    out->cy = proj[2 * 4 + 1];
+    SLS_REQUIRE(out->fx != 0.0f && out->fy != 0.0f, "fx and fy must be non-zero");
+    // p_view = R_vw p + t, R_vw = view[:3,:3]^T, t = view[3,:3]  (scene/cameras.py:43-46)
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out->Rvw[3 * r + c] = view[c * 4 + r];
+    for (int c = 0; c < 3; ++c) out->tvw[c] = view[3 * 4 + c];
+    out->scale_modifier = scale_modifier;
+    out->near_cut = SLS_NEAR;
+    out->far_cut = SLS_FAR;
+    // D5: 360-degree image <=> |fx| * 2pi == W (within a pixel) and whole tiles per row
+    const double period = fabs((double)out->fx) * 2.0 * 3.14159265358979323846;
+    out->wrap = (fabs(period - (double)W) <= 1.0 && (W % kTileW) == 0) ? 1 : 0;
+    return SLS_OK;
+}
+
+int sls_ray_tables(const SlsCamera *cam, float *col_cs, float *row_cs)
+{
+    SLS_REQUIRE(cam && col_cs && row_cs, "null pointer");
+    for (int c = 0; c < cam->W; ++c) {
+        const double a = ((double)c - (double)cam->cx) / (double)cam->fx;
+        col_cs[2 * c] = (float)cos(a);
+        col_cs[2 * c + 1] = (float)sin(a);
+    }
+    for (int r = 0; r < cam->H; ++r) {
+        const double e = ((double)r - (double)cam->cy) / (double)cam->fy;
+        row_cs[2 * r] = (float)cos(e);
+        row_cs[2 * r + 1] = (float)sin(e);
+    }
+    return SLS_OK;
+}
+
+size_t sls_stage1_scratch_bytes(int N) { return sizeof(uint32_t) * (size_t)((N > 0 ? (N + 255) / 256 : 0) + 1); }
+
+int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const float *scales,
+                       const float *rotations, const float *opacities, float *rec, int32_t *radii, int32_t *rect,
+                       uint32_t *tiles_touched, float *depth, uint32_t *offsets, uint32_t *total_out,
+                       void *scratch, size_t scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(cam && total_out, "null pointer");
+    SLS_REQUIRE(N >= 0, "negative N");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        SLS_HIP_CHECK(hipMemsetAsync(total_out, 0, sizeof(uint32_t), st));
+        return SLS_OK;
+    }
+    SLS_REQUIRE(means3D && scales && rotations && opacities && rec && radii && rect && tiles_touched && depth &&
+                    offsets && scratch,
+                "null pointer");
+    if (scratch_bytes < sls_stage1_scratch_bytes(N)) {
+        set_error("stage1 scratch too small");
+        return SLS_E_SCRATCH;
+    }
+    const DevCam dc = make_devcam(*cam);
+    return launch_preprocess_fwd(dc, N, means3D, scales, rotations, opacities, rec, radii, rect, tiles_touched,
+                                 depth, offsets, total_out, (uint32_t *)scratch, st);
+}
+
+size_t sls_sort_scratch_bytes(uint64_t R) { return sort_scratch_bytes(R); }
+
+int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec, const int32_t *rect,
+                       const uint32_t *tiles_touched, const float *depth, const uint32_t *offsets, uint64_t *keys,
+                       uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, void *sort_scratch,
+                       size_t sort_scratch_bytes_, int *sorted_in_tmp, uint32_t *ranges, const float *col_cs,
+                       const float *row_cs, float *allmap, float *pix_state, uint32_t *pix_contrib,
+                       uint32_t *tile_consumed, void *stream)
+{
+    SLS_REQUIRE(cam && sorted_in_tmp && ranges && col_cs && row_cs && allmap && pix_state && pix_contrib,
+                "null pointer");
+    SLS_REQUIRE(R == 0 || (rec && rect && tiles_touched && depth && offsets && keys && vals && keys_tmp &&
+                           vals_tmp && sort_scratch),
+                "null pointer");
+    SLS_REQUIRE(R < (1ull << 32), "more than 2^32 tile instances");
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    int rc = launch_bin_sort(dc, N, R, rect, tiles_touched, depth, offsets, keys, vals, keys_tmp, vals_tmp,
+                             sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges, st);
+    if (rc) return rc;
+    const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
+    return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
+                             tile_consumed, st);
+}
+
+int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
+                 const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
+                 const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
+                 const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, float *dL_dmeans3D,
+                 float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream)
+{
+    SLS_REQUIRE(cam, "null pointer");
+    SLS_REQUIRE(N >= 0, "negative N");
+    if (N == 0) return SLS_OK;
+    SLS_REQUIRE(means3D && scales && rotations && radii && grec && dL_dmeans3D && dL_dscales && dL_drotations &&
+                    dL_dopacities,
+                "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    {
+        ScopedTimer tm(T_GREC_MEMSET, st);
+        SLS_HIP_CHECK(hipMemsetAsync(grec, 0, sizeof(float) * (size_t)N * SLS_GREC_STRIDE, st));
+    }
+    if (R > 0) {
+        SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
+                    "null pointer");
+        int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
+                                   grec, st);
+        if (rc) return rc;
+    }
+    return launch_preprocess_bwd(dc, N, means3D, scales, rotations, radii, grec, dL_dmeans3D, dL_dscales,
+                                 dL_drotations, dL_dopacities, st);
+}
+
+int sls_adam_step(const SlsAdamGroup *groups, int ngroups, float beta1, float beta2, float eps, int64_t step,
+                  void *stream)
+{
+    SLS_REQUIRE(groups && ngroups > 0 && ngroups <= kMaxAdamGroups, "1..8 groups");
+    SLS_REQUIRE(step >= 1, "step is 1-based");
+    AdamArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t units = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        SLS_REQUIRE(groups[i].numel >= 0, "negative numel");
+        SLS_REQUIRE(groups[i].numel == 0 || (groups[i].param && groups[i].grad && groups[i].exp_avg && groups[i].exp_avg_sq),
+                    "null tensor");
+        a.g[i] = groups[i];
+        units += (groups[i].numel + 3) / 4;
+        a.unit_end[i] = units;
+    }
+    for (int i = ngroups; i < kMaxAdamGroups; ++i) a.unit_end[i] = units;
+    a.ngroups = ngroups;
+    a.w1 = (float)(1.0 - (double)beta1);
+    a.b2 = beta2;
+    a.w2 = (float)(1.0 - (double)beta2);
+    a.eps = eps;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    if (units == 0) return SLS_OK;
+    int64_t blocks = (units + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond
+    {
+        ScopedTimer tm(T_ADAM, (hipStream_t)stream);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units);
+    }
+    SLS_LAUNCH_CHECK("adam_kernel");
+    return SLS_OK;
+}
+
+size_t sls_knn_scratch_bytes(int M) { return knn_scratch_bytes(M); }
+
+int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(M >= 0, "negative M");
+    if (M == 0) return SLS_OK;
+    SLS_REQUIRE(xyz && out && scratch, "null pointer");
+    return launch_knn(M, xyz, out, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t *visible, void *stream)
+{
+    SLS_REQUIRE(cam && N >= 0, "bad argument");
+    if (N == 0) return SLS_OK;
+    SLS_REQUIRE(means3D && visible, "null pointer");
+    return launch_mark_visible(make_devcam(*cam), N, means3D, visible, (hipStream_t)stream);
+}
+
+int sls_timing_slots(void) { return T_COUNT; }
+const char *sls_timing_name(int slot) { return (slot >= 0 && slot < T_COUNT) ? kTimerNames[slot] : ""; }
+
+int sls_timing_enable(int on)
+{
+    if (on && g_timer.created == 0) {
+        for (int i = 0; i < kTimerPool; ++i) {
+            if (hipEventCreate(&g_timer.start[i]) != hipSuccess || hipEventCreate(&g_timer.stop[i]) != hipSuccess) break;
+            g_timer.created = i + 1;
+        }
+    }
+    g_timer.enabled = on != 0;
+    g_timer.used = 0;
+    return SLS_OK;
+}
+
+int sls_timing_collect(double *total_ms, int64_t *counts)
+{
+    SLS_REQUIRE(total_ms && counts, "null pointer");
+    for (int s = 0; s < T_COUNT; ++s) { total_ms[s] = 0.0; counts[s] = 0; }
+    for (int i = 0; i < g_timer.used; ++i) {
+        SLS_HIP_CHECK(hipEventSynchronize(g_timer.stop[i]));
+        float ms = 0.0f;
+        SLS_HIP_CHECK(hipEventElapsedTime(&ms, g_timer.start[i], g_timer.stop[i]));
+        total_ms[g_timer.slot[i]] += (double)ms;
+        counts[g_timer.slot[i]] += 1;
+    }
+    const int dropped = (g_timer.used >= g_timer.created) ? 1 : 0;
+    g_timer.used = 0;
+    return dropped ? 1 : SLS_OK;   // 1: pool exhausted, later launches were not timed
+}
+
+int sls_selftest(void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int *d = nullptr;
+    SLS_HIP_CHECK(hipMalloc(&d, sizeof(int)));   // test-only entry point: the one place the library allocates
+    int h = 0;
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_kernel, dim3(2), dim3(128), 0, st, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        set_error("selftest: %s", hipGetErrorString(e));
+        return SLS_E_HIP;
+    }
+    if (h != 0) {
+        set_error("selftest: wave primitive mismatch, flags 0x%x", h);
+        return SLS_E_HIP;
+    }
+    return SLS_OK;
+}
+
+}  // extern "C"

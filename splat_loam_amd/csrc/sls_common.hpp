@@ -1,0 +1,135 @@
+// sls_common.hpp — shared by the HIP translation units of libsls_hip.so.
+// gfx950 only: wave = 64 lanes, DPP row_bcast available (GFX9 family).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sls_abi.h"
+#include "../../include/sls_spec.h"
+
+#ifndef SLS_TILE_W
+#define SLS_TILE_W 16
+#endif
+#ifndef SLS_TILE_H
+#define SLS_TILE_H 16
+#endif
+static_assert((SLS_TILE_W * SLS_TILE_H) % 64 == 0, "a tile must be a whole number of wave64s");
+static_assert(SLS_TILE_W % 8 == 0 && SLS_TILE_H % 8 == 0, "tiles are made of 8x8 wave sub-tiles");
+
+namespace sls {
+
+constexpr int kWave = 64;
+constexpr int kTileW = SLS_TILE_W;
+constexpr int kTileH = SLS_TILE_H;
+constexpr int kTilePix = kTileW * kTileH;
+constexpr int kRec4 = SLS_REC_STRIDE / 4;    // float4 per surfel record
+constexpr int kGrec = SLS_GREC_STRIDE;
+
+// thread-local error text behind sls_last_error()
+void set_error(const char *fmt, ...);
+
+// Optional per-kernel timing with HIP events recorded on the launch stream
+// (sls_timing_enable / sls_timing_collect, used by bench.py for the roofline
+// figures).  Disabled: zero cost beyond one branch per launch.
+enum TimerSlot {
+    T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT_KEYS, T_SORT_HIST, T_SORT_ROWSCAN, T_SORT_SCATTER, T_TILE_RANGES,
+    T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_COUNT
+};
+void timer_begin(int slot, hipStream_t st);
+void timer_end(int slot, hipStream_t st);
+struct ScopedTimer {
+    int slot; hipStream_t st;
+    ScopedTimer(int s, hipStream_t t) : slot(s), st(t) { timer_begin(slot, st); }
+    ~ScopedTimer() { timer_end(slot, st); }
+};
+
+#define SLS_HIP_CHECK(expr)                                                         \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            ::sls::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                   \
+            return SLS_E_HIP;                                                       \
+        }                                                                           \
+    } while (0)
+
+#define SLS_LAUNCH_CHECK(name)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            ::sls::set_error("launch of %s failed: %s", name, hipGetErrorString(e_));       \
+            return SLS_E_HIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+#define SLS_REQUIRE(cond, msg)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            ::sls::set_error("%s: %s", __func__, msg); \
+            return SLS_E_ARG;                        \
+        }                                            \
+    } while (0)
+
+// Device copy of the camera, passed by value as a kernel argument.
+struct DevCam {
+    int H, W, wrap, GX, GY;
+    float fx, fy, cx, cy, mod, near_c, far_c;
+    float R[9];
+    float t[3];
+};
+
+inline DevCam make_devcam(const SlsCamera &c)
+{
+    DevCam d;
+    d.H = c.H; d.W = c.W; d.wrap = c.wrap;
+    d.GX = (c.W + kTileW - 1) / kTileW;
+    d.GY = (c.H + kTileH - 1) / kTileH;
+    d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+    d.mod = c.scale_modifier; d.near_c = c.near_cut; d.far_c = c.far_cut;
+    for (int i = 0; i < 9; ++i) d.R[i] = c.Rvw[i];
+    for (int i = 0; i < 3; ++i) d.t[i] = c.tvw[i];
+    return d;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// One DPP move: returns src permuted by CTRL; lanes whose row is masked off
+// or whose source is invalid receive 0.0f.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 ONLY.
+// 6 DPP-modified adds, no LDS traffic (GFX9 row_bcast15/31).
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += dpp_mov0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov0<0x124, 0xF>(v);  // row_ror:4
+    v += dpp_mov0<0x128, 0xF>(v);  // row_ror:8  -> every lane holds its row's sum
+    v += dpp_mov0<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+    v += dpp_mov0<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ float readlane63(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8
+// (speed only, never correctness); give each XCD a contiguous run of tiles so
+// neighbouring tiles, which share surfel records, share an L2.
+__host__ __device__ inline int xcd_remap(int b, int n)
+{
+    constexpr int kXcd = 8;
+    if (n % kXcd != 0) return b;
+    const int per = n / kXcd;
+    return (b % kXcd) * per + b / kXcd;
+}
+
+}  // namespace sls

@@ -1,0 +1,400 @@
+// sls_preprocess.hip — per-surfel kernels (N threads): 3D -> spherical
+// projection and record build (A1), the tiles-touched scan (A2), the
+// gradient chain back to means/scales/rotations/opacities (A8) and
+// mark_visible (A9).  SURVEY.md §8a; maths in DESIGN.md §2.
+//
+// HBM-bound, trivially parallel.  Built with -ffp-contract=off and only
+// exactly-rounded operations (include/sls_det_math.h) so that every INTEGER
+// this stage emits — tile rectangle, tiles_touched, radii, depth-key bits —
+// is reproducible bit for bit by a CPU checker.
+#include "sls_common.hpp"
+#include "../../include/sls_det_math.h"
+
+namespace sls {
+
+__device__ __forceinline__ float dot3(const float *a, const float *b)
+{
+    return fmaf(a[0], b[0], fmaf(a[1], b[1], a[2] * b[2]));
+}
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+__device__ __forceinline__ void matvec(const float *M, const float *v, float *o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = dot3(M + 3 * i, v);
+}
+__device__ __forceinline__ void matTvec(const float *M, const float *v, float *o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = fmaf(M[i], v[0], fmaf(M[3 + i], v[1], M[6 + i] * v[2]));
+}
+__device__ __forceinline__ int floordiv_i(int a, int b)
+{
+    int q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+__device__ __forceinline__ int posmod_i(int a, int b)
+{
+    int m = a % b;
+    return m < 0 ? m + b : m;
+}
+__device__ __forceinline__ int to_int_clamped(float v)
+{
+    v = fminf(fmaxf(v, -1.0e9f), 1.0e9f);
+    return (int)v;
+}
+// quaternion (w,x,y,z) -> columns of R(q) (utils/general_utils.py:13-37, no
+// re-normalisation: callers pass F.normalize'd rotations).
+__device__ __forceinline__ void quat_axes(const float4 q, float *tu, float *tv, float *tn)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    tu[0] = 1.0f - 2.0f * fmaf(y, y, z * z);
+    tu[1] = 2.0f * fmaf(x, y, r * z);
+    tu[2] = 2.0f * fmaf(x, z, -(r * y));
+    tv[0] = 2.0f * fmaf(x, y, -(r * z));
+    tv[1] = 1.0f - 2.0f * fmaf(x, x, z * z);
+    tv[2] = 2.0f * fmaf(y, z, r * x);
+    tn[0] = 2.0f * fmaf(x, z, r * y);
+    tn[1] = 2.0f * fmaf(y, z, -(r * x));
+    tn[2] = 1.0f - 2.0f * fmaf(x, x, y * y);
+}
+// Angular half-extents (elevation theta, azimuth daz) of a ball of radius rad
+// centred at range rho / horizontal range rxy, seen from the origin (D4).
+__device__ __forceinline__ void ball_extent(float rad, float rho, float rxy, float &theta, float &daz)
+{
+    if (!(rad < rho)) { theta = SLS_PI; daz = SLS_PI; return; }
+    theta = sls_asin01(rad / rho);
+    const float q = rad / rxy;
+    if (!(q < 1.0f)) daz = SLS_PI;
+    else daz = sls_asin01(q);
+}
+
+struct SurfelGeom {
+    float p[3], rho, rho2, rxy, rxy2;
+    float Tu[3], Tv[3], Tn[3], n[3], A[3], B[3], Hu[3], Hv[3];
+    float su, sv, sig, c;
+};
+
+// Shared by forward and backward so both see identical intermediates.
+__device__ __forceinline__ void surfel_geom(const DevCam &cam, const float *m, const float2 s, const float4 q,
+                                            SurfelGeom &g)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        g.p[k] = fmaf(cam.R[3 * k], m[0], fmaf(cam.R[3 * k + 1], m[1], fmaf(cam.R[3 * k + 2], m[2], cam.t[k])));
+    g.rxy2 = fmaf(g.p[0], g.p[0], g.p[1] * g.p[1]);
+    g.rho2 = fmaf(g.p[2], g.p[2], g.rxy2);
+    g.rho = sqrtf(g.rho2);
+    g.rxy = sqrtf(g.rxy2);
+    float tu[3], tv[3], tn[3];
+    quat_axes(q, tu, tv, tn);
+    matvec(cam.R, tu, g.Tu);
+    matvec(cam.R, tv, g.Tv);
+    matvec(cam.R, tn, g.Tn);
+    g.su = s.x * cam.mod;
+    g.sv = s.y * cam.mod;
+    g.c = dot3(g.Tn, g.p);
+    g.sig = (g.c > 0.0f) ? -1.0f : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.n[k] = g.sig * g.Tn[k];
+        g.A[k] = (g.sig * g.Tv[k]) / g.su;
+        g.B[k] = (-g.sig * g.Tu[k]) / g.sv;
+    }
+    cross3(g.A, g.p, g.Hu);
+    cross3(g.B, g.p, g.Hv);
+}
+
+// ---------------------------------------------------------------------------
+// A1 forward preprocess.  One thread per surfel; 256-thread blocks; each block
+// also reduces its tiles_touched into block_sums[] (first level of the scan).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
+    DevCam cam, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
+    const float4 *__restrict__ rots, const float *__restrict__ opac,
+    float4 *__restrict__ rec, int *__restrict__ radii, int4 *__restrict__ rect,
+    uint32_t *__restrict__ tiles, float *__restrict__ depth, uint32_t *__restrict__ block_sums)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (i < N) {
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+        int r_out = 0;
+        int4 rc = make_int4(0, 0, 0, 0);
+        float dep = 0.0f;
+
+        const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
+        const float2 s = scales[i];
+        const float4 q = rots[i];
+        const float o = opac[i];
+        SurfelGeom g;
+        surfel_geom(cam, m, s, q, g);
+        bool vis = (g.rho >= cam.near_c) && (g.rho < 1.0e18f);  // D2 near cut; NaN/inf fail
+        if (vis) {
+            const float az = sls_atan2(g.p[1], g.p[0]);
+            const float el = sls_atan2(g.p[2], g.rxy);
+            const float cpx = fmaf(cam.fx, az, cam.cx), cpy = fmaf(cam.fy, el, cam.cy);
+            const float smax = fmaxf(g.su, g.sv);
+            float theta, daz;
+            ball_extent(SLS_CUTOFF * smax, g.rho, g.rxy, theta, daz);
+            const float rx = fmaxf(fabsf(cam.fx) * daz, SLS_RMIN_PX);
+            const float ry = fmaxf(fabsf(cam.fy) * theta, SLS_RMIN_PX);
+            int xlo = to_int_clamped(floorf(cpx - rx + 0.5f));
+            int xhi = to_int_clamped(floorf(cpx + rx + 0.5f));
+            int ylo = to_int_clamped(floorf(cpy - ry + 0.5f));
+            int yhi = to_int_clamped(floorf(cpy + ry + 0.5f));
+            ylo = max(ylo, 0);
+            yhi = min(yhi, cam.H - 1);
+            int txlo = 0, ncols = 0;
+            if (ylo > yhi) vis = false;
+            if (vis) {
+                if (cam.wrap) {
+                    if ((long long)xhi - (long long)xlo + 1 >= (long long)cam.W) { txlo = 0; ncols = cam.GX; }
+                    else {
+                        const int a = floordiv_i(xlo, kTileW), b = floordiv_i(xhi, kTileW);
+                        ncols = min(b - a + 1, cam.GX);
+                        txlo = posmod_i(a, cam.GX);
+                    }
+                } else {
+                    xlo = max(xlo, 0);
+                    xhi = min(xhi, cam.W - 1);
+                    if (xlo > xhi) vis = false;
+                    else { txlo = xlo / kTileW; ncols = xhi / kTileW - txlo + 1; }
+                }
+            }
+            if (vis) {
+                const int tylo = ylo / kTileH, nrows = yhi / kTileH - tylo + 1;
+                rc = make_int4(txlo, ncols, tylo, nrows);
+                my_tiles = (uint32_t)(ncols * nrows);
+                r_out = to_int_clamped(ceilf(fmaxf(rx, ry)));
+                dep = g.rho;
+                // Conservative support half-extents for the wave-level cull in the
+                // tile kernels: a pixel can only receive alpha >= 1/255 if
+                // rho <= rho_max = 2 ln(255 o); in the 3D branch the hit lies inside
+                // the ball of radius sqrt(rho_max)*smax around p, in the 2D branch
+                // within sqrt(rho_max/2) px of the centre.  Never changes a result.
+                float ex = -1.0e30f, ey = -1.0e30f;
+                const float lo = 255.0f * o;
+                if (lo > 1.0f) {
+                    const float rho_max = 2.0f * logf(lo) * 1.001f + 1.0e-3f;
+                    float th2, daz2;
+                    ball_extent(sqrtf(rho_max) * smax, g.rho, g.rxy, th2, daz2);
+                    const float r2 = sqrtf(0.5f * rho_max);
+                    ex = fmaxf(fabsf(cam.fx) * daz2, r2) * 1.001f + 0.05f;
+                    ey = fmaxf(fabsf(cam.fy) * th2, r2) * 1.001f + 0.05f;
+                }
+                q0 = make_float4(g.Hu[0], g.Hu[1], g.Hu[2], g.sig * g.c);
+                q1 = make_float4(g.Hv[0], g.Hv[1], g.Hv[2], g.rho);
+                q2 = make_float4(g.n[0], g.n[1], g.n[2], o);
+                q3 = make_float4(g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho, 0.0f);
+                q4 = make_float4(cpx, cpy, ex, ey);
+            }
+        }
+        float4 *r = rec + (size_t)i * kRec4;
+        r[0] = q0; r[1] = q1; r[2] = q2; r[3] = q3; r[4] = q4;
+        radii[i] = r_out;
+        rect[i] = rc;
+        tiles[i] = my_tiles;
+        depth[i] = dep;
+    }
+    // block reduction of tiles_touched
+    __shared__ uint32_t s_part[4];
+    uint32_t v = my_tiles;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// A2, level 2: one block turns block_sums[] into exclusive prefixes in place
+// and publishes the grand total R.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *block_sums, int nblocks, uint32_t *total_out)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < nblocks) block_sums[i] = carry + wave_prefix + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+// A2, level 3: inclusive scan inside each 256-surfel block + block prefix.
+__global__ __launch_bounds__(256) void scan_final_kernel(const uint32_t *__restrict__ tiles,
+                                                         const uint32_t *__restrict__ block_prefix,
+                                                         uint32_t *__restrict__ offsets, int N)
+{
+    __shared__ uint32_t s_wave[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v = (i < N) ? tiles[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_prefix = 0;
+    for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+    if (i < N) offsets[i] = block_prefix[blockIdx.x] + wave_prefix + incl;
+}
+
+// ---------------------------------------------------------------------------
+// A8 preprocess backward: gradient record (sls_spec.h) -> input gradients.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(
+    DevCam cam, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
+    const float4 *__restrict__ rots, const int *__restrict__ radii, const float4 *__restrict__ grec,
+    float *__restrict__ dmeans, float2 *__restrict__ dscales, float4 *__restrict__ drots,
+    float *__restrict__ dopac)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float dm[3] = { 0, 0, 0 };
+    float2 ds = make_float2(0, 0);
+    float4 dq = make_float4(0, 0, 0, 0);
+    float dop = 0.0f;
+    if (radii[i] > 0) {
+        const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
+        const float2 s = scales[i];
+        const float4 q = rots[i];
+        SurfelGeom g;
+        surfel_geom(cam, m, s, q, g);
+        const float4 g0 = grec[(size_t)i * 4 + 0], g1 = grec[(size_t)i * 4 + 1];
+        const float4 g2 = grec[(size_t)i * 4 + 2], g3 = grec[(size_t)i * 4 + 3];
+        const float gHu[3] = { g0.x, g0.y, g0.z }, gHv[3] = { g1.x, g1.y, g1.z }, gn[3] = { g2.x, g2.y, g2.z };
+        const float gnpv = g0.w, grhoc = g1.w, go = g2.w, Su = g3.x, Sv = g3.y, gcpx = g3.z, gcpy = g3.w;
+        float dc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dc[k] = g.p[k] / g.rho;
+        float dp[3], dA[3], dB[3], t1[3], t2[3];
+        cross3(g.p, gHu, dA); cross3(gHu, g.A, t1);
+        cross3(g.p, gHv, dB); cross3(gHv, g.B, t2);
+        float dTu[3], dTv[3], dTn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dp[k] = t1[k] + t2[k];
+            dTv[k] = g.sig * dA[k] / g.su;
+            dTu[k] = -g.sig * dB[k] / g.sv;
+        }
+        const float dsu = -dot3(dA, g.A) / g.su, dsv = -dot3(dB, g.B) / g.sv;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dTn[k] = g.sig * (gn[k] + gnpv * g.p[k]);
+            dp[k] += gnpv * g.n[k];
+            dp[k] += grhoc * dc[k];
+        }
+        float gdc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gdc[k] = -(Su * g.Hu[k] + Sv * g.Hv[k]);
+        const float gd = dot3(gdc, dc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dp[k] += (gdc[k] - gd * dc[k]) / g.rho;
+        if (g.rxy2 > 1e-30f) {
+            const float gaz = gcpx * cam.fx, gel = gcpy * cam.fy;
+            dp[0] += gaz * (-g.p[1] / g.rxy2) + gel * (-g.p[2] * g.p[0] / (g.rxy * g.rho2));
+            dp[1] += gaz * (g.p[0] / g.rxy2) + gel * (-g.p[2] * g.p[1] / (g.rxy * g.rho2));
+            dp[2] += gel * (g.rxy / g.rho2);
+        }
+        matTvec(cam.R, dp, dm);
+        ds = make_float2(cam.mod * dsu, cam.mod * dsv);
+        dop = go;
+        float G0[3], G1[3], G2[3];
+        matTvec(cam.R, dTu, G0); matTvec(cam.R, dTv, G1); matTvec(cam.R, dTn, G2);
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        // G[i][j] = dL/dR_ij, column j in {tu, tv, tn}: Gj[i]
+        dq.x = 2.0f * (-z * G1[0] + y * G2[0] + z * G0[1] - x * G2[1] - y * G0[2] + x * G1[2]);
+        dq.y = 2.0f * (y * G1[0] + z * G2[0] + y * G0[1] - 2.0f * x * G1[1] - r * G2[1] + z * G0[2] + r * G1[2] - 2.0f * x * G2[2]);
+        dq.z = 2.0f * (-2.0f * y * G0[0] + x * G1[0] + r * G2[0] + x * G0[1] + z * G2[1] - r * G0[2] + z * G1[2] - 2.0f * y * G2[2]);
+        dq.w = 2.0f * (-2.0f * z * G0[0] - r * G1[0] + x * G2[0] + r * G0[1] - 2.0f * z * G1[1] + y * G2[1] + x * G0[2] + y * G1[2]);
+    }
+    dmeans[3 * i] = dm[0]; dmeans[3 * i + 1] = dm[1]; dmeans[3 * i + 2] = dm[2];
+    dscales[i] = ds;
+    drots[i] = dq;
+    dopac[i] = dop;
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(DevCam cam, int N, const float *__restrict__ means,
+                                                           uint8_t *__restrict__ visible)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        p[k] = fmaf(cam.R[3 * k], means[3 * i], fmaf(cam.R[3 * k + 1], means[3 * i + 1], fmaf(cam.R[3 * k + 2], means[3 * i + 2], cam.t[k])));
+    const float rho = sqrtf(fmaf(p[2], p[2], fmaf(p[0], p[0], p[1] * p[1])));
+    visible[i] = (rho >= cam.near_c && rho < 1.0e18f) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers used by sls_api.hip
+// ---------------------------------------------------------------------------
+int launch_preprocess_fwd(const DevCam &cam, int N, const float *means, const float *scales, const float *rots,
+                          const float *opac, float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles,
+                          float *depth, uint32_t *offsets, uint32_t *total_out, uint32_t *block_sums,
+                          hipStream_t st)
+{
+    const int nb = (N + 255) / 256;
+    {
+    ScopedTimer tm(T_PREPROCESS_FWD, st);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, N, means, (const float2 *)scales,
+                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, block_sums);
+    }
+    SLS_LAUNCH_CHECK("preprocess_fwd_kernel");
+    ScopedTimer tm2(T_SCAN, st);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, total_out);
+    SLS_LAUNCH_CHECK("scan_block_sums_kernel");
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(256), 0, st, tiles, block_sums, offsets, N);
+    SLS_LAUNCH_CHECK("scan_final_kernel");
+    return SLS_OK;
+}
+
+int launch_preprocess_bwd(const DevCam &cam, int N, const float *means, const float *scales, const float *rots,
+                          const int32_t *radii, const float *grec, float *dmeans, float *dscales, float *drots,
+                          float *dopac, hipStream_t st)
+{
+    const int nb = (N + 255) / 256;
+    ScopedTimer tm(T_PREPROCESS_BWD, st);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, N, means, (const float2 *)scales,
+                       (const float4 *)rots, radii, (const float4 *)grec, dmeans, (float2 *)dscales,
+                       (float4 *)drots, dopac);
+    SLS_LAUNCH_CHECK("preprocess_bwd_kernel");
+    return SLS_OK;
+}
+
+int launch_mark_visible(const DevCam &cam, int N, const float *means, uint8_t *visible, hipStream_t st)
+{
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(nb), dim3(256), 0, st, cam, N, means, visible);
+    SLS_LAUNCH_CHECK("mark_visible_kernel");
+    return SLS_OK;
+}
+
+}  // namespace sls

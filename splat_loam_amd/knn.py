@@ -1,0 +1,34 @@
+"""distCUDA2: mean squared distance to the 3 nearest neighbours (simple-knn).
+
+Same name and contract as `simple_knn._C.distCUDA2` used at
+slam/mapper.py:113-115 and scene/gaussian_model.py:77-81: (M,3) float32 device
+tensor -> (M,) float32.  Runs in libsls_hip.so (sls_knn_dist2); no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+
+
+def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+    if not points.is_cuda:
+        raise RuntimeError("distCUDA2 needs a ROCm device tensor (libsls_hip.so); there is no CPU fallback")
+    lib = _abi.lib()
+    pts = points.detach()
+    if pts.dtype != torch.float32:
+        pts = pts.float()
+    pts = pts.contiguous()
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise ValueError("points must be (M,3)")
+    M = int(pts.shape[0])
+    out = torch.empty((M,), dtype=torch.float32, device=pts.device)
+    if M == 0:
+        return out
+    nbytes = int(lib.sls_knn_scratch_bytes(M))
+    scratch = torch.empty((nbytes + 256,), dtype=torch.uint8, device=pts.device)
+    base = scratch.data_ptr()
+    aligned = (base + 255) & ~255
+    _abi.check(lib.sls_knn_dist2(M, pts.data_ptr(), out.data_ptr(), aligned, nbytes,
+                                 torch.cuda.current_stream(pts.device).cuda_stream), "sls_knn_dist2")
+    return out

@@ -1,0 +1,87 @@
+"""The mapper's optimisation step (loss of slam/mapper.py:158-201 + Adam step
+:204) restated on top of renderer.render, plus the keyframe-parallel variant
+that shards independent keyframe renders one-per-GPU and all-reduces the
+gradients (not present in the single-GPU reference).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+from .renderer import render
+
+
+@dataclass
+class MappingConfig:
+    # configs/kitti/kitti-00-odom.yaml:18-21
+    opt_lambda_alpha: float = 0.4
+    opt_lambda_normal: float = 0.5
+    opt_scaling_max: float = 0.1
+    opt_scaling_max_penalty: float = 1.0
+    depth_ratio: float = 0.0
+
+
+def mapping_loss(render_pkg: dict, camera, model, cfg: MappingConfig) -> torch.Tensor:
+    """slam/mapper.py:158-199."""
+    est_alpha, est_depth = render_pkg["rend_alpha"], render_pkg["surf_depth"]
+    est_normal, surf_normal = render_pkg["rend_normal"], render_pkg["surf_normal"]
+    gt_alpha, gt_depth = camera.image_valid, camera.image_depth
+    valid = gt_alpha[0] == 1.0
+    geom_l1 = torch.abs(valid * (est_depth - gt_depth)).mean()
+    normal_loss = (1 - (est_normal[..., valid] * surf_normal[..., valid]).sum(dim=0)).mean()
+    normal_loss = normal_loss * cfg.opt_lambda_normal
+    alpha_loss = torch.nn.functional.binary_cross_entropy(
+        est_alpha[..., valid], gt_alpha[..., valid].float(), reduction="mean") * cfg.opt_lambda_alpha
+    scales_max = model.get_scaling.max(dim=1).values
+    over = scales_max[scales_max >= cfg.opt_scaling_max] - cfg.opt_scaling_max
+    reg_scales = (cfg.opt_scaling_max_penalty * over).sum()
+    return geom_l1 + alpha_loss + normal_loss + reg_scales
+
+
+def optimize_step(model, camera, cfg: MappingConfig) -> torch.Tensor:
+    """One iteration of Mapper.optimize (slam/mapper.py:150-204) for one keyframe."""
+    model.optimizer.zero_grad(set_to_none=True)
+    pkg = render(camera, model, cfg.depth_ratio)
+    loss = mapping_loss(pkg, camera, model, cfg)
+    loss.backward()
+    with torch.no_grad():
+        model.optimizer.step()
+    return loss.detach()
+
+
+def flat_grad_allreduce(model, group=None, average: bool = False) -> None:
+    """all-reduce(SUM) of the four gradient tensors as ONE flat bucket
+    (40 B/surfel: 20 MB at 500k) — a single large collective suits xGMI's
+    point-to-point links better than four small ones."""
+    params = [model._xyz, model._opacity, model._scaling, model._rotation]
+    grads = [p.grad for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def optimize_step_sharded(model, my_camera, cfg: MappingConfig, group=None, average: bool = False) -> torch.Tensor:
+    """Keyframe-parallel iteration: every rank renders ITS keyframe against the
+    replicated model, gradients are summed over ranks, every rank applies the
+    same Adam step (replicas stay bit-identical because the all-reduce result
+    is).  The keyframe-independent scale regulariser is counted once: rank 0
+    keeps it, the others drop it."""
+    model.optimizer.zero_grad(set_to_none=True)
+    pkg = render(my_camera, model, cfg.depth_ratio)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    local_cfg = cfg if rank == 0 else MappingConfig(**{**cfg.__dict__, "opt_scaling_max_penalty": 0.0})
+    loss = mapping_loss(pkg, my_camera, model, local_cfg)
+    loss.backward()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        flat_grad_allreduce(model, group, average)
+    with torch.no_grad():
+        model.optimizer.step()
+    return loss.detach()

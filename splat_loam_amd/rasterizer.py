@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's rasterizer interface.
+
+`GaussianRasterizationSettings` and `GaussianRasterizer` keep the names,
+argument meaning and call pattern of diff_surfel_spherical_rasterization as
+used by gaussian_renderer/__init__.py:16-47 (settings built with exactly these
+seven keywords; rasterizer built with `raster_settings=` and called with
+`means3D, means2D, opacities, scales, rotations, cov3D_precomp`, returning
+`(radii, allmap)`), so gaussian_renderer.render(), slam/mapper.py and
+slam/tracker.py run unmodified.  All arithmetic happens in libsls_hip.so
+(include/sls_abi.h); torch supplies device memory, the stream and autograd
+plumbing only.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _abi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    scale_modifier: float
+    viewmatrix: torch.Tensor   # (4,4) = inv(world_T_lidar)^T   scene/cameras.py:43-46
+    projmatrix: torch.Tensor   # (4,4), [:3,:3] = K^T            scene/cameras.py:47-50
+    prefiltered: bool = False
+    debug: bool = False
+
+
+# ---------------------------------------------------------------------------
+# camera cache: the two 4x4 matrices live on the device; copying them to the
+# host costs a sync, so do it once per (tensor, version).  Entries hold strong
+# references to the tensors, which keeps their addresses from being reused
+# while the entry is alive.
+# ---------------------------------------------------------------------------
+class _CamEntry:
+    __slots__ = ("cam", "col_cs", "row_cs", "view_ref", "proj_ref")
+
+
+_CAM_CACHE: "OrderedDict[tuple, _CamEntry]" = OrderedDict()
+_CAM_CACHE_MAX = 64
+_TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def _ray_tables(cam: _abi.SlsCamera, device: torch.device):
+    key = (cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, str(device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None:
+        _TABLE_CACHE.move_to_end(key)
+        return hit
+    col = torch.empty((cam.W, 2), dtype=torch.float32)
+    row = torch.empty((cam.H, 2), dtype=torch.float32)
+    _abi.check(_abi.lib().sls_ray_tables(C.byref(cam), col.data_ptr(), row.data_ptr()), "sls_ray_tables")
+    out = (col.to(device), row.to(device))
+    _TABLE_CACHE[key] = out
+    while len(_TABLE_CACHE) > 16:
+        _TABLE_CACHE.popitem(last=False)
+    return out
+
+
+def get_camera(settings: GaussianRasterizationSettings, device: torch.device) -> _CamEntry:
+    v, p = settings.viewmatrix, settings.projmatrix
+    key = (v.data_ptr(), v._version, p.data_ptr(), p._version, int(settings.image_height),
+           int(settings.image_width), float(settings.scale_modifier), str(device))
+    hit = _CAM_CACHE.get(key)
+    if hit is not None:
+        _CAM_CACHE.move_to_end(key)
+        return hit
+    vh = v.detach().to("cpu", torch.float32).contiguous()
+    ph = p.detach().to("cpu", torch.float32).contiguous()
+    if vh.shape != (4, 4) or ph.shape != (4, 4):
+        raise ValueError("viewmatrix and projmatrix must be 4x4")
+    e = _CamEntry()
+    e.cam = _abi.SlsCamera()
+    _abi.check(_abi.lib().sls_camera_from_matrices(vh.data_ptr(), ph.data_ptr(), int(settings.image_height),
+                                                   int(settings.image_width), float(settings.scale_modifier),
+                                                   C.byref(e.cam)), "sls_camera_from_matrices")
+    e.col_cs, e.row_cs = _ray_tables(e.cam, device)
+    e.view_ref, e.proj_ref = v, p
+    _CAM_CACHE[key] = e
+    while len(_CAM_CACHE) > _CAM_CACHE_MAX:
+        _CAM_CACHE.popitem(last=False)
+    return e
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the spherical surfel rasterizer runs only on a ROCm device "
+            "(libsls_hip.so); there is no CPU fallback")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class ForwardState:
+    """Everything the backward (and the tests) need from one forward."""
+    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "depth", "offsets", "keys", "vals",
+                 "ranges", "pix_state", "pix_contrib", "tile_consumed", "allmap")
+
+
+def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations) -> ForwardState:
+    """preprocess -> scan -> [host reads R] -> keys -> radix sort -> ranges -> render."""
+    for name, t in (("means3D", means3D), ("opacities", opacities), ("scales", scales), ("rotations", rotations)):
+        _need_cuda(t, name)
+    lib = _abi.lib()
+    dev = means3D.device
+    means3D, opacities, scales, rotations = map(_f32c, (means3D, opacities, scales, rotations))
+    N = int(means3D.shape[0])
+    if means3D.shape != (N, 3) or scales.shape != (N, 2) or rotations.shape != (N, 4) or opacities.numel() != N:
+        raise ValueError("expected means3D (N,3), scales (N,2), rotations (N,4), opacities (N,1)")
+    ce = get_camera(settings, dev)
+    cam = ce.cam
+    H, W = cam.H, cam.W
+    tw, th = _abi.tile_size()
+    T = ((W + tw - 1) // tw) * ((H + th - 1) // th)
+    st = _stream(dev)
+    debug = bool(settings.debug)
+
+    def dbg():
+        # debug=True: surface asynchronous kernel faults at the stage that caused them
+        if debug:
+            torch.cuda.synchronize(dev)
+
+    s = ForwardState()
+    s.cam, s.N = ce, N
+    i32, u32, f32 = torch.int32, torch.int32, torch.float32   # uint32 buffers are carried as int32 tensors
+    s.rec = torch.empty((N, lib.sls_rec_stride()), dtype=f32, device=dev)
+    s.radii = torch.empty((N,), dtype=i32, device=dev)
+    s.rect = torch.empty((N, 4), dtype=i32, device=dev)
+    s.tiles = torch.empty((N,), dtype=u32, device=dev)
+    s.depth = torch.empty((N,), dtype=f32, device=dev)
+    s.offsets = torch.empty((N,), dtype=u32, device=dev)
+    total = torch.zeros((1,), dtype=u32, device=dev)
+    sb = int(lib.sls_stage1_scratch_bytes(N))
+    scratch1 = torch.empty((max(sb, 4),), dtype=torch.uint8, device=dev)
+    _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
+                                      opacities.data_ptr(), s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
+                                      s.tiles.data_ptr(), s.depth.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
+                                      scratch1.data_ptr(), sb, st), "sls_forward_stage1")
+    dbg()
+    R = int(total.item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
+    s.R = R
+    Ra = max(R, 1)
+    keys_a = torch.empty((Ra,), dtype=torch.int64, device=dev)
+    keys_b = torch.empty((Ra,), dtype=torch.int64, device=dev)
+    vals_a = torch.empty((Ra,), dtype=u32, device=dev)
+    vals_b = torch.empty((Ra,), dtype=u32, device=dev)
+    ssb = int(lib.sls_sort_scratch_bytes(R))
+    sort_scratch = torch.empty((max(ssb, 4),), dtype=torch.uint8, device=dev)
+    s.ranges = torch.empty((T, 2), dtype=u32, device=dev)
+    s.allmap = torch.empty((7, H, W), dtype=f32, device=dev)
+    s.pix_state = torch.empty((H * W, 4), dtype=f32, device=dev)
+    s.pix_contrib = torch.empty((H * W, 2), dtype=u32, device=dev)
+    s.tile_consumed = torch.empty((T,), dtype=u32, device=dev)
+    in_tmp = C.c_int(0)
+    _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
+                                      s.depth.data_ptr(), s.offsets.data_ptr(), keys_a.data_ptr(), vals_a.data_ptr(),
+                                      keys_b.data_ptr(), vals_b.data_ptr(), sort_scratch.data_ptr(), ssb,
+                                      C.byref(in_tmp), s.ranges.data_ptr(), ce.col_cs.data_ptr(),
+                                      ce.row_cs.data_ptr(), s.allmap.data_ptr(), s.pix_state.data_ptr(),
+                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(), st), "sls_forward_stage2")
+    dbg()
+    if in_tmp.value:
+        s.keys, s.vals = keys_b, vals_b
+    else:
+        s.keys, s.vals = keys_a, vals_a
+    if R == 0:
+        s.keys, s.vals = s.keys[:0], s.vals[:0]
+    return s
+
+
+def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallmap):
+    lib = _abi.lib()
+    dev = means3D.device
+    N = state.N
+    f32 = torch.float32
+    dL = _f32c(dL_dallmap)
+    grec = torch.empty((N, lib.sls_grec_stride()), dtype=f32, device=dev)
+    dmeans = torch.empty((N, 3), dtype=f32, device=dev)
+    dscales = torch.empty((N, 2), dtype=f32, device=dev)
+    drots = torch.empty((N, 4), dtype=f32, device=dev)
+    dopac = torch.empty((N, 1), dtype=f32, device=dev)
+    ce = state.cam
+    _abi.check(lib.sls_backward(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
+                                rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
+                                state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
+                                ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
+                                dL.data_ptr(), grec.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(),
+                                drots.data_ptr(), dopac.data_ptr(), _stream(dev)), "sls_backward")
+    return dmeans, dscales, drots, dopac, grec
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, cov3D_precomp, raster_settings):
+        if cov3D_precomp is not None:
+            raise NotImplementedError("cov3D_precomp is not supported (the reference never passes it, "
+                                      "gaussian_renderer/__init__.py:46)")
+        if scales is None or rotations is None:
+            raise ValueError("scales and rotations are required")
+        m, o, s_, r = map(_f32c, (means3D.detach(), opacities.detach(), scales.detach(), rotations.detach()))
+        st = rasterize_forward(raster_settings, m, o, s_, r)
+        ctx.state = st
+        ctx.debug = bool(raster_settings.debug)
+        ctx.save_for_backward(m, s_, r)
+        ctx.mark_non_differentiable(st.radii)
+        # allmap is returned as a fresh tensor the caller may overwrite in place
+        # (gaussian_renderer/__init__.py:61-62,70-71); the backward never reads it.
+        return st.radii, st.allmap
+
+    @staticmethod
+    def backward(ctx, _grad_radii, grad_allmap):
+        m, s_, r = ctx.saved_tensors
+        st = ctx.state
+        if grad_allmap is None:
+            grad_allmap = torch.zeros_like(st.allmap)
+        dmeans, dscales, drots, dopac, _ = rasterize_backward(st, m, s_, r, grad_allmap)
+        if ctx.debug:
+            torch.cuda.synchronize(m.device)
+        return dmeans, None, dopac, dscales, drots, None, None
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        _need_cuda(positions, "positions")
+        with torch.no_grad():
+            p = _f32c(positions)
+            ce = get_camera(self.raster_settings, p.device)
+            vis = torch.empty((p.shape[0],), dtype=torch.uint8, device=p.device)
+            _abi.check(_abi.lib().sls_mark_visible(C.byref(ce.cam), int(p.shape[0]), p.data_ptr(), vis.data_ptr(),
+                                                   _stream(p.device)), "sls_mark_visible")
+        return vis.bool()
+
+    def forward(self, means3D, means2D, opacities, scales: Optional[torch.Tensor] = None,
+                rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
+        if (scales is None or rotations is None) == (cov3D_precomp is None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return _RasterizeGaussians.apply(means3D, means2D, opacities, scales, rotations, cov3D_precomp,
+                                         self.raster_settings)

@@ -1,0 +1,86 @@
+"""Minimal host-side mirrors of the two reference classes the render path
+touches: `Camera` (scene/cameras.py:10-50) and the parameter container /
+activation getters of `GaussianModel` (scene/gaussian_model.py:39-69,97-121).
+Only what the hot path reads is reproduced (attribute names identical), so the
+harness code in mapping.py reads like slam/mapper.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .optim import FusedAdam
+
+
+def inverse_sigmoid(x: torch.Tensor) -> torch.Tensor:
+    return torch.log(x / (1 - x))
+
+
+class Camera:
+    """One LiDAR keyframe: range / normal / valid images + the two matrices
+    (world_view_transform = inv(world_T_lidar)^T, projection_matrix[:3,:3] = K^T)."""
+
+    def __init__(self, K, image_depth, image_normal=None, image_valid=None, world_T_lidar=None,
+                 data_device="cuda"):
+        dev = torch.device(data_device)
+        self.data_device = dev
+        image_depth = np.asarray(image_depth, dtype=np.float32)
+        self.image_depth = torch.from_numpy(image_depth).to(dev)
+        self.image_height, self.image_width = int(image_depth.shape[1]), int(image_depth.shape[2])
+        if image_normal is None:
+            image_normal = np.zeros((3, self.image_height, self.image_width), np.float32)
+        if image_valid is None:
+            image_valid = np.ones((1, self.image_height, self.image_width), np.uint8)
+        self.image_normal = torch.from_numpy(np.asarray(image_normal, dtype=np.float32)).to(dev)
+        self.image_valid = torch.from_numpy(np.asarray(image_valid)).to(dev)
+        if world_T_lidar is None:
+            world_T_lidar = np.eye(4)
+        view = np.linalg.inv(np.asarray(world_T_lidar, dtype=np.float64)).astype(np.float32)
+        self.world_view_transform = torch.tensor(view).transpose(0, 1).contiguous().to(dev)
+        self.projection_matrix = torch.eye(4, dtype=torch.float32, device=dev)
+        self.projection_matrix[:3, :3] = torch.from_numpy(np.asarray(K, dtype=np.float32)).to(dev).transpose(0, 1)
+
+
+class SurfelModel:
+    """Raw (pre-activation) parameters + the reference's activations:
+    xyz identity, opacity sigmoid, scaling exp, rotation F.normalize."""
+
+    def __init__(self, xyz, scaling_raw, rotation_raw, opacity_raw, device="cuda"):
+        def par(a):
+            return nn.Parameter(torch.as_tensor(a, dtype=torch.float32).to(device).contiguous().requires_grad_(True))
+        self._xyz, self._scaling = par(xyz), par(scaling_raw)
+        self._rotation, self._opacity = par(rotation_raw), par(opacity_raw)
+        self.optimizer = None
+
+    @classmethod
+    def from_activated(cls, means, scales, rots, opac, device="cuda"):
+        means, scales, rots, opac = (torch.as_tensor(a, dtype=torch.float32) for a in (means, scales, rots, opac))
+        return cls(means, torch.log(scales), rots, inverse_sigmoid(opac.reshape(-1, 1)), device)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    def training_setup(self, position_lr=5e-4, opacity_lr=5e-2, scaling_lr=5e-3, rotation_lr=1e-3, fused=True):
+        """4 groups, eps 1e-15 (scene/gaussian_model.py:97-121; lrs utils/config_utils.py:180-183)."""
+        groups = [
+            {"params": [self._xyz], "lr": position_lr, "name": "xyz"},
+            {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": rotation_lr, "name": "rotation"},
+        ]
+        self.optimizer = (FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+        return self.optimizer

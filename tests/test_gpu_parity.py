@@ -1,0 +1,296 @@
+"""HIP path (through the C-ABI) vs the CPU checker on identical seeded inputs.
+
+Bar (BASELINE.json north_star): tile/key integers bit-exact; rendered
+depth/alpha/normal and all gradients <= 1e-5 relative (max-norm relative per
+channel / tensor; per-surfel gradient records relative to the sum of |terms|).
+Pixels where the checker flags a discrete decision within 1e-4 of its threshold
+("fragile": alpha vs 1/255, T vs 1e-4, rho3d vs rho2d, ...) are compared with a
+loose bound instead, because a 1-ulp different exp/rcp may legitimately decide
+the other way there.  "parity unpinned": the checker is this repo's restatement
+(oracle/sls_oracle.c header).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, hip_backward, hip_forward, rel_err, scene_and_camera, tangent, u32
+
+pytestmark = pytest.mark.gpu
+
+
+def test_selftest(device):
+    from splat_loam_amd import _abi
+    _abi.check(_abi.lib().sls_selftest(torch.cuda.current_stream(device).cuda_stream), "sls_selftest")
+
+
+def _compare_forward(oracle32, st, ost, cam, name):
+    pre = ost["pre"]
+    # ---- integers: bit-exact -------------------------------------------------
+    assert np.array_equal(st.radii.cpu().numpy(), pre["radii"]), f"{name}: radii"
+    assert np.array_equal(st.rect.cpu().numpy(), pre["rect"]), f"{name}: rect"
+    assert np.array_equal(u32(st.tiles), pre["tiles"]), f"{name}: tiles_touched"
+    assert np.array_equal(u32(st.depth), pre["depth"].view(np.uint32)), f"{name}: depth key bits"
+    assert st.R == ost["binned"]["R"], f"{name}: R"
+    assert np.array_equal(u32(st.offsets), np.cumsum(pre["tiles"], dtype=np.uint64).astype(np.uint32))
+    assert np.array_equal(st.keys.cpu().numpy().view(np.uint64), ost["binned"]["keys"]), f"{name}: sorted keys"
+    assert np.array_equal(u32(st.vals), ost["binned"]["vals"]), f"{name}: sorted values"
+    assert np.array_equal(u32(st.ranges), ost["binned"]["ranges"]), f"{name}: tile ranges"
+    # ---- surfel records ---------------------------------------------------------
+    rec = st.rec.cpu().numpy()
+    ref = pre["rec"]
+    exact = np.array_equal(rec[:, :18].view(np.uint32), ref[:, :18].view(np.uint32))
+    if not exact:
+        e = rel_err(rec[:, :18], ref[:, :18], scale=np.abs(ref[:, :18]).max(axis=0, keepdims=True))
+        assert e.max() <= 1e-6, f"{name}: record mismatch {e.max()}"
+    # ---- allmap ---------------------------------------------------------------------
+    am = st.allmap.cpu().numpy()
+    oam = ost["allmap"]
+    frag = ost["fwd"]["fragile"]
+    ok = ~frag
+    worst = {}
+    for c in range(7):
+        scale = max(np.abs(oam[c]).max(), 1e-12)
+        err = np.abs(am[c].astype(np.float64) - oam[c]) / scale
+        worst[c] = err[ok].max() if ok.any() else 0.0
+        tol = RTOL if c != 6 else 1e-4   # distortion: difference of nearly equal sums
+        assert worst[c] <= tol, f"{name}: allmap ch{c} rel err {worst[c]:.3e} (non-fragile pixels)"
+        if frag.any():
+            assert err[frag].max() <= 5e-2, f"{name}: allmap ch{c} fragile pixel error {err[frag].max():.3e}"
+    # saved per-pixel state
+    ps = st.pix_state.cpu().numpy()
+    pc = u32(st.pix_contrib).reshape(-1, 2)
+    okf = ok.reshape(-1)
+    assert np.array_equal(pc[okf, 0], ost["fwd"]["pixN"][okf]), f"{name}: n_contrib"
+    assert np.array_equal(pc[okf, 1], ost["fwd"]["pixMed"][okf]), f"{name}: median_contrib"
+    assert np.abs(ps[okf, 0] - ost["fwd"]["pixT"][okf]).max() <= 1e-5
+    return worst, int(frag.sum())
+
+
+def _compare_backward(oracle32, st, t, ost, sc, name, seed=3):
+    H, W = ost["cam"].H, ost["cam"].W
+    rng = np.random.default_rng(seed)
+    dL = rng.normal(size=(7, H, W)).astype(np.float32)
+    dL[:, ost["fwd"]["fragile"]] = 0.0
+    dm, ds, dr, do, grec = hip_backward(st, t, dL)
+    ob = oracle32.backward(ost, dL, threads=1, want_abs=True)
+    # per-surfel gradient records relative to sum |terms|
+    gabs = ob["gabs"].astype(np.float64)
+    floor = 1e-5 * gabs.max(axis=0, keepdims=True) * 1e-2
+    err = np.abs(grec.astype(np.float64) - ob["grec"]) / np.maximum(gabs, np.maximum(floor, 1e-30))
+    assert err.max() <= RTOL * 4, f"{name}: grec rel-to-abs-sum err {err.max():.3e}"
+    worst = {}
+    for nm, a, ref in (("means", dm, ob["dmeans"]), ("scales", ds, ob["dscales"]), ("opac", do, ob["dopac"]),
+                       ("rots", tangent(dr.astype(np.float64), sc["rots"].astype(np.float64)),
+                        tangent(ob["drots"].astype(np.float64), sc["rots"].astype(np.float64)))):
+        scale = max(np.abs(ref).max(), 1e-30)
+        e = np.abs(a.astype(np.float64) - ref).max() / scale
+        worst[nm] = e
+        assert e <= RTOL, f"{name}: d{nm} max-norm rel err {e:.3e}"
+    return worst
+
+
+CASES = [
+    # name, N, H, W, kwargs
+    ("small_wrap", 3000, 32, 256, {}),
+    ("c2_50k_64x1024", 50000, 64, 1024, {}),
+    ("dense_near", 4000, 64, 512, dict(range_lo=1.0, range_hi=8.0, scale_lo=0.05, scale_hi=0.5)),
+    ("ragged_size", 2500, 40, 200, dict(hfov_deg=120.0)),       # H, W not multiples of the tile, no wrap
+    ("narrow_fov", 3000, 64, 512, dict(hfov_deg=90.0)),
+]
+
+
+@pytest.mark.parametrize("name,N,H,W,kw", CASES, ids=[c[0] for c in CASES])
+def test_forward_backward_parity(device, oracle32, name, N, H, W, kw):
+    kw = dict(kw)
+    hfov = kw.pop("hfov_deg", 360.0)
+    sc, view, proj = scene_and_camera(N, H, W, seed=11, hfov_deg=hfov, **kw)
+    if name == "dense_near":
+        from splat_loam_amd import synth
+        view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(3)[2])
+    st, t = hip_forward(device, sc, view, proj, H, W)
+    from splat_loam_amd import _abi
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    assert cam.wrap == st.cam.cam.wrap
+    wf, nfrag = _compare_forward(oracle32, st, ost, cam, name)
+    wb = _compare_backward(oracle32, st, t, ost, sc, name)
+    print(f"\n[{name}] R={st.R} fragile={nfrag} fwd worst={ {k: f'{v:.1e}' for k, v in wf.items()} } "
+          f"bwd worst={ {k: f'{v:.1e}' for k, v in wb.items()} }")
+
+
+def test_tile_consumed_matches(device, oracle32):
+    from splat_loam_amd import _abi
+    N, H, W = 20000, 64, 512
+    sc, view, proj = scene_and_camera(N, H, W, seed=5, range_lo=2.0, range_hi=20.0)
+    st, _ = hip_forward(device, sc, view, proj, H, W)
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    a, b = u32(st.tile_consumed), ost["fwd"]["tile_consumed"]
+    frag_tiles = ost["fwd"]["fragile"].reshape(cam.GY, cam.tile[1], cam.GX, cam.tile[0]).any(axis=(1, 3)).reshape(-1)
+    assert np.array_equal(a[~frag_tiles], b[~frag_tiles])
+
+
+def test_empty_and_culled(device):
+    """N = 0, and every surfel behind the near cut: empty image, zero gradients."""
+    from splat_loam_amd import synth
+    H, W = 32, 128
+    K = synth.spherical_K(H, W)
+    view, proj = synth.camera_matrices(K)
+    sc = dict(K=K, means=np.zeros((0, 3), np.float32), scales=np.zeros((0, 2), np.float32),
+              rots=np.zeros((0, 4), np.float32), opac=np.zeros((0, 1), np.float32))
+    st, t = hip_forward(device, sc, view, proj, H, W)
+    assert st.R == 0 and float(st.allmap.abs().max()) == 0.0
+    sc2 = synth.make_scene(100, H, W, seed=1, range_lo=0.01, range_hi=0.15)   # all nearer than 0.2 m
+    st, t = hip_forward(device, sc2, view, proj, H, W)
+    assert st.R == 0 and int((st.radii > 0).sum()) == 0
+    assert float(st.allmap.abs().max()) == 0.0
+    dm, ds, dr, do, _ = hip_backward(st, t, np.ones((7, H, W), np.float32))
+    assert not dm.any() and not ds.any() and not dr.any() and not do.any()
+
+
+def test_single_surfel_known_answer(device):
+    """A fronto-parallel surfel centred on a pixel ray at range r:
+    alpha = min(0.99, o), depth = r * alpha, normal = -ray (sensor frame)."""
+    from splat_loam_amd import synth
+    H, W = 32, 128
+    K = synth.spherical_K(H, W).astype(np.float64)
+    view, proj = synth.camera_matrices(K.astype(np.float32))
+    c, r, rng_m, o = 40, 12, 7.5, 0.8
+    az, el = (c - K[0, 2]) / K[0, 0], (r - K[1, 2]) / K[1, 1]
+    ray = np.array([np.cos(az) * np.cos(el), np.sin(az) * np.cos(el), np.sin(el)])
+    tn = -ray
+    helper = np.array([0.0, 0.0, 1.0])
+    tu = np.cross(tn, helper); tu /= np.linalg.norm(tu)
+    tv = np.cross(tn, tu)
+    q = synth._quat_from_R(np.stack([tu, tv, tn], 1)[None])[0]
+    sc = dict(K=K.astype(np.float32), means=(ray * rng_m)[None].astype(np.float32),
+              scales=np.array([[0.3, 0.3]], np.float32), rots=q[None].astype(np.float32),
+              opac=np.array([[o]], np.float32))
+    st, _ = hip_forward(device, sc, view, proj, H, W)
+    am = st.allmap.cpu().numpy()
+    assert abs(am[1, r, c] - o) < 2e-5
+    assert abs(am[0, r, c] - rng_m * o) < 2e-4
+    assert np.abs(am[2:5, r, c] - (-ray) * o).max() < 2e-5
+    assert abs(am[5, r, c] - rng_m) < 1e-4         # median depth = the only surfel
+    assert int(st.radii[0]) > 0
+
+
+def test_autograd_function_matches_raw_calls(device):
+    """GaussianRasterizer (autograd) == rasterize_forward/backward, allmap may be
+    overwritten in place by the caller before backward."""
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    N, H, W = 2000, 32, 256
+    sc, view, proj = scene_and_camera(N, H, W, seed=2)
+    st, t = hip_forward(device, sc, view, proj, H, W)
+    dL = np.random.default_rng(0).normal(size=(7, H, W)).astype(np.float32)
+    ref = hip_backward(st, t, dL)
+    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device),
+                                             torch.tensor(proj, device=device), False, False)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    radii, allmap = GaussianRasterizer(raster_settings=settings)(
+        means3D=leaves["means"], means2D=torch.zeros_like(leaves["means"]), opacities=leaves["opac"],
+        scales=leaves["scales"], rotations=leaves["rots"], cov3D_precomp=None)
+    assert torch.equal(allmap, st.allmap) and torch.equal(radii, st.radii)
+    loss = (allmap * torch.tensor(dL, device=device)).sum()
+    allmap.data.mul_(0.0)          # caller scribbles over allmap before backward
+    loss.backward()
+    for k, r in (("means", ref[0]), ("scales", ref[1]), ("rots", ref[2]), ("opac", ref[3])):
+        g = leaves[k].grad.cpu().numpy()
+        scale = max(np.abs(r).max(), 1e-30)
+        assert np.abs(g - r).max() / scale <= 1e-5, k   # float atomics reorder sums between runs
+
+
+def test_cpu_tensors_are_refused():
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    s = GaussianRasterizationSettings(8, 16, 1.0, torch.eye(4), torch.eye(4), False, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussianRasterizer(raster_settings=s)(means3D=torch.zeros(1, 3), means2D=torch.zeros(1, 3),
+                                              opacities=torch.zeros(1, 1), scales=torch.ones(1, 2),
+                                              rotations=torch.tensor([[1.0, 0, 0, 0]]), cov3D_precomp=None)
+
+
+def test_knn_bitexact(device, oracle32):
+    from splat_loam_amd.knn import distCUDA2
+    from splat_loam_amd import synth
+    for M, seed in ((1, 0), (3, 1), (4, 2), (257, 3), (6000, 4)):
+        pts = synth.make_scene(M, 64, 1024, seed=seed)["means"]
+        got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
+        ref = oracle32.knn_dist2(pts)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"M={M}"
+    # duplicates and collinear points
+    pts = np.repeat(np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [5, 0, 0]], np.float32), 3, axis=0)
+    got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), oracle32.knn_dist2(pts).view(np.uint32))
+
+
+def test_fused_adam_matches_torch(device):
+    from splat_loam_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1001, 3), (1001, 1), (1001, 2), (1001, 4)]
+    lrs = [5e-4, 5e-2, 5e-3, 1e-3]
+    p_ref = [torch.randn(s, generator=g) for s in shapes]
+    p_hip = [p.clone().to(device).requires_grad_(True) for p in p_ref]
+    p_ref = [p.clone().requires_grad_(True) for p in p_ref]
+    o_ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(p_ref, lrs)], lr=0.0, eps=1e-15)
+    o_hip = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(p_hip, lrs)], lr=0.0, eps=1e-15)
+    for it in range(5):
+        for a, b in zip(p_ref, p_hip):
+            gr = torch.randn(a.shape, generator=g) * (10.0 ** (it - 2))
+            a.grad = gr.clone()
+            b.grad = gr.clone().to(device)
+        o_ref.step(); o_hip.step()
+    for a, b in zip(p_ref, p_hip):
+        assert torch.allclose(a.detach(), b.detach().cpu(), rtol=2e-6, atol=1e-7)
+        sa, sb = o_ref.state[a], o_hip.state[b]
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"].cpu(), rtol=2e-6, atol=1e-12)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu(), rtol=2e-6, atol=1e-20)
+
+
+def test_mark_visible(device):
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    H, W = 32, 128
+    sc, view, proj = scene_and_camera(500, H, W, seed=3, range_lo=0.05, range_hi=5.0)
+    s = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device))
+    vis = GaussianRasterizer(raster_settings=s).markVisible(torch.tensor(sc["means"], device=device)).cpu().numpy()
+    rho = np.linalg.norm(sc["means"].astype(np.float64), axis=1)
+    sure = np.abs(rho - 0.2) > 1e-5
+    assert np.array_equal(vis[sure], (rho >= 0.2)[sure])
+
+
+def test_full_size_properties(device):
+    """BASELINE config 3 size (500k surfels, 64x2048): size-independent properties."""
+    N, H, W = 500000, 64, 2048
+    sc, view, proj = scene_and_camera(N, H, W, seed=0)
+    st, t = hip_forward(device, sc, view, proj, H, W)
+    keys = st.keys.cpu().numpy().view(np.uint64)
+    vals = u32(st.vals)
+    assert st.R == int(u32(st.tiles).sum())
+    assert np.all(keys[1:] >= keys[:-1]), "keys sorted"
+    same = keys[1:] == keys[:-1]
+    assert np.all(vals[1:][same] > vals[:-1][same]), "stable: equal keys keep surfel order"
+    # the sorted pairs are a permutation of the emitted pairs: checksum of (tile, surfel) pairs
+    depth_bits = u32(st.depth)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), depth_bits[vals]), "payload follows key"
+    tiles_of = np.bincount(vals, minlength=N)
+    assert np.array_equal(tiles_of.astype(np.uint32), u32(st.tiles)), "every surfel emitted tiles_touched times"
+    rng = u32(st.ranges).reshape(-1, 2)
+    tile_ids = (keys >> np.uint64(32)).astype(np.int64)
+    cnt = np.bincount(tile_ids, minlength=rng.shape[0])
+    assert np.array_equal((rng[:, 1] - rng[:, 0]).astype(np.int64), cnt), "ranges partition the list"
+    am = st.allmap.cpu().numpy()
+    assert np.isfinite(am).all()
+    assert am[1].min() >= 0.0 and am[1].max() <= 1.0, "alpha in [0,1] (fed to BCE, slam/mapper.py:182)"
+    nrm = np.linalg.norm(am[2:5], axis=0)
+    assert np.all(nrm <= am[1] + 1e-4), "|sum w n| <= sum w"
+    # forward is deterministic (no atomics): bit-identical on a second run
+    st2, _ = hip_forward(device, sc, view, proj, H, W)
+    assert torch.equal(st.allmap, st2.allmap) and torch.equal(st.vals, st2.vals)
+    # backward: finite, linear in dL
+    g = np.random.default_rng(1)
+    d1 = g.normal(size=(7, H, W)).astype(np.float32)
+    d2 = g.normal(size=(7, H, W)).astype(np.float32)
+    b1, b2, b12 = hip_backward(st, t, d1), hip_backward(st, t, d2), hip_backward(st, t, d1 + d2)
+    for x, y, z in zip(b1[:4], b2[:4], b12[:4]):
+        assert np.isfinite(z).all()
+        scale = np.abs(z).max()
+        assert np.abs((x + y) - z).max() <= 2e-4 * scale, "backward is linear in dL/dallmap"
