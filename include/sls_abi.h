@@ -138,8 +138,8 @@ typedef struct SlsAdamGroup {
     float lr;
     float pad;
 } SlsAdamGroup;
-int sls_adam_step(const SlsAdamGroup *groups_host, int ngroups, float beta1, float beta2,
-                  float eps, int64_t step, void *stream);
+int sls_adam_step(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
+                  double eps, int64_t step, void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------
  * out[i] = mean of squared distances from point i to its 3 nearest other

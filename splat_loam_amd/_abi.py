@@ -49,7 +49,7 @@ _PROTOS = {
     "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 9 +
                            [_VP, C.c_size_t, C.POINTER(C.c_int)] + [_VP] * 7 + [_VP]),
     "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP]),
-    "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_float, C.c_float, C.c_float, C.c_int64, _VP]),
+    "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),

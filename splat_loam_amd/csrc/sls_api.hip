@@ -279,7 +279,7 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
                                  dL_drotations, dL_dopacities, st);
 }
 
-int sls_adam_step(const SlsAdamGroup *groups, int ngroups, float beta1, float beta2, float eps, int64_t step,
+int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                   void *stream)
 {
     SLS_REQUIRE(groups && ngroups > 0 && ngroups <= kMaxAdamGroups, "1..8 groups");
@@ -297,12 +297,12 @@ int sls_adam_step(const SlsAdamGroup *groups, int ngroups, float beta1, float be
     }
     for (int i = ngroups; i < kMaxAdamGroups; ++i) a.unit_end[i] = units;
     a.ngroups = ngroups;
-    a.w1 = (float)(1.0 - (double)beta1);
-    a.b2 = beta2;
-    a.w2 = (float)(1.0 - (double)beta2);
-    a.eps = eps;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.w1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    a.bc1 = (float)(1.0 - pow(beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     if (units == 0) return SLS_OK;
     int64_t blocks = (units + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond
