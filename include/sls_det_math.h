@@ -11,7 +11,8 @@
  * is enough to move a floor() across a tile boundary.  So the projection
  * uses ONLY operations that IEEE-754 defines exactly (+ - * / sqrt fma,
  * compare/select); atan2 is a fixed odd polynomial evaluated with fmaf.
- * Max abs error of sls_atan2 vs. the real atan2 is 1.1e-7 rad (< 4e-5 px at
+ * Max abs error of sls_atan2 vs. the real atan2 is < 4e-7 rad in float
+ * (polynomial 1.1e-7 + one ulp at |angle| ~ pi), i.e. < 1.4e-4 px at
  * |fx| = 326 px/rad), see tests/test_det_math.py.
  *
  * Rules for users of this header (both sides):

@@ -201,6 +201,12 @@ class Oracle:
         self.lib.or_adam(C.c_int64(p.size), _ptr(p), _ptr(self._r(g)), _ptr(m), _ptr(v),
                          C.c_double(lr), C.c_double(b1), C.c_double(b2), C.c_double(eps), C.c_int64(step))
 
+    def atan2(self, y, x):
+        y, x = self._r(y), self._r(x)
+        out = np.empty_like(y)
+        self.lib.or_atan2(C.c_int(y.size), _ptr(y), _ptr(x), _ptr(out))
+        return out
+
     def knn_dist2(self, pts):
         pts = np.ascontiguousarray(pts, np.float32)
         out = np.empty(pts.shape[0], np.float32)

@@ -663,6 +663,12 @@ void or_knn_dist2(int M, const float *pts, float *out)
     }
 }
 
+/* test hook: the shared polynomial atan2 (include/sls_det_math.h) */
+void or_atan2(int n, const real *y, const real *x, real *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = sls_atan2(y[i], x[i]);
+}
+
 int or_max_threads(void)
 {
 #ifdef _OPENMP

@@ -40,10 +40,10 @@ def mapping_loss(render_pkg: dict, camera, model, cfg: MappingConfig) -> torch.T
     return geom_l1 + alpha_loss + normal_loss + reg_scales
 
 
-def optimize_step(model, camera, cfg: MappingConfig) -> torch.Tensor:
+def optimize_step(model, camera, cfg: MappingConfig, **render_kw) -> torch.Tensor:
     """One iteration of Mapper.optimize (slam/mapper.py:150-204) for one keyframe."""
     model.optimizer.zero_grad(set_to_none=True)
-    pkg = render(camera, model, cfg.depth_ratio)
+    pkg = render(camera, model, cfg.depth_ratio, **render_kw)
     loss = mapping_loss(pkg, camera, model, cfg)
     loss.backward()
     with torch.no_grad():
@@ -68,14 +68,15 @@ def flat_grad_allreduce(model, group=None, average: bool = False) -> None:
         off += n
 
 
-def optimize_step_sharded(model, my_camera, cfg: MappingConfig, group=None, average: bool = False) -> torch.Tensor:
+def optimize_step_sharded(model, my_camera, cfg: MappingConfig, group=None, average: bool = False,
+                          **render_kw) -> torch.Tensor:
     """Keyframe-parallel iteration: every rank renders ITS keyframe against the
     replicated model, gradients are summed over ranks, every rank applies the
     same Adam step (replicas stay bit-identical because the all-reduce result
     is).  The keyframe-independent scale regulariser is counted once: rank 0
     keeps it, the others drop it."""
     model.optimizer.zero_grad(set_to_none=True)
-    pkg = render(my_camera, model, cfg.depth_ratio)
+    pkg = render(my_camera, model, cfg.depth_ratio, **render_kw)
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     local_cfg = cfg if rank == 0 else MappingConfig(**{**cfg.__dict__, "opt_scaling_max_penalty": 0.0})
     loss = mapping_loss(pkg, my_camera, model, local_cfg)

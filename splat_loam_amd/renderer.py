@@ -57,13 +57,16 @@ def depth_to_normal(camera, depth: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def render(camera, model, depth_ratio: float = 0.0) -> dict:
-    """Same contract as gaussian_renderer.render (gaussian_renderer/__init__.py:11-93)."""
+def render(camera, model, depth_ratio: float = 0.0, rasterizer_cls=GaussianRasterizer) -> dict:
+    """Same contract as gaussian_renderer.render (gaussian_renderer/__init__.py:11-93).
+    `rasterizer_cls` exists so the CPU tests can drive this function with the
+    checker's rasterizer; the default (and only product path) is the HIP one, which
+    refuses CPU tensors."""
     settings = GaussianRasterizationSettings(
         image_height=int(camera.image_height), image_width=int(camera.image_width), scale_modifier=1.0,
         viewmatrix=camera.world_view_transform, projmatrix=camera.projection_matrix,
         prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(raster_settings=settings)
+    rasterizer = rasterizer_cls(raster_settings=settings)
     means3D = model.get_xyz
     means2D = torch.zeros_like(means3D, dtype=torch.float32)
     radii, allmap = rasterizer(means3D=means3D, means2D=means2D, opacities=model.get_opacity,

@@ -31,7 +31,7 @@ def camera_matrices(K: np.ndarray, world_T_lidar: np.ndarray | None = None):
     """(viewmatrix, projmatrix) exactly as scene/cameras.py:43-50 builds them."""
     if world_T_lidar is None:
         world_T_lidar = np.eye(4)
-    view = np.linalg.inv(np.asarray(world_T_lidar, dtype=np.float64)).T.astype(np.float32)
+    view = np.ascontiguousarray(np.linalg.inv(np.asarray(world_T_lidar, dtype=np.float64)).T, dtype=np.float32)
     proj = np.eye(4, dtype=np.float32)
     proj[:3, :3] = np.asarray(K, dtype=np.float32).T
     return view, proj

@@ -1,0 +1,92 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/sls_abi.h
+declares, and its host-side entry points behave (no device compute here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from splat_loam_amd import _abi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "sls_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sls_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = C.CDLL(_abi.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in sls_abi.h but not exported"
+        assert n in _abi.EXPORTS, f"{n} has no ctypes prototype in _abi.py"
+
+
+def test_constants_match_spec_header():
+    lib = _abi.lib()
+    spec = open(os.path.join(ROOT, "include", "sls_spec.h")).read()
+    assert lib.sls_rec_stride() == int(re.search(r"#define SLS_REC_STRIDE (\d+)", spec).group(1)) == 20
+    assert lib.sls_grec_stride() == int(re.search(r"#define SLS_GREC_STRIDE (\d+)", spec).group(1)) == 16
+    tw, th = _abi.tile_size()
+    assert (tw * th) % 64 == 0 and tw % 8 == 0 and th % 8 == 0
+    assert lib.sls_timing_slots() >= 12 and lib.sls_timing_name(7) == b"render_fwd"
+
+
+def test_camera_from_matrices_and_ray_tables(oracle32):
+    lib = _abi.lib()
+    H, W = 64, 1024
+    K = synth.spherical_K(H, W)
+    view, proj = synth.camera_matrices(K, synth.keyframe_poses(4)[3])
+    cam = _abi.SlsCamera()
+    _abi.check(lib.sls_camera_from_matrices(view.ctypes.data, proj.ctypes.data, H, W, 1.0, C.byref(cam)), "camera")
+    ocam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    assert cam.wrap == ocam.wrap == 1
+    assert np.array_equal(np.array([cam.fx, cam.fy, cam.cx, cam.cy], np.float32), ocam.fcam[:4])
+    assert np.array_equal(np.array(list(cam.Rvw) + list(cam.tvw), np.float32), ocam.fcam[7:19])
+    assert (cam.near_cut, cam.far_cut) == (np.float32(0.2), np.float32(100.0))
+    col = np.empty((W, 2), np.float32); row = np.empty((H, 2), np.float32)
+    _abi.check(lib.sls_ray_tables(C.byref(cam), col.ctypes.data, row.ctypes.data), "tables")
+    ocol, orow = oracle32.ray_tables(ocam)
+    assert np.array_equal(col, ocol) and np.array_equal(row, orow)          # bit-exact
+    # narrow horizontal field of view: no wrap
+    view, proj = synth.camera_matrices(synth.spherical_K(H, W, hfov_deg=120.0))
+    _abi.check(lib.sls_camera_from_matrices(view.ctypes.data, proj.ctypes.data, H, W, 1.0, C.byref(cam)), "camera")
+    assert cam.wrap == 0
+
+
+def test_error_reporting_never_throws():
+    lib = _abi.lib()
+    cam = _abi.SlsCamera()
+    rc = lib.sls_camera_from_matrices(None, None, 4, 4, 1.0, C.byref(cam))
+    assert rc == -1 and b"null pointer" in lib.sls_last_error()
+    proj = np.eye(4, dtype=np.float32); proj[1, 0] = 0.3                    # skewed K
+    rc = lib.sls_camera_from_matrices(np.eye(4, dtype=np.float32).ctypes.data, proj.ctypes.data, 4, 4, 1.0, C.byref(cam))
+    assert rc == -1 and b"skew" in lib.sls_last_error()
+    with pytest.raises(RuntimeError, match="skew"):
+        _abi.check(rc, "sls_camera_from_matrices")
+    grp = (_abi.SlsAdamGroup * 1)()
+    assert lib.sls_adam_step(grp, 0, 0.9, 0.999, 1e-15, 1, None) == -1
+    assert lib.sls_adam_step(grp, 1, 0.9, 0.999, 1e-15, 0, None) == -1       # step is 1-based
+    assert lib.sls_knn_scratch_bytes(0) == 0 and lib.sls_knn_scratch_bytes(1000) > 1000 * 36
+    assert lib.sls_sort_scratch_bytes(0) >= 1024 and lib.sls_stage1_scratch_bytes(1000) >= 16
+
+
+def test_product_never_touches_the_checker():
+    """No module of the product imports or opens anything under oracle/."""
+    pkg = os.path.join(ROOT, "splat_loam_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle|oracle/|liboracle", txt):
+                    bad.append(os.path.join(dirpath, f))
+    for shim in ("diff_surfel_spherical_rasterization/__init__.py", "simple_knn/_C.py"):
+        if re.search(r"oracle", open(os.path.join(ROOT, shim)).read()):
+            bad.append(shim)
+    assert not bad, bad

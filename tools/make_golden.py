@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python
+(/root/reference, importable only in the build container) and recording inputs
+and outputs.  Only data is committed; no reference source travels.
+
+    python tools/make_golden.py            # rewrites tests/golden/g*.npz
+
+G1  camera conventions + spherical back-projection: scene/cameras.py:10-50,
+    utils/graphic_utils.py:26-88
+G2  gaussian_renderer.render() post-processing on a seeded allmap
+    (gaussian_renderer/__init__.py:48-93) and its gradient for a weighted sum
+G3  build_rotation / inverse_sigmoid / matrix_to_quaternion /
+    create_rotation_matrix_from_direction_vector_batch / sample_geometric
+    (utils/general_utils.py, utils/sampling_utils.py)
+G5  Mapper.optimize (slam/mapper.py:140-214) for 3 Adam iterations with the
+    reference's GaussianModel.training_setup, on top of the CPU checker injected
+    as `diff_surfel_spherical_rasterization` -> parameter trajectories
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def install_stubs():
+    from oracle import torch_function as tf
+    m = types.ModuleType("diff_surfel_spherical_rasterization")
+    m.GaussianRasterizer = tf.GaussianRasterizer
+    m.GaussianRasterizationSettings = tf.GaussianRasterizationSettings
+    sys.modules["diff_surfel_spherical_rasterization"] = m
+    knn = types.ModuleType("simple_knn")
+    knn_c = types.ModuleType("simple_knn._C")
+    knn_c.distCUDA2 = lambda x: (_ for _ in ()).throw(RuntimeError("not used"))
+    sys.modules["simple_knn"], sys.modules["simple_knn._C"] = knn, knn_c
+    gs = types.ModuleType("gsaligner")
+
+    class GSAlignerParams:  # dataclass field default in utils/config_utils.py
+        pass
+
+    class GSAligner:
+        pass
+    gs.GSAlignerParams, gs.GSAligner = GSAlignerParams, GSAligner
+    sys.modules["gsaligner"] = gs
+    for name in ("plyfile", "rerun"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["rerun"].__path__ = []
+    sys.modules["rerun.blueprint"] = types.ModuleType("rerun.blueprint")
+    sys.modules["rerun"].blueprint = sys.modules["rerun.blueprint"]
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    try:
+        import omegaconf  # noqa: F401
+    except ImportError:
+        oc = types.ModuleType("omegaconf")
+
+        class OmegaConf:
+            pass
+        oc.OmegaConf = OmegaConf
+        sys.modules["omegaconf"] = oc
+
+
+def g1():
+    from scene.cameras import Camera
+    from utils.graphic_utils import depth_to_normal, depth_to_points
+    from splat_loam_amd import synth
+    rng = np.random.default_rng(1)
+    out = {}
+    H, W = 8, 16
+    for i, (hfov, pose) in enumerate(((360.0, np.eye(4)), (120.0, synth.keyframe_poses(3)[2]), (360.0, None))):
+        K = synth.spherical_K(H, W, hfov_deg=hfov)
+        if pose is None:
+            a = 0.7
+            pose = np.eye(4)
+            pose[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+            pose[:3, 3] = [1.0, -2.0, 0.5]
+        depth = rng.uniform(2, 30, (1, H, W)).astype(np.float32)
+        cam = Camera(K, depth, np.zeros((3, H, W), np.float32), np.ones((1, H, W), np.uint8),
+                     world_T_lidar=pose.astype(np.float32), data_device="cpu")
+        d = torch.from_numpy(depth)
+        out[f"K{i}"], out[f"pose{i}"], out[f"depth{i}"] = K, pose.astype(np.float32), depth
+        out[f"view{i}"] = cam.world_view_transform.numpy()
+        out[f"proj{i}"] = cam.projection_matrix.numpy()
+        out[f"pts_sensor{i}"] = depth_to_points(cam, d, False).numpy()
+        out[f"pts_world{i}"] = depth_to_points(cam, d, True).numpy()
+        out[f"normal{i}"] = depth_to_normal(cam, d).numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_camera.npz"), **out)
+
+
+class _FixedAllmapRasterizer(torch.nn.Module):
+    allmap = None
+    radii = None
+
+    def __init__(self, raster_settings):
+        super().__init__()
+
+    def forward(self, **kw):
+        return _FixedAllmapRasterizer.radii, _FixedAllmapRasterizer.allmap
+
+
+def g2():
+    import gaussian_renderer
+    from scene.cameras import Camera
+    from splat_loam_amd import synth
+    rng = np.random.default_rng(2)
+    H, W = 8, 16
+    K = synth.spherical_K(H, W)
+    pose = synth.keyframe_poses(2)[1]
+    cam = Camera(K, np.ones((1, H, W), np.float32), np.zeros((3, H, W), np.float32), np.ones((1, H, W), np.uint8),
+                 world_T_lidar=pose.astype(np.float32), data_device="cpu")
+    alpha = rng.uniform(0.2, 1.0, (H, W))
+    alpha[rng.uniform(size=(H, W)) < 0.15] = 0.0      # some empty pixels
+    allmap = np.zeros((7, H, W), np.float32)
+    allmap[1] = alpha
+    allmap[0] = alpha * rng.uniform(3, 20, (H, W))
+    nrm = rng.normal(size=(3, H, W)); nrm /= np.linalg.norm(nrm, axis=0, keepdims=True)
+    allmap[2:5] = nrm * alpha
+    allmap[5] = rng.uniform(3, 20, (H, W)) * (alpha > 0)
+    allmap[6] = rng.uniform(0, 0.01, (H, W)) * (alpha > 0)
+    out = {"K": K, "pose": pose.astype(np.float32), "allmap": allmap}
+
+    class M:
+        get_xyz = torch.zeros(5, 3)
+        get_opacity = get_scaling = get_rotation = None
+    saved = gaussian_renderer.GaussianRasterizer
+    gaussian_renderer.GaussianRasterizer = _FixedAllmapRasterizer
+    try:
+        for ratio in (0.0, 0.3):
+            am = torch.from_numpy(allmap.copy()).requires_grad_(True)
+            _FixedAllmapRasterizer.allmap = am * 1.0       # non-leaf, so the in-place writes are legal
+            _FixedAllmapRasterizer.radii = torch.ones(5, dtype=torch.int32)
+            pkg = gaussian_renderer.render(cam, M, ratio)
+            wts = {k: torch.from_numpy(rng.normal(size=tuple(pkg[k].shape)).astype(np.float32))
+                   for k in ("rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal")}
+            loss = sum((pkg[k] * wts[k]).sum() for k in wts)
+            loss.backward()
+            tag = f"_r{int(ratio * 10)}"
+            for k in wts:
+                out[k + tag] = pkg[k].detach().numpy()
+                out["w_" + k + tag] = wts[k].numpy()
+            out["grad_allmap" + tag] = am.grad.numpy()
+    finally:
+        gaussian_renderer.GaussianRasterizer = saved
+    np.savez_compressed(os.path.join(OUT, "g2_render.npz"), **out)
+
+
+def g3():
+    from utils import general_utils as gu
+    from utils import sampling_utils as su
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=(16, 4)).astype(np.float32)
+    out = {"q": q, "R": gu.build_rotation(torch.from_numpy(q)).numpy()}
+    x = rng.uniform(0.01, 0.99, 32).astype(np.float32)
+    out["x"], out["inv_sigmoid"] = x, gu.inverse_sigmoid(torch.from_numpy(x)).numpy()
+    d = rng.normal(size=(16, 3)).astype(np.float32)
+    Rm = gu.create_rotation_matrix_from_direction_vector_batch(torch.from_numpy(d))
+    out["dirs"], out["R_from_dirs"] = d, Rm.numpy()
+    out["quat_from_R"] = gu.matrix_to_quaternion(Rm).numpy()
+    for n, p in ((1, 0.4), (5, 0.4), (8, 0.7)):
+        out[f"geom_{n}_{int(p * 10)}"] = np.asarray(su.sample_geometric(list(range(n)), p), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g3_utils.npz"), **out)
+
+
+def g5():
+    from scene.cameras import Camera
+    from scene.frame import Frame
+    from scene.gaussian_model import GaussianModel
+    from slam.local_model import LocalModel
+    from slam.mapper import Mapper
+    from utils.config_utils import Configuration
+    from splat_loam_amd import synth
+    N, H, W = 200, 16, 64
+    sc = synth.make_scene(N, H, W, seed=5, range_lo=2.0, range_hi=12.0, scale_lo=0.05, scale_hi=0.3)
+    depth, valid = synth.make_targets(H, W, sc)
+    valid = valid.copy(); valid[0, :2, :5] = 0            # a few invalid pixels
+    pose = synth.keyframe_poses(2)[1].astype(np.float32)
+    cfg = Configuration()
+    cfg.device = "cpu"
+    cfg.logging.enable = False
+    cfg.mapping.num_iterations = 2                         # loop runs num_iterations + 1 = 3 times
+    cfg.mapping.opt_lambda_alpha, cfg.mapping.opt_lambda_normal = 0.4, 0.5
+    cfg.mapping.opt_scaling_max, cfg.mapping.opt_scaling_max_penalty = 0.1, 1.0
+    cfg.mapping.prob_view_last_keyframe = -1.0
+    cfg.opt.depth_ratio = 0.0
+    cam = Camera(sc["K"], depth, np.zeros((3, H, W), np.float32), valid, world_T_lidar=pose, data_device="cpu")
+    frame = Frame(cam, 0.0, "cpu")
+    gm = GaussianModel("cpu")
+    gm._xyz = torch.nn.Parameter(torch.tensor(sc["means"]))
+    gm._scaling = torch.nn.Parameter(torch.log(torch.tensor(sc["scales"])))
+    gm._rotation = torch.nn.Parameter(torch.tensor(sc["rots"]) * 1.3)      # un-normalised raw quaternions
+    gm._opacity = torch.nn.Parameter(torch.log(torch.tensor(sc["opac"]) / (1 - torch.tensor(sc["opac"]))))
+    init = {k: getattr(gm, k).detach().numpy().copy() for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
+    gm.training_setup(cfg)
+    lm = LocalModel(cfg)
+    lm.gmodel = gm if hasattr(lm, "gmodel") else gm
+    for attr in ("gmodel", "_gmodel", "model"):
+        if hasattr(lm, attr):
+            setattr(lm, attr, gm)
+    lm.keyframes = [frame]
+    mapper = Mapper(cfg)
+    mapper.register_model(lm)
+    assert lm.get_gmodel is gm
+    np.random.seed(0)
+    mapper.optimize()
+    out = {"K": sc["K"], "pose": pose, "depth": depth, "valid": valid,
+           "lr": np.array([cfg.opt.position_lr, cfg.opt.opacity_lr, cfg.opt.scaling_lr, cfg.opt.rotation_lr])}
+    for k, v in init.items():
+        out["init" + k] = v
+        out["final" + k] = getattr(gm, k).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_mapper.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    install_stubs()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5"]
+    for name in which:
+        globals()[name]()
+        print("wrote", name)
