@@ -163,6 +163,11 @@ const char *sls_timing_name(int slot);
 int sls_timing_enable(int on);
 int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
 
+/* Diagnostic: when non-null, the tile kernels write the shader-clock cycles each
+ * wave spent (T * waves_per_tile uint32 each, DEVICE pointers) — used to look at
+ * load balance across tiles.  Pass nulls to switch it off (the default). */
+int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles);
+
 /* Device self-test of the wave64 primitives (DPP reduction, ballot ranking).
  * Returns 0 if they behave as the kernels assume.  Synchronises. */
 int sls_selftest(void *stream);

@@ -57,6 +57,7 @@ _PROTOS = {
     "sls_timing_name": (C.c_char_p, [C.c_int]),
     "sls_timing_enable": (C.c_int, [C.c_int]),
     "sls_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "sls_debug_wave_cycles": (C.c_int, [_VP, _VP]),
     "sls_selftest": (C.c_int, [_VP]),
 }
 

@@ -63,6 +63,7 @@ int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
+extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
 size_t knn_scratch_bytes(int M);
 int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
 
@@ -139,6 +140,21 @@ __global__ void selftest_kernel(int *out)
     if (lane_id() != lane) bad |= 8;
     const uint64_t lt = (1ull << lane) - 1ull;
     if ((lane % 3) == 0 && (int)__popcll(bal & lt) != lane / 3) bad |= 16;
+    // 16-way reduce-scatter: x[k] = (lane+1)(k+1)/4 -> component k sums to 520 (k+1)
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = 0.25f * (float)((lane + 1) * (k + 1));
+    const float r16 = wave_reduce16(x, lane);
+    if (r16 != 520.0f * (float)(reduce16_component(lane) + 1)) bad |= 32;
+    // lanes 0..15 must own 16 distinct components
+    const uint64_t own = __ballot(lane < 16 && reduce16_component(lane) == (threadIdx.x & 15));
+    (void)own;
+    uint32_t seen = 0;
+    for (int l = 0; l < 16; ++l) seen |= 1u << reduce16_component(l);
+    if (seen != 0xFFFFu) bad |= 64;
+    int xa, xb, ya, yb;
+    const uint64_t mm = __ballot(lane == 10 || lane == 29 || lane == 52);   // (2,1) (5,3) (4,6)
+    if (!mask_bbox8x8(mm, xa, xb, ya, yb) || xa != 2 || xb != 5 || ya != 1 || yb != 6) bad |= 128;
     if (bad) atomicOr(out, bad);
 }
 
@@ -330,6 +346,13 @@ int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t 
     if (N == 0) return SLS_OK;
     SLS_REQUIRE(means3D && visible, "null pointer");
     return launch_mark_visible(make_devcam(*cam), N, means3D, visible, (hipStream_t)stream);
+}
+
+int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles)
+{
+    g_dbg_fwd_cycles = fwd_cycles;
+    g_dbg_bwd_cycles = bwd_cycles;
+    return SLS_OK;
 }
 
 int sls_timing_slots(void) { return T_COUNT; }

@@ -116,6 +116,54 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// Reduce-scatter of 16 per-lane values over the wave: returns, in EVERY lane l,
+// the wave-wide sum of component reduce16_component(l).  Each step halves the
+// number of live values by exchanging one half with a partner lane (DPP
+// quad_perm / row_half_mirror / row_mirror — all involutions), so the whole
+// 16 x 64 reduction costs ~70 instructions instead of 16 full wave sums.
+// The selection bits are chosen so partners always hold the same subset.
+__device__ __forceinline__ int reduce16_component(int lane)
+{
+    const int s0 = (lane ^ (lane >> 2)) & 1, s1 = ((lane >> 1) ^ (lane >> 2)) & 1;
+    const int s2 = ((lane >> 2) ^ (lane >> 3)) & 1, s3 = (lane >> 3) & 1;
+    return 8 * s0 + 4 * s1 + 2 * s2 + s3;
+}
+__device__ __forceinline__ float wave_reduce16(const float (&x)[16], int lane)
+{
+    const bool s0 = ((lane ^ (lane >> 2)) & 1) != 0, s1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+    const bool s2 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0, s3 = ((lane >> 3) & 1) != 0;
+    float y[8], z[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = (s0 ? x[i + 8] : x[i]) + dpp_mov0<0xB1, 0xF>(s0 ? x[i] : x[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = (s1 ? y[i + 4] : y[i]) + dpp_mov0<0x4E, 0xF>(s1 ? y[i] : y[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w[i] = (s2 ? z[i + 2] : z[i]) + dpp_mov0<0x141, 0xF>(s2 ? z[i] : z[i + 2]);
+    float v = (s3 ? w[1] : w[0]) + dpp_mov0<0x140, 0xF>(s3 ? w[0] : w[1]);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// Bounding box (in lane coordinates of an 8x8 sub-tile, lane = y*8 + x) of the
+// lanes set in `m`; all scalar work.  Empty mask -> returns false.
+__device__ __forceinline__ bool mask_bbox8x8(uint64_t m, int &xmin, int &xmax, int &ymin, int &ymax)
+{
+    if (m == 0) return false;
+    uint64_t c = m | (m >> 32);
+    c |= c >> 16;
+    c |= c >> 8;
+    const uint32_t cols = (uint32_t)c & 0xFFu;
+    uint64_t t = (m | (m >> 4)) & 0x0F0F0F0F0F0F0F0Full;
+    t = (t | (t >> 2)) & 0x0303030303030303ull;
+    t = (t | (t >> 1)) & 0x0101010101010101ull;
+    xmin = __builtin_ctz(cols);
+    xmax = 31 - __builtin_clz(cols);
+    ymin = __builtin_ctzll(t) >> 3;
+    ymax = (63 - __builtin_clzll(t)) >> 3;
+    return true;
+}
+
 __device__ __forceinline__ float readlane63(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

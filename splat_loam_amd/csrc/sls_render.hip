@@ -2,22 +2,25 @@
 // backward (A7).  SURVEY.md §8a rows A6/A7; maths in DESIGN.md §2.
 //
 // Mapping to CDNA4:
-//   * one workgroup = one TILE_W x TILE_H tile = 4 waves; each wave owns an 8x8
-//     pixel sub-tile and keeps its own "all 64 pixels saturated" early-out;
+//   * one workgroup = one TILE_W x TILE_H tile; each wave owns an 8x8 pixel
+//     sub-tile and keeps its own "all 64 pixels saturated" early-out;
 //   * the tile's depth-sorted surfel list is staged through LDS in batches of
-//     256 records (80 B each, 5 x float4).  Staging is lane-linear: thread k
+//     kBatch records (80 B each, 5 x float4).  Staging is lane-linear: thread k
 //     of round i fetches float4 #(k mod 5) of record #(k div 5), so adjacent
 //     lanes read adjacent 16-B pieces of one record and the LDS image is
-//     written with stride-1 ds_write_b128.  The next batch is prefetched into
-//     registers while the current one is consumed;
+//     written with stride-1 ds_write_b128.  Two-deep software pipeline: while
+//     batch b is consumed, the records of b+1 and the list indices of b+2 are
+//     in flight (no branch between the loads, so they all overlap);
 //   * wave64 ballot culling: lane j tests record j of the batch against the
-//     wave's sub-tile (conservative support box written by preprocess); the
-//     64-bit ballot is then walked with scalar ff1 — surfels that cannot touch
-//     the sub-tile cost no VALU work at all, the survivors are evaluated with
-//     wave-uniform (broadcast) LDS reads;
-//   * backward: per-surfel gradient = sum over the wave's pixels by 6 DPP adds
-//     (row_ror / row_bcast, no LDS traffic), cross-wave accumulation with LDS
-//     float atomics, one global float atomic per touched (tile, surfel, field).
+//     bounding box of the wave's still-active pixels (conservative support box
+//     from preprocess); the 64-bit ballot is walked with scalar ff1 — surfels
+//     that cannot touch an active pixel cost no VALU work, the survivors are
+//     evaluated with wave-uniform (broadcast) LDS reads.  The active box
+//     shrinks as pixels saturate, which is what bounds the straggler waves;
+//   * backward: the 16 per-surfel gradient fields are reduced over the wave's
+//     pixels with ONE 16-way DPP reduce-scatter (sls_common.hpp), accumulated
+//     across waves with LDS float atomics (16 lanes, 16 distinct addresses) and
+//     flushed with one global float atomic per touched (tile, surfel, field).
 // No MFMA: there is no dense contraction here (BASELINE.json north_star).
 #include "sls_common.hpp"
 
@@ -25,6 +28,7 @@ namespace sls {
 
 constexpr int kThreads = kTilePix;          // one thread per tile pixel
 constexpr int kBatch = kThreads;            // records staged per batch (one index per thread)
+constexpr int kRounds = kBatch / 64;
 constexpr int kSubX = kTileW / 8;           // wave sub-tiles per tile row
 
 struct Eval {
@@ -35,7 +39,7 @@ struct Eval {
 // One (pixel, surfel) evaluation; identical in forward and backward.
 __device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
                                             const float4 q4, float d0, float d1, float d2, float pc, float pr,
-                                            int wrap, float Wf, float near_c, Eval &e)
+                                            float wrapW, float invW, float near_c, Eval &e)
 {
     e.dl0 = d0 - q3.x; e.dl1 = d1 - q3.y; e.dl2 = d2 - q3.z;
     const float nd = q2.x * d0 + q2.y * d1 + q2.z * d2;
@@ -47,12 +51,9 @@ __device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, co
     e.v = e.hv * e.rinv;
     e.t = q0.w * e.rinv;
     const float rho3 = e.u * e.u + e.v * e.v;
-    float dx = pc - q4.x;
-    if (wrap) {
-        if (dx > 0.5f * Wf) dx -= Wf;
-        else if (dx < -0.5f * Wf) dx += Wf;
-    }
-    e.dx = dx;
+    // D5 wrapped azimuth difference, branch-free: wrapW = W (360-degree image) or 0
+    const float dx0 = pc - q4.x;
+    e.dx = dx0 - wrapW * __builtin_rintf(dx0 * invW);
     e.dy = pr - q4.y;
     const float rho2 = SLS_FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
     e.use3d = valid3d && (rho3 <= rho2);
@@ -64,15 +65,47 @@ __device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, co
     e.skip = (e.depth < near_c) || (e.alpha < SLS_ALPHA_MIN);
 }
 
-__device__ __forceinline__ bool cull_pass(const float4 q4, float wcx, float wcy, int wrap, float Wf)
+// Conservative test: can the surfel (centre q4.xy, support half-extents q4.zw)
+// reach a pixel of the box centred (bcx, bcy) with half-extents (bhx, bhy)?
+__device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy, float bhx, float bhy,
+                                          float wrapW, float invW)
 {
-    float dxc = wcx - q4.x;
-    if (wrap) {
-        if (dxc > 0.5f * Wf) dxc -= Wf;
-        else if (dxc < -0.5f * Wf) dxc += Wf;
-    }
-    return (fabsf(dxc) <= q4.z + 3.5f) && (fabsf(wcy - q4.y) <= q4.w + 3.5f);
+    const float dx0 = bcx - q4.x;
+    const float dxc = dx0 - wrapW * __builtin_rintf(dx0 * invW);
+    return (fabsf(dxc) <= q4.z + bhx) && (fabsf(bcy - q4.y) <= q4.w + bhy);
 }
+
+// Box of the active lanes of an 8x8 sub-tile at (x0, y0); false if none.
+__device__ __forceinline__ bool active_box(uint64_t m, int x0, int y0, float &bcx, float &bcy, float &bhx,
+                                           float &bhy)
+{
+    int xa, xb, ya, yb;
+    if (!mask_bbox8x8(m, xa, xb, ya, yb)) return false;
+    bcx = (float)x0 + 0.5f * (float)(xa + xb);
+    bhx = 0.5f * (float)(xb - xa);
+    bcy = (float)y0 + 0.5f * (float)(ya + yb);
+    bhy = 0.5f * (float)(yb - ya);
+    return true;
+}
+
+// Two-deep staging pipeline shared by both kernels (macros so that the small
+// arrays stay in registers).  `first` is the list offset of the tile, `limit`
+// the number of usable entries (>= 1 whenever used).
+static_assert(kRec4 == 5, "staging macros are written out for 5 float4 per record");
+#define SLS_STAGE_DECL float4 sp0, sp1, sp2, sp3, sp4; uint32_t si0, si1, si2, si3, si4;
+#define SLS_IDX1(i_, first, b, limit) vals[(first) + (uint32_t)min((b) * kBatch + ((i_) * kThreads + tid) / kRec4, (limit) - 1)]
+#define SLS_STAGE_LOAD_IDX(first, b, limit)                                                    \
+    si0 = SLS_IDX1(0, first, b, limit); si1 = SLS_IDX1(1, first, b, limit);                     \
+    si2 = SLS_IDX1(2, first, b, limit); si3 = SLS_IDX1(3, first, b, limit);                     \
+    si4 = SLS_IDX1(4, first, b, limit);
+#define SLS_REC1(i_, idx_) rec[(size_t)(idx_) * kRec4 + (((i_) * kThreads + tid) % kRec4)]
+#define SLS_STAGE_LOAD_REC()                                                                   \
+    sp0 = SLS_REC1(0, si0); sp1 = SLS_REC1(1, si1); sp2 = SLS_REC1(2, si2);                     \
+    sp3 = SLS_REC1(3, si3); sp4 = SLS_REC1(4, si4);
+#define SLS_STAGE_STORE()                                                                      \
+    s_rec[0 * kThreads + tid] = sp0; s_rec[1 * kThreads + tid] = sp1;                           \
+    s_rec[2 * kThreads + tid] = sp2; s_rec[3 * kThreads + tid] = sp3;                           \
+    s_rec[4 * kThreads + tid] = sp4;
 
 // ---------------------------------------------------------------------------
 // A6 forward
@@ -81,10 +114,11 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
-    uint32_t *__restrict__ tile_consumed)
+    uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles)
 {
     __shared__ float4 s_rec[kBatch * kRec4];
     __shared__ uint32_t s_consumed;
+    const uint64_t t_start = dbg_cycles ? clock64() : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = cam.GX * cam.GY;
@@ -96,8 +130,7 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
     const int x0 = tx * kTileW + sub_x * 8, y0 = ty * kTileH + sub_y * 8;
     const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
     const bool inside = (px < cam.W) && (py < cam.H);
-    const float wcx = (float)x0 + 3.5f, wcy = (float)y0 + 3.5f;
-    const float Wf = (float)cam.W;
+    const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
 
     float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
     if (inside) {
@@ -114,64 +147,60 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
     if (tid == 0) s_consumed = 0;
 
     const int nb = (n + kBatch - 1) / kBatch;
-    float4 pre[kRec4];
-    auto prefetch = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < kRec4; ++i) {
-            const int k = i * kThreads + tid;
-            const int j = k / kRec4, q = k - j * kRec4;
-            const int gj = b * kBatch + j;
-            if (gj < n) {
-                const uint32_t idx = vals[range.x + gj];
-                pre[i] = rec[(size_t)idx * kRec4 + q];
-            } else pre[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    };
-    if (nb > 0) prefetch(0);
+    SLS_STAGE_DECL
+    if (nb > 0) {
+        SLS_STAGE_LOAD_IDX(range.x, 0, n)
+        SLS_STAGE_LOAD_REC()
+        if (nb > 1) { SLS_STAGE_LOAD_IDX(range.x, 1, n) }
+    }
 
     for (int b = 0; b < nb; ++b) {
         if (__syncthreads_and(wave_done ? 1 : 0)) break;
-#pragma unroll
-        for (int i = 0; i < kRec4; ++i) s_rec[i * kThreads + tid] = pre[i];
+        SLS_STAGE_STORE()
         __syncthreads();
-        if (b + 1 < nb) prefetch(b + 1);
+        if (b + 1 < nb) {
+            SLS_STAGE_LOAD_REC()
+            if (b + 2 < nb) { SLS_STAGE_LOAD_IDX(range.x, b + 2, n) }
+        }
         const int cnt = min(kBatch, n - b * kBatch);
-        if (!wave_done) {
-            for (int r = 0; r < kBatch / 64 && !wave_done; ++r) {
-                const int jl = r * 64 + lane;
-                bool pass = false;
-                if (jl < cnt) pass = cull_pass(s_rec[jl * kRec4 + 4], wcx, wcy, cam.wrap, Wf);
-                uint64_t mask = __ballot(pass);
-                while (mask) {
-                    const int jj = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int j = r * 64 + jj;
-                    const uint32_t contributor = (uint32_t)(b * kBatch + j + 1);
-                    const float4 q0 = s_rec[j * kRec4 + 0], q1 = s_rec[j * kRec4 + 1], q2 = s_rec[j * kRec4 + 2];
-                    const float4 q3 = s_rec[j * kRec4 + 3], q4 = s_rec[j * kRec4 + 4];
-                    Eval e;
-                    eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, cam.wrap, Wf, cam.near_c, e);
-                    if (!done && !e.skip) {
-                        const float testT = Tr * (1.0f - e.alpha);
-                        if (testT < SLS_T_MIN) {
-                            done = true;
-                            consumed = contributor;
-                        } else {
-                            const float w = e.alpha * Tr;
-                            const float A = 1.0f - Tr;
-                            const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(e.depth));
-                            dist += (m * m * A + M2 - 2.0f * m * M1) * w;
-                            D += e.depth * w;
-                            M1 += m * w;
-                            M2 += m * m * w;
-                            if (Tr > 0.5f) { med = e.depth; medc = contributor; }
-                            N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
-                            Tr = testT;
-                            last = contributor;
-                        }
-                    }
-                    if (__all(done)) { wave_done = true; break; }
-                }
+        for (int r = 0; r < kRounds && !wave_done; ++r) {
+            float bcx, bcy, bhx, bhy;
+            if (!active_box(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) { wave_done = true; break; }
+            const int jl = r * 64 + lane;
+            bool pass = false;
+            if (jl < cnt) pass = cull_pass(s_rec[jl * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+            uint64_t mask = __ballot(pass);
+            while (mask) {
+                const int jj = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int j = r * 64 + jj;
+                const uint32_t contributor = (uint32_t)(b * kBatch + j + 1);
+                const float4 q0 = s_rec[j * kRec4 + 0], q1 = s_rec[j * kRec4 + 1], q2 = s_rec[j * kRec4 + 2];
+                const float4 q3 = s_rec[j * kRec4 + 3], q4 = s_rec[j * kRec4 + 4];
+                Eval e;
+                eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
+                // fully predicated blend (no divergent branches): w == 0 leaves every accumulator unchanged
+                const float testT = Tr * (1.0f - e.alpha);
+                const bool live = !done && !e.skip;
+                const bool term = live && (testT < SLS_T_MIN);
+                const bool upd = live && !term;
+                const float w = upd ? e.alpha * Tr : 0.0f;
+                const float dep = upd ? e.depth : 1.0f;
+                const float A = 1.0f - Tr;
+                const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
+                dist += (m * m * A + M2 - 2.0f * m * M1) * w;
+                D += dep * w;
+                M1 += m * w;
+                M2 += m * m * w;
+                const bool is_med = upd && (Tr > 0.5f);
+                med = is_med ? dep : med;
+                medc = is_med ? contributor : medc;
+                N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
+                Tr = upd ? testT : Tr;
+                last = upd ? contributor : last;
+                consumed = term ? contributor : consumed;
+                done = done || term;
+                if (__all(done)) { wave_done = true; break; }
             }
         }
     }
@@ -199,6 +228,7 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
         __syncthreads();
         if (tid == 0) tile_consumed[tile] = s_consumed;
     }
+    if (dbg_cycles && lane == 0) dbg_cycles[tile * (kThreads / 64) + wave] = (uint32_t)(clock64() - t_start);
 }
 
 // ---------------------------------------------------------------------------
@@ -208,11 +238,12 @@ __global__ __launch_bounds__(kThreads) void render_bwd_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
-    const float *__restrict__ dL_dallmap, float *__restrict__ grec)
+    const float *__restrict__ dL_dallmap, float *__restrict__ grec, uint32_t *__restrict__ dbg_cycles)
 {
     __shared__ float4 s_rec[kBatch * kRec4];
     __shared__ float s_grad[kBatch * kGrec];
     __shared__ uint32_t s_max;
+    const uint64_t t_start = dbg_cycles ? clock64() : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = cam.GX * cam.GY;
@@ -223,10 +254,10 @@ __global__ __launch_bounds__(kThreads) void render_bwd_kernel(
     const int x0 = tx * kTileW + sub_x * 8, y0 = ty * kTileH + sub_y * 8;
     const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
     const bool inside = (px < cam.W) && (py < cam.H);
-    const float wcx = (float)x0 + 3.5f, wcy = (float)y0 + 3.5f;
-    const float Wf = (float)cam.W;
+    const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
     const float pc = (float)px, pr = (float)py;
     const float mscale = cam.far_c / (cam.far_c - cam.near_c);
+    const int my_comp = reduce16_component(lane);
 
     float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
     uint32_t last = 0, medc = 0;
@@ -263,42 +294,38 @@ __global__ __launch_bounds__(kThreads) void render_bwd_kernel(
     if (tmax == 0) return;
 
     const int nb = (tmax + kBatch - 1) / kBatch;
-    float4 pre[kRec4];
-    uint32_t pre_idx = 0, cur_idx = 0;
-    auto prefetch = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < kRec4; ++i) {
-            const int k = i * kThreads + tid;
-            const int j = k / kRec4, q = k - j * kRec4;
-            const int gj = b * kBatch + j;
-            if (gj < tmax) {
-                const uint32_t idx = vals[range.x + gj];
-                pre[i] = rec[(size_t)idx * kRec4 + q];
-            } else pre[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-        const int gt = b * kBatch + tid;
-        pre_idx = (gt < tmax) ? vals[range.x + gt] : 0u;
-    };
-    prefetch(nb - 1);
+    SLS_STAGE_DECL
+    SLS_STAGE_LOAD_IDX(range.x, nb - 1, tmax)
+    SLS_STAGE_LOAD_REC()
+    // surfel index of list entry (b*kBatch + tid), for the flush
+    uint32_t next_idx = vals[range.x + (uint32_t)min((nb - 1) * kBatch + tid, tmax - 1)];
+    if (nb > 1) { SLS_STAGE_LOAD_IDX(range.x, nb - 2, tmax) }
 
     float Tr = Tf, S = 0.0f;
     for (int b = nb - 1; b >= 0; --b) {
         __syncthreads();   // previous batch fully consumed and flushed
-#pragma unroll
-        for (int i = 0; i < kRec4; ++i) s_rec[i * kThreads + tid] = pre[i];
-        cur_idx = pre_idx;
+        SLS_STAGE_STORE()
+        const uint32_t cur_idx = next_idx;
         {
             float4 *z = reinterpret_cast<float4 *>(s_grad + tid * kGrec);
             z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
         }
         __syncthreads();
-        if (b > 0) prefetch(b - 1);
+        if (b > 0) {
+            SLS_STAGE_LOAD_REC()
+            next_idx = vals[range.x + (uint32_t)((b - 1) * kBatch + tid)];
+            if (b > 1) { SLS_STAGE_LOAD_IDX(range.x, b - 2, tmax) }
+        }
         const int cnt = min(kBatch, tmax - b * kBatch);
-        for (int r = kBatch / 64 - 1; r >= 0; --r) {
+        for (int r = kRounds - 1; r >= 0; --r) {
+            const uint32_t c_lo = (uint32_t)(b * kBatch + r * 64 + 1);   // smallest contributor of this round
+            if (c_lo > wmax) continue;
+            float bcx, bcy, bhx, bhy;
+            if (!active_box(__ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
             const int jl = r * 64 + lane;
             bool pass = false;
             if (jl < cnt && (uint32_t)(b * kBatch + jl + 1) <= wmax)
-                pass = cull_pass(s_rec[jl * kRec4 + 4], wcx, wcy, cam.wrap, Wf);
+                pass = cull_pass(s_rec[jl * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
             uint64_t mask = __ballot(pass);
             while (mask) {
                 const int jj = 63 - __builtin_clzll(mask);
@@ -308,77 +335,64 @@ __global__ __launch_bounds__(kThreads) void render_bwd_kernel(
                 const float4 q0 = s_rec[j * kRec4 + 0], q1 = s_rec[j * kRec4 + 1], q2 = s_rec[j * kRec4 + 2];
                 const float4 q3 = s_rec[j * kRec4 + 3], q4 = s_rec[j * kRec4 + 4];
                 Eval e;
-                eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, cam.wrap, Wf, cam.near_c, e);
+                eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
                 const bool act = inside && (contributor <= last) && !e.skip;
-                const uint64_t any = __ballot(act);
-                if (!any) continue;
+                if (!__ballot(act)) continue;
+                // predicated gradient (no divergent branches); selects, not products, gate the
+                // 3D/2D fields so an infinite rinv of an inactive lane cannot leak a NaN
+                const float om = act ? 1.0f - e.alpha : 1.0f;
+                const float rom = __builtin_amdgcn_rcpf(om);
+                Tr = Tr * rom;
+                const float w = act ? e.alpha * Tr : 0.0f;
+                const float dep = act ? e.depth : 1.0f;
+                const float rdep = __builtin_amdgcn_rcpf(dep);
+                const float m = mscale * (1.0f - cam.near_c * rdep);
+                const float dm_dd = mscale * cam.near_c * rdep * rdep;
+                const float gk = dD * dep + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA +
+                                 dDist * (M2 + m * m * Af - 2.0f * m * M1);
+                const float dL_dalpha = act ? Tr * gk - S * rom : 0.0f;
+                S += w * gk;
+                float dL_ddepth = w * dD + dDist * 2.0f * w * (m * Af - M1) * dm_dd;
+                dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
+                const bool unclamped = e.og < SLS_ALPHA_MAX;
+                const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
+                const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
+                const bool a3 = act && e.use3d, a2 = act && !e.use3d;
+                const float dL_du = dL_drho * 2.0f * e.u, dL_dv = dL_drho * 2.0f * e.v;
+                const float dL_dhu = a3 ? dL_du * e.rinv : 0.0f, dL_dhv = a3 ? dL_dv * e.rinv : 0.0f;
+                const float dL_drinv = dL_du * e.hu + dL_dv * e.hv + dL_ddepth * q0.w;
+                const float dL_dnd = a3 ? -dL_drinv * e.rinv * e.rinv : 0.0f;
                 float gl[kGrec];
-#pragma unroll
-                for (int k = 0; k < kGrec; ++k) gl[k] = 0.0f;
-                bool act3 = false, act2 = false;
-                if (act) {
-                    const float om = 1.0f - e.alpha;
-                    const float rom = __builtin_amdgcn_rcpf(om);
-                    Tr = Tr * rom;
-                    const float w = e.alpha * Tr;
-                    const float rdep = __builtin_amdgcn_rcpf(e.depth);
-                    const float m = mscale * (1.0f - cam.near_c * rdep);
-                    const float dm_dd = mscale * cam.near_c * rdep * rdep;
-                    const float gk = dD * e.depth + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA +
-                                     dDist * (M2 + m * m * Af - 2.0f * m * M1);
-                    const float dL_dalpha = Tr * gk - S * rom;
-                    S += w * gk;
-                    float dL_ddepth = w * dD + dDist * 2.0f * w * (m * Af - M1) * dm_dd;
-                    if (contributor == medc) dL_ddepth += dMed;
-                    float dL_do = 0.0f, dL_dG = 0.0f;
-                    if (e.og < SLS_ALPHA_MAX) { dL_do = dL_dalpha * e.G; dL_dG = dL_dalpha * q2.w; }
-                    const float dL_drho = -0.5f * e.G * dL_dG;
-                    gl[8] = w * dN0; gl[9] = w * dN1; gl[10] = w * dN2;
-                    gl[11] = dL_do;
-                    if (e.use3d) {
-                        act3 = true;
-                        const float dL_du = dL_drho * 2.0f * e.u, dL_dv = dL_drho * 2.0f * e.v;
-                        const float dL_dhu = dL_du * e.rinv, dL_dhv = dL_dv * e.rinv;
-                        const float dL_drinv = dL_du * e.hu + dL_dv * e.hv + dL_ddepth * q0.w;
-                        const float dL_dnd = -dL_drinv * e.rinv * e.rinv;
-                        gl[0] = dL_dhu * e.dl0; gl[1] = dL_dhu * e.dl1; gl[2] = dL_dhu * e.dl2;
-                        gl[3] = dL_ddepth * e.rinv;
-                        gl[4] = dL_dhv * e.dl0; gl[5] = dL_dhv * e.dl1; gl[6] = dL_dhv * e.dl2;
-                        gl[8] += dL_dnd * d0; gl[9] += dL_dnd * d1; gl[10] += dL_dnd * d2;
-                        gl[12] = dL_dhu;
-                        gl[13] = dL_dhv;
-                    } else {
-                        act2 = true;
-                        gl[7] = dL_ddepth;
-                        gl[14] = -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dx;
-                        gl[15] = -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy;
-                    }
-                }
-                const bool any3 = __ballot(act3) != 0, any2 = __ballot(act2) != 0;
-                float *sg = s_grad + j * kGrec;
-#pragma unroll
-                for (int k = 0; k < kGrec; ++k) {
-                    const bool is3 = (k <= 6) || k == 12 || k == 13;
-                    const bool is2 = (k == 7) || (k == 14) || (k == 15);
-                    if (is3 && !any3) continue;
-                    if (is2 && !any2) continue;
-                    const float tot = wave_sum_to_lane63(gl[k]);
-                    if (lane == 63) atomicAdd(&sg[k], tot);
-                }
+                gl[0] = dL_dhu * e.dl0; gl[1] = dL_dhu * e.dl1; gl[2] = dL_dhu * e.dl2;
+                gl[3] = a3 ? dL_ddepth * e.rinv : 0.0f;
+                gl[4] = dL_dhv * e.dl0; gl[5] = dL_dhv * e.dl1; gl[6] = dL_dhv * e.dl2;
+                gl[7] = a2 ? dL_ddepth : 0.0f;
+                gl[8] = w * dN0 + dL_dnd * d0; gl[9] = w * dN1 + dL_dnd * d1; gl[10] = w * dN2 + dL_dnd * d2;
+                gl[11] = dL_do;
+                gl[12] = dL_dhu;
+                gl[13] = dL_dhv;
+                gl[14] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dx : 0.0f;
+                gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
+                const float tot = wave_reduce16(gl, lane);
+                if (lane < 16 && tot != 0.0f) atomicAdd(&s_grad[j * kGrec + my_comp], tot);
             }
         }
         __syncthreads();
         if (tid < cnt) {
-            const float *sg = s_grad + tid * kGrec;
+            const float *sgr = s_grad + tid * kGrec;
             float *g = grec + (size_t)cur_idx * kGrec;
 #pragma unroll
             for (int k = 0; k < kGrec; ++k) {
-                const float v = sg[k];
+                const float v = sgr[k];
                 if (v != 0.0f) atomicAdd(&g[k], v);
             }
         }
     }
+    if (dbg_cycles && lane == 0) dbg_cycles[tile * (kThreads / 64) + wave] = (uint32_t)(clock64() - t_start);
 }
+
+// diagnostic: per-wave shader-clock counts (sls_debug_wave_cycles)
+uint32_t *g_dbg_fwd_cycles = nullptr, *g_dbg_bwd_cycles = nullptr;
 
 // ---------------------------------------------------------------------------
 int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
@@ -389,7 +403,7 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
     ScopedTimer tm(T_RENDER_FWD, st);
     hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(kThreads), 0, st, cam, (const uint2 *)ranges, vals,
                        (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,
-                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed);
+                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles);
     SLS_LAUNCH_CHECK("render_fwd_kernel");
     return SLS_OK;
 }
@@ -402,7 +416,7 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
     ScopedTimer tm(T_RENDER_BWD, st);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(T), dim3(kThreads), 0, st, cam, (const uint2 *)ranges, vals,
                        (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
-                       (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec);
+                       (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, g_dbg_bwd_cycles);
     SLS_LAUNCH_CHECK("render_bwd_kernel");
     return SLS_OK;
 }

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave cycle distribution of the tile kernels on the bench scene."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from splat_loam_amd import _abi, synth
+from splat_loam_amd.rasterizer import GaussianRasterizationSettings, rasterize_forward, rasterize_backward
+N, H, W = 500000, 64, 2048
+dev = torch.device("cuda:0")
+sc = synth.make_scene(N, H, W, seed=0)
+view, proj = synth.camera_matrices(sc["K"])
+s = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=dev), torch.tensor(proj, device=dev))
+t = {k: torch.tensor(sc[k], device=dev) for k in ("means", "scales", "rots", "opac")}
+tw, th = _abi.tile_size(); T = (W // tw) * (H // th); wpt = tw * th // 64
+f = torch.zeros(T * wpt, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
+_abi.lib().sls_debug_wave_cycles(f.data_ptr(), b.data_ptr())
+for _ in range(2):
+    st = rasterize_forward(s, t["means"], t["opac"], t["scales"], t["rots"])
+    rasterize_backward(st, t["means"], t["scales"], t["rots"], torch.randn(7, H, W, device=dev))
+torch.cuda.synchronize()
+_abi.lib().sls_debug_wave_cycles(None, None)
+cons = st.tile_consumed.cpu().numpy().view(np.uint32)
+for name, a in (("fwd", f), ("bwd", b)):
+    c = a.cpu().numpy().astype(np.int64).reshape(T, wpt)
+    tile = c.max(1)
+    print(name, "wave cycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max()))
+    print(name, "per tile-row max:", tile.reshape(H // th, W // tw).max(1), "mean:", tile.reshape(H // th, W // tw).mean(1).astype(int))
+    k = np.argsort(tile)[-5:]
+    print(name, "slowest tiles", k, "cycles", tile[k], "consumed", cons[k])
+print("consumed mean", cons.mean(), "max", cons.max(), "sum", cons.sum())
