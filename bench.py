@@ -57,6 +57,7 @@ def algorithmic_bytes(name, N, R, R_eff, P, n_sort_passes):
         "render_bwd": R_eff * (84 + 64) + P * (28 + 24),
         "preprocess_bwd": N * (40 + 4 + 64 + 40),
         "adam": N * 10 * 28,
+        "consumer": P * (2 * 28 + 5 + 4 + 2 * 48 + 28),
     }.get(name, 0)
 
 
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--unfused", action="store_true",
+                    help="torch render()/loss glue instead of the fused HIP consumer (same maths)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,7 +88,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from splat_loam_amd import _abi, synth
-    from splat_loam_amd.mapping import MappingConfig, optimize_step_sharded
+    from splat_loam_amd.mapping import MappingConfig, optimize_step_fused, optimize_step_sharded
     from splat_loam_amd.scene import Camera, SurfelModel
 
     lib = _abi.lib()
@@ -99,7 +102,9 @@ def main():
     cfg = MappingConfig()
 
     def step():
-        return optimize_step_sharded(model, cam, cfg)
+        if args.unfused:
+            return optimize_step_sharded(model, cam, cfg)
+        return optimize_step_fused(model, cam, cfg)
 
     def barrier():
         if world > 1:
@@ -204,7 +209,8 @@ def main():
         "metric": "fwd+bwd Msplats/s", "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU: render fwd + mapper loss + bwd + fused Adam",
+        "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU: render fwd + mapper loss + bwd + fused Adam"
+                               + (" (torch loss glue)" if args.unfused else " (HIP loss consumer)"),
                    "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff,
                    "parallelism": f"keyframe-dp{world}"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,

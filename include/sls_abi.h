@@ -16,6 +16,9 @@
  *   distCUDA2(points)  slam/mapper.py:113-115,                  sls_knn_dist2
  *     scene/gaussian_model.py:77-81
  *   GaussianRasterizer.markVisible (lineage API, unused in tree) sls_mark_visible
+ *   render() post-processing + depth_to_normal + mapper loss     sls_consumer_fwd_bwd
+ *     gaussian_renderer/__init__.py:48-93,                       ("next" row 1)
+ *     utils/graphic_utils.py:26-88, slam/mapper.py:158-187
  *
  * Conventions
  *   - plain C, no torch types; all pointers are DEVICE pointers to
@@ -76,6 +79,10 @@ int sls_camera_from_matrices(const float *view_host, const float *proj_host, int
  * pixel rays, evaluated in double and rounded once.  col_cs_host: 2*W floats,
  * row_cs_host: 2*H floats.  The caller uploads them (they depend on K only). */
 int sls_ray_tables(const SlsCamera *cam, float *col_cs_host, float *row_cs_host);
+/* Same at image coordinate (c + col_offset, r + row_offset); the reference's
+ * back-projection uses (-0.5, -0.5) (utils/graphic_utils.py:46-49). */
+int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, float *col_cs_host,
+                      float *row_cs_host);
 
 /* ---- forward, stage 1: preprocess + scan -------------------------------
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
@@ -125,6 +132,21 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R,
                  const float *dL_dallmap, float *grec,
                  float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
                  float *dL_dopacities, void *stream);
+
+/* ---- fused consumer of allmap: render() post-processing + mapper loss ------
+ * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of
+ * slam/mapper.py:174-187 on top of the maps of gaussian_renderer/__init__.py:48-93
+ * and writes dL/dallmap (7*H*W) for a loss weight of 1.
+ *   loss_sums (4 floats, device): [sum_valid |s-gt|, sum_valid (1-<n_hat,n_surf*alpha>),
+ *                                  sum_valid BCE(alpha,1), total]
+ *   total = sums[0]/(H*W) + lambda_normal*sums[1]/n_valid + lambda_alpha*sums[2]/n_valid
+ * gt_depth: H*W floats, valid: H*W uint8 (1 = valid), col_cs_half/row_cs_half: ray
+ * tables at offset (-0.5,-0.5) (device), n_valid: number of valid pixels (host). */
+size_t sls_consumer_scratch_bytes(int H, int W);
+int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
+                         const float *col_cs_half, const float *row_cs_half, float depth_ratio,
+                         float lambda_normal, float lambda_alpha, int n_valid, float *loss_sums,
+                         float *dL_dallmap, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- fused Adam over up to 8 parameter tensors in one launch ------------
  * torch.optim.Adam semantics (no weight decay, no amsgrad); step is 1-based

@@ -43,6 +43,10 @@ _PROTOS = {
     "sls_grec_stride": (C.c_int, []),
     "sls_camera_from_matrices": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.POINTER(SlsCamera)]),
     "sls_ray_tables": (C.c_int, [C.POINTER(SlsCamera), _VP, _VP]),
+    "sls_ray_tables_at": (C.c_int, [C.POINTER(SlsCamera), C.c_float, C.c_float, _VP, _VP]),
+    "sls_consumer_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sls_consumer_fwd_bwd": (C.c_int, [C.c_int, C.c_int] + [_VP] * 5 + [C.c_float] * 3 + [C.c_int, _VP, _VP, _VP,
+                                                                                         C.c_size_t, _VP]),
     "sls_stage1_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 11 + [_VP, C.c_size_t, _VP]),
     "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),

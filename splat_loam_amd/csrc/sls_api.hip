@@ -63,6 +63,11 @@ int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
+size_t consumer_scratch_bytes(int H, int W);
+int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
+                    const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
+                    int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
+                    hipStream_t st);
 extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
 size_t knn_scratch_bytes(int M);
 int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
@@ -201,14 +206,19 @@ int sls_camera_from_matrices(const float *view, const float *proj, int H, int W,
 
 int sls_ray_tables(const SlsCamera *cam, float *col_cs, float *row_cs)
 {
+    return sls_ray_tables_at(cam, 0.0f, 0.0f, col_cs, row_cs);
+}
+
+int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, float *col_cs, float *row_cs)
+{
     SLS_REQUIRE(cam && col_cs && row_cs, "null pointer");
     for (int c = 0; c < cam->W; ++c) {
-        const double a = ((double)c - (double)cam->cx) / (double)cam->fx;
+        const double a = ((double)c + (double)col_offset - (double)cam->cx) / (double)cam->fx;
         col_cs[2 * c] = (float)cos(a);
         col_cs[2 * c + 1] = (float)sin(a);
     }
     for (int r = 0; r < cam->H; ++r) {
-        const double e = ((double)r - (double)cam->cy) / (double)cam->fy;
+        const double e = ((double)r + (double)row_offset - (double)cam->cy) / (double)cam->fy;
         row_cs[2 * r] = (float)cos(e);
         row_cs[2 * r + 1] = (float)sin(e);
     }
@@ -328,6 +338,21 @@ int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double 
     }
     SLS_LAUNCH_CHECK("adam_kernel");
     return SLS_OK;
+}
+
+size_t sls_consumer_scratch_bytes(int H, int W) { return (H > 0 && W > 0) ? consumer_scratch_bytes(H, W) : 0; }
+
+int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
+                         const float *col_cs_half, const float *row_cs_half, float depth_ratio,
+                         float lambda_normal, float lambda_alpha, int n_valid, float *loss_sums,
+                         float *dL_dallmap, void *scratch, size_t scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(H > 0 && W > 0 && n_valid >= 0, "bad size");
+    SLS_REQUIRE(allmap && gt_depth && valid && col_cs_half && row_cs_half && loss_sums && dL_dallmap && scratch,
+                "null pointer");
+    return launch_consumer(H, W, allmap, gt_depth, valid, col_cs_half, row_cs_half, depth_ratio, lambda_normal,
+                           lambda_alpha, n_valid, loss_sums, dL_dallmap, scratch, scratch_bytes,
+                           (hipStream_t)stream);
 }
 
 size_t sls_knn_scratch_bytes(int M) { return knn_scratch_bytes(M); }

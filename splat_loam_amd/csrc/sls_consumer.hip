@@ -1,0 +1,198 @@
+// sls_consumer.hip — the consumer of allmap fused into two small kernels:
+// render()'s post-processing (gaussian_renderer/__init__.py:48-93), the
+// spherical back-projection + central-difference normals it calls
+// (utils/graphic_utils.py:26-88) and the per-pixel terms of the mapper's loss
+// (slam/mapper.py:158-187), forward AND gradient w.r.t. allmap.
+// in the reference this stage is ~85 tiny torch kernels plus
+// host syncs per iteration and costs more than the rasterizer itself.
+//
+//   loss = mean_all |valid (s - gt)|                              (geom, :174-175)
+//        + lambda_n * mean_valid (1 - <n_hat, n_surf * alpha>)    (normal, :177-180)
+//        + lambda_a * mean_valid BCE(alpha, 1)                    (alpha, :182-187)
+//   s      = D/alpha * (1 - depth_ratio) + median * depth_ratio   (surf_depth)
+//   n_hat  = N/alpha (view frame; the loss is rotation invariant, so nothing is
+//            rotated to the world frame here)
+//   n_surf = normalize((P[r+1,c]-P[r-1,c]) x (P[r,c+1]-P[r,c-1])), P = s * ray(c-.5, r-.5),
+//            zero on the 1-pixel border.
+// Kernel B (per pixel): loss terms (block-reduced, one atomic per block and
+// term) + the stencil's adjoint pieces dL/du, dL/dv; kernel C (per pixel):
+// gathers the four neighbours' pieces and writes dL/dallmap.  HBM-bound,
+// ~100 B/pixel.
+#include "sls_common.hpp"
+
+namespace sls {
+
+struct ConsumerArgs {
+    int H, W;
+    float depth_ratio, lambda_n, lambda_a;
+    float inv_P, inv_nv;      // 1/(H*W), 1/n_valid (0 if n_valid == 0)
+    const float *allmap, *gt_depth;
+    const uint8_t *valid;
+    const float2 *col_h, *row_h;   // half-pixel ray tables
+    float4 *du, *dv, *ns;          // scratch: dL/du, dL/dv, (n_surf, dot)
+    float *sums;                   // [geom, normal, alpha, total]
+    float *dL_dallmap;
+};
+
+__device__ __forceinline__ float3 surf_point(const ConsumerArgs &a, int r, int c, float &s_out)
+{
+    const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
+    const float al = a.allmap[SLS_CH_ALPHA * P + pix];
+    const float D = a.allmap[SLS_CH_DEPTH * P + pix];
+    const float med = a.allmap[SLS_CH_MEDIAN * P + pix];
+    const float Dh = (al > 0.0f) ? D / al : D;
+    const float s = Dh * (1.0f - a.depth_ratio) + med * a.depth_ratio;
+    const float2 cc = a.col_h[c], rr = a.row_h[r];
+    s_out = s;
+    return make_float3(s * cc.x * rr.x, s * cc.y * rr.x, s * rr.y);
+}
+
+__global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float lg = 0.0f, ln = 0.0f, la = 0.0f;
+    if (c < a.W && r < a.H) {
+        const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
+        const bool valid = a.valid[pix] == 1;
+        const float al = a.allmap[SLS_CH_ALPHA * P + pix];
+        const bool hit = al > 0.0f;
+        const float inv = hit ? 1.0f / al : 1.0f;
+        const float n0 = a.allmap[(SLS_CH_NORMAL + 0) * P + pix] * inv;
+        const float n1 = a.allmap[(SLS_CH_NORMAL + 1) * P + pix] * inv;
+        const float n2 = a.allmap[(SLS_CH_NORMAL + 2) * P + pix] * inv;
+        float s;
+        (void)surf_point(a, r, c, s);
+        float4 du = make_float4(0, 0, 0, 0), dv = du, nsd = du;
+        const bool interior = (r > 0) && (r < a.H - 1) && (c > 0) && (c < a.W - 1);
+        if (interior) {
+            float t;
+            const float3 pu = surf_point(a, r + 1, c, t), pd = surf_point(a, r - 1, c, t);
+            const float3 pr = surf_point(a, r, c + 1, t), pl = surf_point(a, r, c - 1, t);
+            const float u0 = pu.x - pd.x, u1 = pu.y - pd.y, u2 = pu.z - pd.z;
+            const float v0 = pr.x - pl.x, v1 = pr.y - pl.y, v2 = pr.z - pl.z;
+            const float c0 = u1 * v2 - u2 * v1, c1 = u2 * v0 - u0 * v2, c2 = u0 * v1 - u1 * v0;
+            const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+            const float rden = 1.0f / fmaxf(len, 1e-12f);            // F.normalize eps
+            const float s0 = c0 * rden, s1 = c1 * rden, s2 = c2 * rden;
+            const float dot = n0 * s0 + n1 * s1 + n2 * s2;
+            nsd = make_float4(s0, s1, s2, dot);
+            if (valid) {
+                // dL/dn_surf = -lambda_n/Nv * alpha * n_hat ; through normalize ; through the cross product
+                const float k = -a.lambda_n * a.inv_nv * al;
+                float g0 = k * n0, g1 = k * n1, g2 = k * n2;
+                if (len > 1e-12f) {
+                    const float gd = g0 * s0 + g1 * s1 + g2 * s2;
+                    g0 = (g0 - gd * s0) * rden; g1 = (g1 - gd * s1) * rden; g2 = (g2 - gd * s2) * rden;
+                } else {
+                    g0 *= rden; g1 *= rden; g2 *= rden;
+                }
+                // cr = u x v : dL/du = v x g, dL/dv = g x u
+                du = make_float4(v1 * g2 - v2 * g1, v2 * g0 - v0 * g2, v0 * g1 - v1 * g0, 0.0f);
+                dv = make_float4(g1 * u2 - g2 * u1, g2 * u0 - g0 * u2, g0 * u1 - g1 * u0, 0.0f);
+            }
+        }
+        a.du[pix] = du; a.dv[pix] = dv; a.ns[pix] = nsd;
+        if (valid) {
+            lg = fabsf(s - a.gt_depth[pix]);
+            ln = 1.0f - al * nsd.w;
+            la = -fmaxf(logf(al), -100.0f);                            // torch BCE clamps log at -100
+        }
+    }
+    // block reduction -> one atomic per block and term
+    __shared__ float s_part[3][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lg += __shfl_down(lg, off, 64);
+        ln += __shfl_down(ln, off, 64);
+        la += __shfl_down(la, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_part[0][wave] = lg; s_part[1][wave] = ln; s_part[2][wave] = la; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float v = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
+        if (v != 0.0f) atomicAdd(&a.sums[threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void consumer_c_kernel(ConsumerArgs a)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        a.sums[3] = a.sums[0] * a.inv_P + a.lambda_n * a.inv_nv * a.sums[1] + a.lambda_a * a.inv_nv * a.sums[2];
+    if (c >= a.W || r >= a.H) return;
+    const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
+    const bool valid = a.valid[pix] == 1;
+    const float al = a.allmap[SLS_CH_ALPHA * P + pix];
+    const float D = a.allmap[SLS_CH_DEPTH * P + pix];
+    const float N0 = a.allmap[(SLS_CH_NORMAL + 0) * P + pix];
+    const float N1 = a.allmap[(SLS_CH_NORMAL + 1) * P + pix];
+    const float N2 = a.allmap[(SLS_CH_NORMAL + 2) * P + pix];
+    const bool hit = al > 0.0f;
+    const float inv = hit ? 1.0f / al : 1.0f;
+    float s;
+    (void)surf_point(a, r, c, s);
+    // gather the stencil adjoint: P(r,c) enters u(r-1,c) with +, u(r+1,c) with -, v(r,c-1) with +, v(r,c+1) with -
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    if (r > 0) { const float4 t = a.du[pix - a.W]; g0 += t.x; g1 += t.y; g2 += t.z; }
+    if (r < a.H - 1) { const float4 t = a.du[pix + a.W]; g0 -= t.x; g1 -= t.y; g2 -= t.z; }
+    if (c > 0) { const float4 t = a.dv[pix - 1]; g0 += t.x; g1 += t.y; g2 += t.z; }
+    if (c < a.W - 1) { const float4 t = a.dv[pix + 1]; g0 -= t.x; g1 -= t.y; g2 -= t.z; }
+    const float2 cc = a.col_h[c], rr = a.row_h[r];
+    float ds = g0 * cc.x * rr.x + g1 * cc.y * rr.x + g2 * rr.y;
+    const float4 nsd = a.ns[pix];
+    float da = 0.0f, dn0 = 0.0f, dn1 = 0.0f, dn2 = 0.0f;
+    if (valid) {
+        const float diff = s - a.gt_depth[pix];
+        ds += ((diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f)) * a.inv_P;
+        const float k = -a.lambda_n * a.inv_nv;
+        dn0 = k * al * nsd.x; dn1 = k * al * nsd.y; dn2 = k * al * nsd.z;
+        da = k * nsd.w + a.lambda_a * a.inv_nv * (al - 1.0f) / fmaxf((1.0f - al) * al, 1e-12f);   // torch BCE backward
+    }
+    const float dDh = (1.0f - a.depth_ratio) * ds;
+    if (hit) da -= (dDh * D + dn0 * N0 + dn1 * N1 + dn2 * N2) * inv * inv;
+    a.dL_dallmap[SLS_CH_DEPTH * P + pix] = dDh * inv;
+    a.dL_dallmap[SLS_CH_ALPHA * P + pix] = da;
+    a.dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix] = dn0 * inv;
+    a.dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix] = dn1 * inv;
+    a.dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix] = dn2 * inv;
+    a.dL_dallmap[SLS_CH_MEDIAN * P + pix] = a.depth_ratio * ds;
+    a.dL_dallmap[SLS_CH_DIST * P + pix] = 0.0f;
+}
+
+size_t consumer_scratch_bytes(int H, int W) { return sizeof(float4) * 3 * (size_t)H * (size_t)W; }
+
+int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
+                    const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
+                    int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
+                    hipStream_t st)
+{
+    if (scratch_bytes < consumer_scratch_bytes(H, W)) {
+        set_error("consumer scratch too small");
+        return SLS_E_SCRATCH;
+    }
+    ConsumerArgs a;
+    a.H = H; a.W = W;
+    a.depth_ratio = depth_ratio; a.lambda_n = lambda_n; a.lambda_a = lambda_a;
+    a.inv_P = 1.0f / ((float)H * (float)W);
+    a.inv_nv = n_valid > 0 ? 1.0f / (float)n_valid : 0.0f;
+    a.allmap = allmap; a.gt_depth = gt_depth; a.valid = valid;
+    a.col_h = (const float2 *)col_h; a.row_h = (const float2 *)row_h;
+    a.du = (float4 *)scratch;
+    a.dv = a.du + (size_t)H * W;
+    a.ns = a.dv + (size_t)H * W;
+    a.sums = sums;
+    a.dL_dallmap = dL_dallmap;
+    ScopedTimer tm(T_CONSUMER, st);
+    SLS_HIP_CHECK(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
+    const dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(consumer_b_kernel, grid, dim3(256), 0, st, a);
+    SLS_LAUNCH_CHECK("consumer_b_kernel");
+    hipLaunchKernelGGL(consumer_c_kernel, grid, dim3(256), 0, st, a);
+    SLS_LAUNCH_CHECK("consumer_c_kernel");
+    return SLS_OK;
+}
+
+}  // namespace sls

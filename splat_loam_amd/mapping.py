@@ -51,6 +51,23 @@ def optimize_step(model, camera, cfg: MappingConfig, **render_kw) -> torch.Tenso
     return loss.detach()
 
 
+def optimize_step_fused(model, camera, cfg: MappingConfig, group=None, average: bool = False) -> torch.Tensor:
+    """The same iteration with the consumer fused into HIP (fused.py): rasterizer
+    forward -> sls_consumer_fwd_bwd -> rasterizer backward -> fused Adam.  With a
+    process group: keyframe-parallel, gradients all-reduced, regulariser on rank 0."""
+    from .fused import fused_loss
+    model.optimizer.zero_grad(set_to_none=True)
+    sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if sharded else 0
+    loss = fused_loss(model, camera, cfg, with_regulariser=(rank == 0))
+    loss.backward()
+    if sharded:
+        flat_grad_allreduce(model, group, average)
+    with torch.no_grad():
+        model.optimizer.step()
+    return loss.detach()
+
+
 def flat_grad_allreduce(model, group=None, average: bool = False) -> None:
     """all-reduce(SUM) of the four gradient tensors as ONE flat bucket
     (40 B/surfel: 20 MB at 500k) — a single large collective suits xGMI's

@@ -308,3 +308,62 @@ def test_full_size_properties(device):
         assert np.isfinite(z).all()
         scale = np.abs(z).max()
         assert np.abs((x + y) - z).max() <= 2e-4 * scale, "backward is linear in dL/dallmap"
+
+
+def test_fused_consumer_matches_torch_render_and_loss(device):
+    """sls_consumer_fwd_bwd == mapping_loss(postprocess(allmap)) in value and in
+    dL/dallmap (the torch path is itself pinned to the reference by G2/G5)."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.fused import fused_pixel_loss
+    from splat_loam_amd.mapping import MappingConfig, mapping_loss
+    from splat_loam_amd.renderer import postprocess
+    from splat_loam_amd.scene import Camera, SurfelModel
+    for (H, W, ratio, hfov) in ((32, 256, 0.0, 360.0), (40, 200, 0.3, 120.0)):
+        sc, view, proj = scene_and_camera(6000, H, W, seed=8, hfov_deg=hfov, range_lo=2.0, range_hi=15.0)
+        depth, valid = synth.make_targets(H, W, sc)
+        valid = valid.copy(); valid[0, :3, :7] = 0; valid[0, H // 2, ::5] = 0
+        cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+        view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(2)[1])
+        st, _ = hip_forward(device, sc, view, proj, H, W)
+        cfg = MappingConfig(depth_ratio=ratio, opt_scaling_max_penalty=0.0)
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+        am1 = st.allmap.clone().double().requires_grad_(True)       # float64 torch reference
+        cam64 = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+        l_ref = mapping_loss(postprocess(cam64, am1.float(), ratio), cam64, model, cfg)
+        l_ref.backward()
+        am2 = st.allmap.clone().requires_grad_(True)
+        l_hip = fused_pixel_loss(am2, cam, cfg)
+        (3.0 * l_hip).backward()
+        assert abs(float(l_hip) - float(l_ref)) <= 2e-5 * abs(float(l_ref))
+        g_ref, g_hip = am1.grad.float().cpu().numpy(), am2.grad.cpu().numpy() / 3.0
+        for c in range(7):
+            scale = max(np.abs(g_ref[c]).max(), 1e-30)
+            assert np.abs(g_hip[c] - g_ref[c]).max() <= 2e-4 * scale + 1e-12, (H, W, c)
+
+
+def test_fused_step_matches_unfused_step(device):
+    """optimize_step_fused (HIP consumer + fused Adam) tracks optimize_step (torch
+    render/loss + torch Adam) over 3 iterations."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.mapping import MappingConfig, optimize_step, optimize_step_fused
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=12, range_lo=2.0, range_hi=15.0, scale_hi=0.2)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, None, data_device=str(device))
+    cfg = MappingConfig()
+    a = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+    b = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+    a.training_setup(fused=False); b.training_setup(fused=True)
+    names = ("_xyz", "_scaling", "_rotation", "_opacity")
+    init = {k: getattr(a, k).detach().clone() for k in names}
+    for _ in range(3):
+        la = float(optimize_step(a, cam, cfg)); lb = float(optimize_step_fused(b, cam, cfg))
+        assert abs(la - lb) <= 1e-4 * abs(la)
+    for k in names:
+        pa, pb = getattr(a, k).detach(), getattr(b, k).detach()
+        moved = float((pa - init[k]).abs().max())
+        # Adam normalises every gradient to a step of about lr, so surfels with a
+        # near-zero gradient amplify rounding differences; bound the drift by a
+        # fraction of the distance actually travelled
+        assert moved > 0 and float((pa - pb).abs().max()) <= 0.05 * moved, k
