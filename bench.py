@@ -71,8 +71,12 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--unfused", action="store_true",
-                    help="torch render()/loss glue instead of the fused HIP consumer (same maths)")
+    ap.add_argument("--mode", choices=("engine", "fused", "unfused"), default="engine",
+                    help="engine: one native sls_mapping_step per iteration (default); fused: torch autograd around "
+                         "the HIP rasterizer + HIP loss consumer; unfused: torch render()/loss glue (same maths)")
+    ap.add_argument("--async-steps", action="store_true",
+                    help="engine mode: do not read the status word after every iteration (the reference syncs once "
+                         "per iteration for its loss EMA, slam/mapper.py:206-209; default keeps that sync)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,8 +105,15 @@ def main():
     model.training_setup(fused=True)
     cfg = MappingConfig()
 
+    engine = None
+    if args.mode == "engine":
+        from splat_loam_amd.engine import MappingEngine
+        engine = MappingEngine(model, cfg)
+
     def step():
-        if args.unfused:
+        if engine is not None:
+            return engine.step(cam, sync=not args.async_steps)
+        if args.mode == "unfused":
             return optimize_step_sharded(model, cam, cfg)
         return optimize_step_fused(model, cam, cfg)
 
@@ -122,6 +133,8 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if engine is not None and args.async_steps:
+        assert not engine._read_status()["overflow"], "instance buffers overflowed during the timed region"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,7 +223,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU: render fwd + mapper loss + bwd + fused Adam"
-                               + (" (torch loss glue)" if args.unfused else " (HIP loss consumer)"),
+                               + {"engine": " (one native sls_mapping_step per iteration)",
+                                  "fused": " (torch autograd + HIP loss consumer)",
+                                  "unfused": " (torch loss glue)"}[args.mode],
                    "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff,
                    "parallelism": f"keyframe-dp{world}"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,

@@ -16,6 +16,7 @@
  *   distCUDA2(points)  slam/mapper.py:113-115,                  sls_knn_dist2
  *     scene/gaussian_model.py:77-81
  *   GaussianRasterizer.markVisible (lineage API, unused in tree) sls_mark_visible
+ *   one iteration of Mapper.optimize  slam/mapper.py:150-204     sls_mapping_step
  *   render() post-processing + depth_to_normal + mapper loss     sls_consumer_fwd_bwd
  *     gaussian_renderer/__init__.py:48-93,                       ("next" row 1)
  *     utils/graphic_utils.py:26-88, slam/mapper.py:158-187
@@ -84,35 +85,39 @@ int sls_ray_tables(const SlsCamera *cam, float *col_cs_host, float *row_cs_host)
 int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, float *col_cs_host,
                       float *row_cs_host);
 
-/* ---- forward, stage 1: preprocess + scan -------------------------------
+/* ---- forward, stage 1: preprocess + depth order + scan ---------------------
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
  * tiles_touched: N uint32, depth: N floats (range of the centre, the sort key),
- * offsets: N uint32 (inclusive scan of tiles_touched),
+ * order: N uint32 = surfel index at each position of the (depth, index) order,
+ * offsets: N uint32 = inclusive scan of tiles_touched[order[.]],
  * total_out: 1 uint32 on the DEVICE = number of tile instances R.
  * The caller reads total_out (one D2H sync, as the lineage does) to size the
- * stage-2 buffers. */
+ * stage-2 buffers (sls_mapping_step has no such sync). */
 size_t sls_stage1_scratch_bytes(int N);
 int sls_forward_stage1(const SlsCamera *cam, int N,
                        const float *means3D, const float *scales, const float *rotations,
                        const float *opacities,
                        float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles_touched,
-                       float *depth, uint32_t *offsets, uint32_t *total_out,
+                       float *depth, uint32_t *order, uint32_t *offsets, uint32_t *total_out,
                        void *scratch, size_t scratch_bytes, void *stream);
 
-/* ---- forward, stage 2: keys, radix sort, ranges, per-tile render -------
- * keys/keys_tmp: R uint64, vals/vals_tmp: R uint32 (ping-pong), ranges: T*2
- * uint32 with T = ceil(W/tw)*ceil(H/th).  On return *sorted_in_tmp tells
- * which pair holds the sorted list (0: keys/vals, 1: keys_tmp/vals_tmp).
- * allmap: 7*H*W floats; pix_state: H*W float4 {T_final, M1, M2, 0};
- * pix_contrib: H*W uint2 {n_contrib, median_contrib};
- * tile_consumed: T uint32 (list entries consumed before the tile finished,
- * the R_eff of SURVEY §8d). */
+/* ---- forward, stage 2: binning, stable sort by tile, ranges, per-tile render
+ * total_dev: the device word stage 1 wrote (= R).  tile_keys/vals and the _tmp
+ * pair: R uint32 each (ping-pong); on return *sorted_in_tmp tells which pair
+ * holds the sorted list (tile id, surfel index).  keys64_out (optional, R
+ * uint64): the 64-bit keys (tile << 32 | depth bits) the list is ordered by.
+ * ranges: T*2 uint32 with T = ceil(W/tw)*ceil(H/th).  allmap: 7*H*W floats;
+ * pix_state: H*W float4 {T_final, M1, M2, 0}; pix_contrib: H*W uint2
+ * {n_contrib, median_contrib}; tile_consumed: T uint32 (list entries consumed
+ * before the tile finished, the R_eff of SURVEY §8d). */
 size_t sls_sort_scratch_bytes(uint64_t R);
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
                        const float *rec, const int32_t *rect, const uint32_t *tiles_touched,
-                       const float *depth, const uint32_t *offsets,
-                       uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp,
+                       const float *depth, const uint32_t *order, const uint32_t *offsets,
+                       const uint32_t *total_dev,
+                       uint32_t *tile_keys, uint32_t *vals, uint32_t *tile_keys_tmp, uint32_t *vals_tmp,
                        void *sort_scratch, size_t sort_scratch_bytes, int *sorted_in_tmp,
+                       uint64_t *keys64_out,
                        uint32_t *ranges, const float *col_cs, const float *row_cs,
                        float *allmap, float *pix_state, uint32_t *pix_contrib,
                        uint32_t *tile_consumed, void *stream);
@@ -148,6 +153,43 @@ int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_dept
                          float lambda_normal, float lambda_alpha, int n_valid, float *loss_sums,
                          float *dL_dallmap, void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---- one whole mapping iteration, enqueued without any host sync -----------
+ * slam/mapper.py:150-204 for one keyframe: activations (scene/gaussian_model.py:
+ * 39-44) -> rasterizer forward -> sls_consumer_fwd_bwd -> rasterizer backward ->
+ * activation backward + scale regulariser (slam/mapper.py:190-195) -> Adam.
+ * Parameters are the RAW (pre-activation) tensors of the model.  grads /
+ * exp_avg / exp_avg_sq are flat 10*N buckets laid out [xyz 3N | opacity N |
+ * scaling 2N | rotation 4N] (the optimiser's group order) — one contiguous
+ * buffer, i.e. one RCCL all-reduce in the keyframe-parallel mode.
+ * The instance count R stays on the device: buffers are sized for R_capacity;
+ * if R exceeds it the excess is dropped, status.overflow is set and the Adam
+ * update is skipped (the caller grows the capacity and repeats the iteration).
+ * status_dev lives in DEVICE memory; read it after the stream has drained.
+ * *allmap_out (optional) receives the address of allmap inside the workspace. */
+typedef struct SlsMappingConfig {
+    float lambda_alpha, lambda_normal, scaling_max, scaling_max_penalty, depth_ratio;
+    float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
+    int32_t apply_adam;   /* 0: gradients only (all-reduce them, then sls_adam_step) */
+    double beta1, beta2, eps;
+} SlsMappingConfig;
+typedef struct SlsMappingStatus {
+    uint32_t R;           /* tile instances of this iteration */
+    uint32_t overflow;    /* 1: R > R_capacity, gradients incomplete, Adam skipped */
+    float loss_sums[4];   /* sums of the three pixel terms, pixel-loss total */
+    float loss_reg;       /* scale regulariser */
+    uint32_t pad;
+} SlsMappingStatus;
+size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity);
+int sls_mapping_step(const SlsCamera *cam, int N,
+                     float *xyz, float *scaling_raw, float *rotation_raw, float *opacity_raw,
+                     float *grads, float *exp_avg, float *exp_avg_sq, int64_t adam_step,
+                     const float *gt_depth, const uint8_t *valid, int n_valid,
+                     const float *col_cs, const float *row_cs,
+                     const float *col_cs_half, const float *row_cs_half,
+                     const SlsMappingConfig *cfg, uint64_t R_capacity,
+                     void *workspace, size_t workspace_bytes,
+                     SlsMappingStatus *status_dev, float **allmap_out, void *stream);
+
 /* ---- fused Adam over up to 8 parameter tensors in one launch ------------
  * torch.optim.Adam semantics (no weight decay, no amsgrad); step is 1-based
  * and shared by all groups. */
@@ -162,6 +204,10 @@ typedef struct SlsAdamGroup {
 } SlsAdamGroup;
 int sls_adam_step(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
                   double eps, int64_t step, void *stream);
+/* Same, but the update is skipped on the device when *skip_flag_dev != 0 (the
+ * overflow word of SlsMappingStatus, possibly OR-reduced over ranks). */
+int sls_adam_step_guarded(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
+                          double eps, int64_t step, const uint32_t *skip_flag_dev, void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------
  * out[i] = mean of squared distances from point i to its 3 nearest other

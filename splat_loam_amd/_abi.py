@@ -25,6 +25,21 @@ class SlsCamera(C.Structure):
     ]
 
 
+class SlsMappingConfig(C.Structure):
+    _fields_ = [
+        ("lambda_alpha", C.c_float), ("lambda_normal", C.c_float), ("scaling_max", C.c_float),
+        ("scaling_max_penalty", C.c_float), ("depth_ratio", C.c_float),
+        ("lr_xyz", C.c_float), ("lr_opacity", C.c_float), ("lr_scaling", C.c_float), ("lr_rotation", C.c_float),
+        ("apply_adam", C.c_int32),
+        ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+    ]
+
+
+class SlsMappingStatus(C.Structure):
+    _fields_ = [("R", C.c_uint32), ("overflow", C.c_uint32), ("loss_sums", C.c_float * 4),
+                ("loss_reg", C.c_float), ("pad", C.c_uint32)]
+
+
 class SlsAdamGroup(C.Structure):
     _fields_ = [
         ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -48,12 +63,18 @@ _PROTOS = {
     "sls_consumer_fwd_bwd": (C.c_int, [C.c_int, C.c_int] + [_VP] * 5 + [C.c_float] * 3 + [C.c_int, _VP, _VP, _VP,
                                                                                          C.c_size_t, _VP]),
     "sls_stage1_scratch_bytes": (C.c_size_t, [C.c_int]),
-    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 11 + [_VP, C.c_size_t, _VP]),
+    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 12 + [_VP, C.c_size_t, _VP]),
     "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),
-    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 9 +
-                           [_VP, C.c_size_t, C.POINTER(C.c_int)] + [_VP] * 7 + [_VP]),
+    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 11 +
+                           [_VP, C.c_size_t, C.POINTER(C.c_int), _VP] + [_VP] * 7 + [_VP]),
+    "sls_mapping_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "sls_mapping_step": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 7 + [C.c_int64, _VP, _VP, C.c_int] +
+                         [_VP] * 4 + [C.POINTER(SlsMappingConfig), C.c_uint64, _VP, C.c_size_t, _VP,
+                                      C.POINTER(C.c_void_p), _VP]),
     "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP]),
     "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
+    "sls_adam_step_guarded": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_int64, _VP, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),

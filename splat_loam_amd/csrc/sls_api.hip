@@ -50,19 +50,7 @@ void timer_end(int slot, hipStream_t st)
 }
 
 // launchers implemented in the other translation units
-int launch_preprocess_fwd(const DevCam &, int, const float *, const float *, const float *, const float *, float *,
-                          int32_t *, int32_t *, uint32_t *, float *, uint32_t *, uint32_t *, uint32_t *, hipStream_t);
-int launch_preprocess_bwd(const DevCam &, int, const float *, const float *, const float *, const int32_t *,
-                          const float *, float *, float *, float *, float *, hipStream_t);
 int launch_mark_visible(const DevCam &, int, const float *, uint8_t *, hipStream_t);
-size_t sort_scratch_bytes(uint64_t R);
-int launch_bin_sort(const DevCam &, int, uint64_t, const int32_t *, const uint32_t *, const float *,
-                    const uint32_t *, uint64_t *, uint32_t *, uint64_t *, uint32_t *, void *, size_t, int *,
-                    uint32_t *, hipStream_t);
-int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
-                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
-int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
-                      const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
@@ -92,8 +80,10 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
     p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units)
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units,
+                                                   const uint32_t *__restrict__ skip_flag)
 {
+    if (skip_flag && *skip_flag) return;   // e.g. the instance buffers overflowed: gradients are incomplete
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * 256) {
         int gi = 0;
 #pragma unroll
@@ -225,88 +215,11 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
     return SLS_OK;
 }
 
-size_t sls_stage1_scratch_bytes(int N) { return sizeof(uint32_t) * (size_t)((N > 0 ? (N + 255) / 256 : 0) + 1); }
+}  // extern "C"
 
-int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const float *scales,
-                       const float *rotations, const float *opacities, float *rec, int32_t *radii, int32_t *rect,
-                       uint32_t *tiles_touched, float *depth, uint32_t *offsets, uint32_t *total_out,
-                       void *scratch, size_t scratch_bytes, void *stream)
-{
-    SLS_REQUIRE(cam && total_out, "null pointer");
-    SLS_REQUIRE(N >= 0, "negative N");
-    hipStream_t st = (hipStream_t)stream;
-    if (N == 0) {
-        SLS_HIP_CHECK(hipMemsetAsync(total_out, 0, sizeof(uint32_t), st));
-        return SLS_OK;
-    }
-    SLS_REQUIRE(means3D && scales && rotations && opacities && rec && radii && rect && tiles_touched && depth &&
-                    offsets && scratch,
-                "null pointer");
-    if (scratch_bytes < sls_stage1_scratch_bytes(N)) {
-        set_error("stage1 scratch too small");
-        return SLS_E_SCRATCH;
-    }
-    const DevCam dc = make_devcam(*cam);
-    return launch_preprocess_fwd(dc, N, means3D, scales, rotations, opacities, rec, radii, rect, tiles_touched,
-                                 depth, offsets, total_out, (uint32_t *)scratch, st);
-}
-
-size_t sls_sort_scratch_bytes(uint64_t R) { return sort_scratch_bytes(R); }
-
-int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec, const int32_t *rect,
-                       const uint32_t *tiles_touched, const float *depth, const uint32_t *offsets, uint64_t *keys,
-                       uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, void *sort_scratch,
-                       size_t sort_scratch_bytes_, int *sorted_in_tmp, uint32_t *ranges, const float *col_cs,
-                       const float *row_cs, float *allmap, float *pix_state, uint32_t *pix_contrib,
-                       uint32_t *tile_consumed, void *stream)
-{
-    SLS_REQUIRE(cam && sorted_in_tmp && ranges && col_cs && row_cs && allmap && pix_state && pix_contrib,
-                "null pointer");
-    SLS_REQUIRE(R == 0 || (rec && rect && tiles_touched && depth && offsets && keys && vals && keys_tmp &&
-                           vals_tmp && sort_scratch),
-                "null pointer");
-    SLS_REQUIRE(R < (1ull << 32), "more than 2^32 tile instances");
-    hipStream_t st = (hipStream_t)stream;
-    const DevCam dc = make_devcam(*cam);
-    int rc = launch_bin_sort(dc, N, R, rect, tiles_touched, depth, offsets, keys, vals, keys_tmp, vals_tmp,
-                             sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges, st);
-    if (rc) return rc;
-    const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
-    return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                             tile_consumed, st);
-}
-
-int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
-                 const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
-                 const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
-                 const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, float *dL_dmeans3D,
-                 float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream)
-{
-    SLS_REQUIRE(cam, "null pointer");
-    SLS_REQUIRE(N >= 0, "negative N");
-    if (N == 0) return SLS_OK;
-    SLS_REQUIRE(means3D && scales && rotations && radii && grec && dL_dmeans3D && dL_dscales && dL_drotations &&
-                    dL_dopacities,
-                "null pointer");
-    hipStream_t st = (hipStream_t)stream;
-    const DevCam dc = make_devcam(*cam);
-    {
-        ScopedTimer tm(T_GREC_MEMSET, st);
-        SLS_HIP_CHECK(hipMemsetAsync(grec, 0, sizeof(float) * (size_t)N * SLS_GREC_STRIDE, st));
-    }
-    if (R > 0) {
-        SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
-                    "null pointer");
-        int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   grec, st);
-        if (rc) return rc;
-    }
-    return launch_preprocess_bwd(dc, N, means3D, scales, rotations, radii, grec, dL_dmeans3D, dL_dscales,
-                                 dL_drotations, dL_dopacities, st);
-}
-
-int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
-                  void *stream)
+namespace sls {
+int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
+                const uint32_t *skip_flag, hipStream_t stream)
 {
     SLS_REQUIRE(groups && ngroups > 0 && ngroups <= kMaxAdamGroups, "1..8 groups");
     SLS_REQUIRE(step >= 1, "step is 1-based");
@@ -334,10 +247,25 @@ int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double 
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond
     {
         ScopedTimer tm(T_ADAM, (hipStream_t)stream);
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units, skip_flag);
     }
     SLS_LAUNCH_CHECK("adam_kernel");
     return SLS_OK;
+}
+}  // namespace sls
+
+extern "C" {
+
+int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
+                  void *stream)
+{
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream);
+}
+
+int sls_adam_step_guarded(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps,
+                          int64_t step, const uint32_t *skip_flag_dev, void *stream)
+{
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, skip_flag_dev, (hipStream_t)stream);
 }
 
 size_t sls_consumer_scratch_bytes(int H, int W) { return (H > 0 && W > 0) ? consumer_scratch_bytes(H, W) : 0; }

@@ -20,8 +20,9 @@
 namespace sls {
 
 size_t sort_scratch_bytes(uint64_t R);
-int radix_sort_pairs(uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t R,
-                     int nbits, void *scratch, size_t scratch_bytes, int *result_in_tmp, hipStream_t st);
+int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                         const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch, size_t scratch_bytes,
+                         int *result_in_tmp, hipStream_t st);
 
 constexpr int kKnnBox = 256;
 
@@ -36,10 +37,11 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(u);
 }
 
-__global__ void knn_init_bbox_kernel(uint32_t *bbox)
+__global__ void knn_init_bbox_kernel(uint32_t *bbox, uint32_t M)
 {
     if (threadIdx.x < 3) bbox[threadIdx.x] = 0xFFFFFFFFu;       // min (ordered domain)
     else if (threadIdx.x < 6) bbox[threadIdx.x] = 0u;           // max
+    else if (threadIdx.x == 6) bbox[6] = M;                     // item count for the sorter
 }
 
 __global__ __launch_bounds__(256) void knn_bbox_kernel(int M, const float *__restrict__ xyz, uint32_t *bbox)
@@ -82,7 +84,7 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 
 __global__ __launch_bounds__(256) void knn_morton_kernel(int M, const float *__restrict__ xyz,
                                                          const uint32_t *__restrict__ bbox,
-                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(int M, const float *__r
     const uint32_t qx = (uint32_t)fminf(fmaxf((xyz[3 * i] - mnx) * s, 0.0f), 1023.0f);
     const uint32_t qy = (uint32_t)fminf(fmaxf((xyz[3 * i + 1] - mny) * s, 0.0f), 1023.0f);
     const uint32_t qz = (uint32_t)fminf(fmaxf((xyz[3 * i + 2] - mnz) * s, 0.0f), 1023.0f);
-    keys[i] = (uint64_t)(spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2));
+    keys[i] = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
     vals[i] = (uint32_t)i;
 }
 
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(int M, int nboxes, const
 // scratch layout (all 256-byte aligned)
 struct KnnScratch {
     uint32_t *bbox;
-    uint64_t *keys, *keys_tmp;
+    uint32_t *keys, *keys_tmp;
     uint32_t *vals, *vals_tmp;
     float4 *pts, *boxes;
     void *sort;
@@ -192,9 +194,9 @@ static KnnScratch knn_layout(int M, void *base)
     char *p = (char *)base;
     size_t off = 0;
     const int nboxes = (M + kKnnBox - 1) / kKnnBox;
-    s.bbox = (uint32_t *)(p + off); off += al(6 * sizeof(uint32_t));
-    s.keys = (uint64_t *)(p + off); off += al(sizeof(uint64_t) * (size_t)M);
-    s.keys_tmp = (uint64_t *)(p + off); off += al(sizeof(uint64_t) * (size_t)M);
+    s.bbox = (uint32_t *)(p + off); off += al(8 * sizeof(uint32_t));
+    s.keys = (uint32_t *)(p + off); off += al(sizeof(uint32_t) * (size_t)M);
+    s.keys_tmp = (uint32_t *)(p + off); off += al(sizeof(uint32_t) * (size_t)M);
     s.vals = (uint32_t *)(p + off); off += al(sizeof(uint32_t) * (size_t)M);
     s.vals_tmp = (uint32_t *)(p + off); off += al(sizeof(uint32_t) * (size_t)M);
     s.pts = (float4 *)(p + off); off += al(sizeof(float4) * (size_t)M);
@@ -221,14 +223,15 @@ int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratc
     }
     const int nb = (M + 255) / 256;
     ScopedTimer tm(T_KNN, st);
-    hipLaunchKernelGGL(knn_init_bbox_kernel, dim3(1), dim3(64), 0, st, s.bbox);
+    hipLaunchKernelGGL(knn_init_bbox_kernel, dim3(1), dim3(64), 0, st, s.bbox, (uint32_t)M);
     SLS_LAUNCH_CHECK("knn_init_bbox_kernel");
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, M, xyz, s.bbox);
     SLS_LAUNCH_CHECK("knn_bbox_kernel");
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, st, M, xyz, s.bbox, s.keys, s.vals);
     SLS_LAUNCH_CHECK("knn_morton_kernel");
     int which = 0;
-    int rc = radix_sort_pairs(s.keys, s.vals, s.keys_tmp, s.vals_tmp, (uint64_t)M, 30, s.sort, s.sort_bytes, &which, st);
+    int rc = radix_sort_pairs_u32(s.keys, s.vals, s.keys_tmp, s.vals_tmp, s.bbox + 6, (uint32_t)M, 30, s.sort,
+                                  s.sort_bytes, &which, st);
     if (rc) return rc;
     const int nboxes = (M + kKnnBox - 1) / kKnnBox;
     hipLaunchKernelGGL(knn_gather_boxes_kernel, dim3(nboxes), dim3(kKnnBox), 0, st, M, xyz,

@@ -1,0 +1,267 @@
+// sls_pipeline.hip — host-side orchestration behind the C-ABI: the two-stage
+// forward and the backward of the drop-in rasterizer interface, and
+// sls_mapping_step, which enqueues one WHOLE mapping iteration
+// (slam/mapper.py:150-204: render -> loss -> backward -> Adam) on a stream with
+// no device->host sync and no torch op in between.
+#include <string.h>
+
+#include "sls_common.hpp"
+
+namespace sls {
+
+// launchers implemented in the other translation units
+int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
+                          const float *means, const float *scales, const float *rots, const float *opac, float *rec,
+                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, hipStream_t st);
+int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
+                          const float *scales, const float *rots, const float *opac, const int32_t *radii,
+                          const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
+                          hipStream_t st);
+size_t sort_scratch_bytes(uint64_t cap);
+size_t order_scratch_bytes(int N);
+int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
+                            uint32_t *total_out, void *scratch, size_t scratch_bytes, hipStream_t st);
+int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
+                    const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
+                    uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
+                    size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
+                    uint32_t *overflow, hipStream_t st);
+int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
+                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
+int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
+                      const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
+size_t consumer_scratch_bytes(int H, int W);
+int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
+                    const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
+                    int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
+                    hipStream_t st);
+int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
+                const uint32_t *skip_flag, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// workspace of sls_mapping_step: one caller-owned buffer, carved here
+// ---------------------------------------------------------------------------
+struct MapWs {
+    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; float *depth; uint32_t *order; uint32_t *offsets;
+    void *order_scratch; size_t order_scratch_bytes;
+    uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
+    uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
+    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec;
+    size_t total;
+};
+
+static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    MapWs w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void *r = (void *)(p + off); off += al(bytes); return r; };
+    const size_t n = (size_t)(N > 0 ? N : 1), P = (size_t)H * W, c = (size_t)(cap > 0 ? cap : 1);
+    const int GX = (W + kTileW - 1) / kTileW, GY = (H + kTileH - 1) / kTileH;
+    const size_t T = (size_t)GX * GY;
+    w.rec = (float *)take(n * SLS_REC_STRIDE * 4);
+    w.radii = (int32_t *)take(n * 4);
+    w.rect = (int32_t *)take(n * 16);
+    w.tiles = (uint32_t *)take(n * 4);
+    w.depth = (float *)take(n * 4);
+    w.order = (uint32_t *)take(n * 4);
+    w.offsets = (uint32_t *)take(n * 4);
+    w.order_scratch_bytes = order_scratch_bytes(N);
+    w.order_scratch = take(w.order_scratch_bytes);
+    w.tkeys = (uint32_t *)take(c * 4);
+    w.vals = (uint32_t *)take(c * 4);
+    w.tkeys_tmp = (uint32_t *)take(c * 4);
+    w.vals_tmp = (uint32_t *)take(c * 4);
+    w.sort_scratch_bytes = sort_scratch_bytes(cap);
+    w.sort_scratch = take(w.sort_scratch_bytes);
+    w.ranges = (uint32_t *)take(T * 8);
+    w.allmap = (float *)take(P * 7 * 4);
+    w.pix_state = (float *)take(P * 16);
+    w.pix_contrib = (uint32_t *)take(P * 8);
+    w.tile_consumed = (uint32_t *)take(T * 4);
+    w.dL_dallmap = (float *)take(P * 7 * 4);
+    w.consumer_scratch_bytes = consumer_scratch_bytes(H, W);
+    w.consumer_scratch = take(w.consumer_scratch_bytes);
+    w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace sls
+
+using namespace sls;
+
+extern "C" {
+
+size_t sls_stage1_scratch_bytes(int N) { return order_scratch_bytes(N); }
+
+int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const float *scales,
+                       const float *rotations, const float *opacities, float *rec, int32_t *radii, int32_t *rect,
+                       uint32_t *tiles_touched, float *depth, uint32_t *order, uint32_t *offsets,
+                       uint32_t *total_out, void *scratch, size_t scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(cam && total_out, "null pointer");
+    SLS_REQUIRE(N >= 0, "negative N");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        SLS_HIP_CHECK(hipMemsetAsync(total_out, 0, sizeof(uint32_t), st));
+        return SLS_OK;
+    }
+    SLS_REQUIRE(means3D && scales && rotations && opacities && rec && radii && rect && tiles_touched && depth &&
+                    order && offsets && scratch,
+                "null pointer");
+    const DevCam dc = make_devcam(*cam);
+    int rc = launch_preprocess_fwd(dc, 0, 0.0f, 0.0f, nullptr, N, means3D, scales, rotations, opacities, rec, radii,
+                                   rect, tiles_touched, depth, st);
+    if (rc) return rc;
+    return launch_depth_order_scan(N, depth, tiles_touched, order, offsets, total_out, scratch, scratch_bytes, st);
+}
+
+size_t sls_sort_scratch_bytes(uint64_t R) { return sort_scratch_bytes(R); }
+
+int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec, const int32_t *rect,
+                       const uint32_t *tiles_touched, const float *depth, const uint32_t *order,
+                       const uint32_t *offsets, const uint32_t *total_dev, uint32_t *tkeys, uint32_t *vals,
+                       uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *sort_scratch, size_t sort_scratch_bytes_,
+                       int *sorted_in_tmp, uint64_t *keys64_out, uint32_t *ranges, const float *col_cs,
+                       const float *row_cs, float *allmap, float *pix_state, uint32_t *pix_contrib,
+                       uint32_t *tile_consumed, void *stream)
+{
+    SLS_REQUIRE(cam && sorted_in_tmp && ranges && col_cs && row_cs && allmap && pix_state && pix_contrib,
+                "null pointer");
+    SLS_REQUIRE(R == 0 || (rec && rect && tiles_touched && depth && order && offsets && total_dev && tkeys && vals &&
+                           tkeys_tmp && vals_tmp && sort_scratch),
+                "null pointer");
+    SLS_REQUIRE(R < (1ull << 32), "more than 2^32 tile instances");
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    int rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched, depth, offsets, tkeys, vals,
+                             tkeys_tmp, vals_tmp, sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges,
+                             keys64_out, nullptr, st);
+    if (rc) return rc;
+    const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
+    return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
+                             tile_consumed, st);
+}
+
+int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
+                 const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
+                 const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
+                 const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, float *dL_dmeans3D,
+                 float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream)
+{
+    SLS_REQUIRE(cam, "null pointer");
+    SLS_REQUIRE(N >= 0, "negative N");
+    if (N == 0) return SLS_OK;
+    SLS_REQUIRE(means3D && scales && rotations && radii && grec && dL_dmeans3D && dL_dscales && dL_drotations &&
+                    dL_dopacities,
+                "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    {
+        ScopedTimer tm(T_GREC_MEMSET, st);
+        SLS_HIP_CHECK(hipMemsetAsync(grec, 0, sizeof(float) * (size_t)N * SLS_GREC_STRIDE, st));
+    }
+    if (R > 0) {
+        SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
+                    "null pointer");
+        int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
+                                   grec, st);
+        if (rc) return rc;
+    }
+    return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, grec, dL_dmeans3D,
+                                 dL_dscales, dL_drotations, dL_dopacities, st);
+}
+
+size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity)
+{
+    if (N < 0 || H <= 0 || W <= 0) return 0;
+    return carve(N, H, W, R_capacity, nullptr).total;
+}
+
+int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw, float *rotation_raw,
+                     float *opacity_raw, float *grads, float *exp_avg, float *exp_avg_sq, int64_t adam_step,
+                     const float *gt_depth, const uint8_t *valid, int n_valid, const float *col_cs,
+                     const float *row_cs, const float *col_cs_half, const float *row_cs_half,
+                     const SlsMappingConfig *cfg, uint64_t R_capacity, void *workspace, size_t workspace_bytes,
+                     SlsMappingStatus *status_dev, float **allmap_out, void *stream)
+{
+    SLS_REQUIRE(cam && cfg && status_dev && workspace, "null pointer");
+    SLS_REQUIRE(N > 0, "N must be positive");
+    SLS_REQUIRE(xyz && scaling_raw && rotation_raw && opacity_raw && grads && gt_depth && valid && col_cs && row_cs &&
+                    col_cs_half && row_cs_half,
+                "null pointer");
+    SLS_REQUIRE(!cfg->apply_adam || (exp_avg && exp_avg_sq && adam_step >= 1), "Adam state missing");
+    SLS_REQUIRE(R_capacity > 0 && R_capacity < (1ull << 32), "bad instance capacity");
+    SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const int H = cam->H, W = cam->W;
+    const MapWs w = carve(N, H, W, R_capacity, workspace);
+    if (workspace_bytes < w.total) {
+        set_error("mapping workspace too small: %zu < %zu", workspace_bytes, w.total);
+        return SLS_E_SCRATCH;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    const uint32_t cap = (uint32_t)R_capacity;
+    if (allmap_out) *allmap_out = w.allmap;
+    SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
+
+    // ---- forward ---------------------------------------------------------------
+    int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, &status_dev->loss_reg, N, xyz,
+                                   scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
+                                   st);
+    if (rc) return rc;
+    rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
+                                 w.order_scratch_bytes, st);
+    if (rc) return rc;
+    int in_tmp = 0;
+    rc = launch_bin_sort(dc, N, &status_dev->R, cap, w.order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,
+                         w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
+                         &status_dev->overflow, st);
+    if (rc) return rc;
+    const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
+    rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
+                           w.tile_consumed, st);
+    if (rc) return rc;
+    // ---- loss + dL/dallmap --------------------------------------------------------
+    rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
+                         cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
+                         w.consumer_scratch, w.consumer_scratch_bytes, st);
+    if (rc) return rc;
+    // ---- backward -----------------------------------------------------------------
+    {
+        ScopedTimer tm(T_GREC_MEMSET, st);
+        SLS_HIP_CHECK(hipMemsetAsync(w.grec, 0, sizeof(float) * (size_t)N * SLS_GREC_STRIDE, st));
+    }
+    rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
+                           w.grec, st);
+    if (rc) return rc;
+    // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
+    float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
+    rc = launch_preprocess_bwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, N, xyz, scaling_raw, rotation_raw,
+                               opacity_raw, w.radii, w.grec, g_xyz, g_sc, g_rot, g_op, st);
+    if (rc) return rc;
+    // ---- optimiser -------------------------------------------------------------------
+    if (cfg->apply_adam) {
+        SlsAdamGroup grp[4];
+        memset(grp, 0, sizeof(grp));
+        float *params[4] = { xyz, opacity_raw, scaling_raw, rotation_raw };
+        const size_t offs[4] = { 0, (size_t)3 * N, (size_t)4 * N, (size_t)6 * N };
+        const int64_t numel[4] = { (int64_t)3 * N, (int64_t)N, (int64_t)2 * N, (int64_t)4 * N };
+        const float lrs[4] = { cfg->lr_xyz, cfg->lr_opacity, cfg->lr_scaling, cfg->lr_rotation };
+        for (int k = 0; k < 4; ++k) {
+            grp[k].param = params[k];
+            grp[k].grad = grads + offs[k];
+            grp[k].exp_avg = exp_avg + offs[k];
+            grp[k].exp_avg_sq = exp_avg_sq + offs[k];
+            grp[k].numel = numel[k];
+            grp[k].lr = lrs[k];
+        }
+        rc = launch_adam(grp, 4, cfg->beta1, cfg->beta2, cfg->eps, adam_step, &status_dev->overflow, st);
+        if (rc) return rc;
+    }
+    return SLS_OK;
+}
+
+}  // extern "C"

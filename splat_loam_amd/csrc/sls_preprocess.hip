@@ -110,18 +110,38 @@ __device__ __forceinline__ void surfel_geom(const DevCam &cam, const float *m, c
     cross3(g.B, g.p, g.Hv);
 }
 
+// Parameter activations of the reference model (scene/gaussian_model.py:39-44):
+// scaling exp, opacity sigmoid, rotation F.normalize (eps 1e-12).  Used by the
+// raw-parameter entry points (sls_mapping_step) so that no torch op sits
+// between the optimiser state and the rasterizer.
+struct RegArgs {
+    int raw;            // 1: scales/rots/opac are raw (pre-activation) parameters
+    float smax, pen;    // slam/mapper.py:190-195 scale regulariser (pen == 0: off)
+    float *reg_out;     // device scalar accumulating pen * sum relu(max_axis_scale - smax)
+};
+
+__device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q, float &o)
+{
+    if (!ra.raw) return;
+    s.x = expf(s.x); s.y = expf(s.y);
+    o = 1.0f / (1.0f + expf(-o));
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
+}
+
 // ---------------------------------------------------------------------------
-// A1 forward preprocess.  One thread per surfel; 256-thread blocks; each block
-// also reduces its tiles_touched into block_sums[] (first level of the scan).
+// A1 forward preprocess.  One thread per surfel; 256-thread blocks.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
-    DevCam cam, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
+    DevCam cam, RegArgs ra, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
     const float4 *__restrict__ rots, const float *__restrict__ opac,
     float4 *__restrict__ rec, int *__restrict__ radii, int4 *__restrict__ rect,
-    uint32_t *__restrict__ tiles, float *__restrict__ depth, uint32_t *__restrict__ block_sums)
+    uint32_t *__restrict__ tiles, float *__restrict__ depth)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
+    float my_reg = 0.0f;
     if (i < N) {
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
         int r_out = 0;
@@ -129,9 +149,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         float dep = 0.0f;
 
         const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
-        const float2 s = scales[i];
-        const float4 q = rots[i];
-        const float o = opac[i];
+        float2 s = scales[i];
+        float4 q = rots[i];
+        float o = opac[i];
+        activate(ra, s, q, o);
+        if (ra.pen != 0.0f) my_reg = ra.pen * fmaxf(fmaxf(s.x, s.y) - ra.smax, 0.0f);
         SurfelGeom g;
         surfel_geom(cam, m, s, q, g);
         bool vis = (g.rho >= cam.near_c) && (g.rho < 1.0e18f);  // D2 near cut; NaN/inf fail
@@ -202,77 +224,32 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         tiles[i] = my_tiles;
         depth[i] = dep;
     }
-    // block reduction of tiles_touched
-    __shared__ uint32_t s_part[4];
-    uint32_t v = my_tiles;
+    (void)my_tiles;
+    if (ra.pen != 0.0f && ra.reg_out) {   // block reduction of the regulariser, one atomic per block
+        __shared__ float s_part[4];
+        float v = my_reg;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-}
-
-// A2, level 2: one block turns block_sums[] into exclusive prefixes in place
-// and publishes the grand total R.
-__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *block_sums, int nblocks, uint32_t *total_out)
-{
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            if (tot != 0.0f) atomicAdd(ra.reg_out, tot);
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-        const uint32_t carry = s_carry;
-        if (i < nblocks) block_sums[i] = carry + wave_prefix + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-// A2, level 3: inclusive scan inside each 256-surfel block + block prefix.
-__global__ __launch_bounds__(256) void scan_final_kernel(const uint32_t *__restrict__ tiles,
-                                                         const uint32_t *__restrict__ block_prefix,
-                                                         uint32_t *__restrict__ offsets, int N)
-{
-    __shared__ uint32_t s_wave[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v = (i < N) ? tiles[i] : 0u;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wave_prefix = 0;
-    for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-    if (i < N) offsets[i] = block_prefix[blockIdx.x] + wave_prefix + incl;
 }
 
 // ---------------------------------------------------------------------------
 // A8 preprocess backward: gradient record (sls_spec.h) -> input gradients.
 // ---------------------------------------------------------------------------
+// With ra.raw the inputs are raw parameters, the activations are re-applied here
+// and the outputs are gradients w.r.t. the RAW parameters (exp / sigmoid /
+// normalize backward + the scale regulariser's gradient), opacity needed too.
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
-    DevCam cam, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
-    const float4 *__restrict__ rots, const int *__restrict__ radii, const float4 *__restrict__ grec,
-    float *__restrict__ dmeans, float2 *__restrict__ dscales, float4 *__restrict__ drots,
-    float *__restrict__ dopac)
+    DevCam cam, RegArgs ra, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
+    const float4 *__restrict__ rots, const float *__restrict__ opac, const int *__restrict__ radii,
+    const float4 *__restrict__ grec, float *__restrict__ dmeans, float2 *__restrict__ dscales,
+    float4 *__restrict__ drots, float *__restrict__ dopac)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -280,10 +257,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float2 ds = make_float2(0, 0);
     float4 dq = make_float4(0, 0, 0, 0);
     float dop = 0.0f;
+    float2 s = scales[i];
+    const float4 q_in = rots[i];
+    float4 q = q_in;
+    float o = ra.raw ? opac[i] : 0.0f;
+    activate(ra, s, q, o);
     if (radii[i] > 0) {
         const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
-        const float2 s = scales[i];
-        const float4 q = rots[i];
         SurfelGeom g;
         surfel_geom(cam, m, s, q, g);
         const float4 g0 = grec[(size_t)i * 4 + 0], g1 = grec[(size_t)i * 4 + 1];
@@ -334,6 +314,19 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         dq.z = 2.0f * (-2.0f * y * G0[0] + x * G1[0] + r * G2[0] + x * G0[1] + z * G2[1] - r * G0[2] + z * G1[2] - 2.0f * y * G2[2]);
         dq.w = 2.0f * (-2.0f * z * G0[0] - r * G1[0] + x * G2[0] + r * G0[1] - 2.0f * z * G1[1] + y * G2[1] + x * G0[2] + y * G1[2]);
     }
+    if (ra.pen != 0.0f) {   // d/ds of pen * relu(max(s.x, s.y) - smax); torch.max picks the first index on ties
+        const bool first = s.x >= s.y;
+        if ((first ? s.x : s.y) >= ra.smax) { if (first) ds.x += ra.pen; else ds.y += ra.pen; }
+    }
+    if (ra.raw) {
+        ds.x *= s.x; ds.y *= s.y;                                   // exp backward
+        dop *= o * (1.0f - o);                                      // sigmoid backward
+        const float nrm = sqrtf(q_in.x * q_in.x + q_in.y * q_in.y + q_in.z * q_in.z + q_in.w * q_in.w);
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);                // F.normalize backward
+        const float dd = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w;
+        dq.x = (dq.x - dd * q.x) * inv; dq.y = (dq.y - dd * q.y) * inv;
+        dq.z = (dq.z - dd * q.z) * inv; dq.w = (dq.w - dd * q.w) * inv;
+    }
     dmeans[3 * i] = dm[0]; dmeans[3 * i + 1] = dm[1]; dmeans[3 * i + 2] = dm[2];
     dscales[i] = ds;
     drots[i] = dq;
@@ -356,34 +349,31 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(DevCam cam, int N, co
 // ---------------------------------------------------------------------------
 // host-side launchers used by sls_api.hip
 // ---------------------------------------------------------------------------
-int launch_preprocess_fwd(const DevCam &cam, int N, const float *means, const float *scales, const float *rots,
-                          const float *opac, float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles,
-                          float *depth, uint32_t *offsets, uint32_t *total_out, uint32_t *block_sums,
-                          hipStream_t st)
+int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
+                          const float *means, const float *scales, const float *rots, const float *opac, float *rec,
+                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, hipStream_t st)
 {
     const int nb = (N + 255) / 256;
-    {
+    RegArgs ra;
+    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, N, means, (const float2 *)scales,
-                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, block_sums);
-    }
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
+                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth);
     SLS_LAUNCH_CHECK("preprocess_fwd_kernel");
-    ScopedTimer tm2(T_SCAN, st);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, total_out);
-    SLS_LAUNCH_CHECK("scan_block_sums_kernel");
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(256), 0, st, tiles, block_sums, offsets, N);
-    SLS_LAUNCH_CHECK("scan_final_kernel");
     return SLS_OK;
 }
 
-int launch_preprocess_bwd(const DevCam &cam, int N, const float *means, const float *scales, const float *rots,
-                          const int32_t *radii, const float *grec, float *dmeans, float *dscales, float *drots,
-                          float *dopac, hipStream_t st)
+int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
+                          const float *scales, const float *rots, const float *opac, const int32_t *radii,
+                          const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
+                          hipStream_t st)
 {
     const int nb = (N + 255) / 256;
+    RegArgs ra;
+    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = nullptr;
     ScopedTimer tm(T_PREPROCESS_BWD, st);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, N, means, (const float2 *)scales,
-                       (const float4 *)rots, radii, (const float4 *)grec, dmeans, (float2 *)dscales,
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
+                       (const float4 *)rots, opac, radii, (const float4 *)grec, dmeans, (float2 *)dscales,
                        (float4 *)drots, dopac);
     SLS_LAUNCH_CHECK("preprocess_bwd_kernel");
     return SLS_OK;

@@ -1,17 +1,28 @@
-// sls_sort.hip — tile binning (A3), LSD radix sort of (tile<<32 | depth bits)
-// keys with surfel-index payload (A4) and per-tile range detection (A5).
-// SURVEY.md §8a; all integer work, checked bit-exactly.
+// sls_sort.hip — tile binning (A3), sorting (A4) and per-tile range detection
+// (A5).  SURVEY.md §8a; all integer work, checked bit-exactly.
 //
-// Radix sort design (wave64-native, no vendor library):
-//   * 8-bit digits, only the ceil((32 + tile_bits)/8) passes that carry
-//     information;
-//   * the unit of work is ONE WAVE owning 1024 consecutive items (16 rounds of
-//     64): no workgroup barrier is needed inside a pass, each wave keeps its
+// The sorted list is defined by the 64-bit key (tile << 32 | depth bits) with
+// ties broken by surfel index (D3, D9).  It is produced WITHOUT ever sorting
+// 64-bit keys over the R tile instances:
+//   1. the N surfels are sorted by (depth bits, index)   — 4 passes over N pairs;
+//   2. instances are emitted in that order                — so within any tile
+//      the emission order already is the final order;
+//   3. one STABLE sort of the R instances by tile id      — ceil(tile_bits/8)
+//      passes (2 for up to 65,536 tiles) over (u32 tile, u32 surfel) pairs.
+// LSD radix principle (least-significant part first, stable passes after); the
+// result is bit-identical to a stable 64-bit sort and costs ~40 B of HBM traffic
+// per instance instead of ~190 B.
+//
+// Radix sort building block (wave64-native, no vendor library):
+//   * 8-bit digits; the unit of work is ONE WAVE owning 1024 consecutive items
+//     (16 rounds of 64): no workgroup barrier inside a pass, each wave keeps its
 //     256 running bucket cursors in a private LDS slice;
 //   * stable ranking inside a round by 8 ballots (the set of lanes holding my
 //     digit), rank = popcount(peers below me);
-//   * per pass: histogram -> per-digit row scan over chunks -> scatter.
-// HBM-bound: a pass reads 8 B/item (histogram) + 12 B/item and writes 12 B/item.
+//   * per pass: histogram -> per-digit row scan over chunks -> scatter;
+//   * the item count is read from DEVICE memory (count_ptr), grids are sized for
+//     a host-side capacity, so a whole iteration can be enqueued without a
+//     device->host sync (sls_mapping_step).
 #include "sls_common.hpp"
 
 namespace sls {
@@ -20,76 +31,59 @@ constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kWave * kSortRounds;  // 1024 items per wave
 constexpr int kSortWavesPerBlock = 4;
 
-// ---------------------------------------------------------------------------
-// A3: one thread per surfel walks its tile rectangle (row-major: y outer,
-// x inner, x wrapping modulo the grid width in 360-degree mode, D5/D9).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_keys_kernel(int N, int GX, const int4 *__restrict__ rect,
-                                                        const uint32_t *__restrict__ tiles,
-                                                        const uint32_t *__restrict__ offsets,
-                                                        const float *__restrict__ depth,
-                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+__device__ __forceinline__ uint32_t load_count(const uint32_t *count_ptr, uint32_t cap)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t t = tiles[i];
-    if (!t) return;
-    uint32_t off = offsets[i] - t;
-    const int4 rc = rect[i];
-    const uint64_t db = (uint64_t)__float_as_uint(depth[i]);
-    for (int y = 0; y < rc.w; ++y) {
-        const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
-        for (int k = 0; k < rc.y; ++k) {
-            int tx = rc.x + k;
-            if (tx >= GX) tx -= GX;
-            keys[off] = ((uint64_t)(row + (uint32_t)tx) << 32) | db;
-            vals[off] = (uint32_t)i;
-            ++off;
-        }
-    }
+    const uint32_t c = *count_ptr;
+    return c < cap ? c : cap;
 }
 
 // ---------------------------------------------------------------------------
-// A4 pass, step 1: per-wave-chunk digit histogram -> cnt[digit][chunk].
+// step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sort_hist_kernel(const uint64_t *__restrict__ keys, uint64_t R, int shift,
-                                                        uint32_t *__restrict__ cnt, int nchunks)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *__restrict__ keys,
+                                                        const uint32_t *__restrict__ count_ptr, uint32_t cap,
+                                                        int shift, uint32_t *__restrict__ cnt, int nchunks_cap)
 {
     __shared__ uint32_t s_hist[kSortWavesPerBlock][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
+    const uint32_t R = load_count(count_ptr, cap);
+    const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_hist[wave][lane + 64 * k] = 0;
     if (chunk >= nchunks) return;
-    const uint64_t base = (uint64_t)chunk * kSortWaveItems + lane;
-    uint64_t k[kSortRounds];
+    const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
+    KeyT k[kSortRounds];
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
-        const uint64_t idx = base + (uint64_t)r * 64;
-        k[r] = (idx < R) ? keys[idx] : ~0ull;
+        const uint32_t idx = base + (uint32_t)r * 64;
+        k[r] = (idx < R) ? keys[idx] : (KeyT)0;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
-        const uint64_t idx = base + (uint64_t)r * 64;
+        const uint32_t idx = base + (uint32_t)r * 64;
         if (idx < R) atomicAdd(&s_hist[wave][(uint32_t)(k[r] >> shift) & 255u], 1u);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d = lane + 64 * q;
-        cnt[(size_t)d * nchunks + chunk] = s_hist[wave][d];
+        cnt[(size_t)d * nchunks_cap + chunk] = s_hist[wave][d];
     }
 }
 
-// A4 pass, step 2: block d scans row d of cnt[][] exclusively in place and
-// writes the row total.
-__global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ cnt, int nchunks,
-                                                           uint32_t *__restrict__ totals)
+// step 2: block d scans row d of cnt[][] exclusively in place, writes the row total
+__global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ cnt,
+                                                           const uint32_t *__restrict__ count_ptr, uint32_t cap,
+                                                           int nchunks_cap, uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_carry;
-    uint32_t *row = cnt + (size_t)blockIdx.x * nchunks;
+    const uint32_t R = load_count(count_ptr, cap);
+    const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
+    uint32_t *row = cnt + (size_t)blockIdx.x * nchunks_cap;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -115,18 +109,23 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
     if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
 }
 
-// A4 pass, step 3: stable scatter.
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t *__restrict__ keys_in,
+// step 3: stable scatter
+template <typename KeyT>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restrict__ keys_in,
                                                            const uint32_t *__restrict__ vals_in,
-                                                           uint64_t *__restrict__ keys_out,
-                                                           uint32_t *__restrict__ vals_out, uint64_t R, int shift,
-                                                           const uint32_t *__restrict__ cnt,
-                                                           const uint32_t *__restrict__ totals, int nchunks)
+                                                           KeyT *__restrict__ keys_out,
+                                                           uint32_t *__restrict__ vals_out,
+                                                           const uint32_t *__restrict__ count_ptr, uint32_t cap,
+                                                           int shift, const uint32_t *__restrict__ cnt,
+                                                           const uint32_t *__restrict__ totals, int nchunks_cap)
 {
     __shared__ uint32_t s_cursor[kSortWavesPerBlock][256];
     __shared__ uint32_t s_digit_base[256];
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t R = load_count(count_ptr, cap);
+    const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
+    if ((int)(blockIdx.x * kSortWavesPerBlock) >= nchunks) return;   // whole block beyond the data
     {   // exclusive scan of the 256 digit totals (one per thread)
         const uint32_t v = totals[threadIdx.x];
         uint32_t incl = v;
@@ -147,23 +146,23 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t *__res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d = lane + 64 * q;
-        s_cursor[wave][d] = s_digit_base[d] + cnt[(size_t)d * nchunks + chunk];
+        s_cursor[wave][d] = s_digit_base[d] + cnt[(size_t)d * nchunks_cap + chunk];
     }
-    const uint64_t base = (uint64_t)chunk * kSortWaveItems + lane;
-    uint64_t k[kSortRounds];
+    const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
+    KeyT k[kSortRounds];
     uint32_t v[kSortRounds];
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
-        const uint64_t idx = base + (uint64_t)r * 64;
+        const uint32_t idx = base + (uint32_t)r * 64;
         const bool valid = idx < R;
-        k[r] = valid ? keys_in[idx] : ~0ull;
+        k[r] = valid ? keys_in[idx] : (KeyT)0;
         v[r] = valid ? vals_in[idx] : 0u;
     }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
-        const uint64_t idx = base + (uint64_t)r * 64;
+        const uint32_t idx = base + (uint32_t)r * 64;
         const bool valid = idx < R;
         const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
@@ -188,23 +187,207 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint64_t *__res
 }
 
 // ---------------------------------------------------------------------------
-// A5: [start, end) of every tile in the sorted list.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t *__restrict__ keys, uint64_t R,
-                                                          uint2 *__restrict__ ranges)
+size_t sort_scratch_bytes(uint64_t cap)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= R) return;
-    const uint32_t t = (uint32_t)(keys[j] >> 32);
-    if (j == 0 || (uint32_t)(keys[j - 1] >> 32) != t) ranges[t].x = (uint32_t)j;
-    if (j + 1 == R || (uint32_t)(keys[j + 1] >> 32) != t) ranges[t].y = (uint32_t)(j + 1);
+    const uint64_t nchunks = (cap + kSortWaveItems - 1) / kSortWaveItems;
+    return (size_t)(256 * (nchunks ? nchunks : 1) + 256) * sizeof(uint32_t);
+}
+
+// Stable LSD radix sort of (key, u32 value) pairs on the low `nbits` key bits.
+// Item count = min(*count_ptr, cap), read on the device.  Ping-pongs between
+// (keys, vals) and (keys_tmp, vals_tmp); *result_in_tmp says where the sorted
+// data ended up.
+template <typename KeyT>
+static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32_t *vals_tmp,
+                              const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
+                              size_t scratch_bytes, int *result_in_tmp, hipStream_t st)
+{
+    *result_in_tmp = 0;
+    if (cap == 0 || nbits <= 0) return SLS_OK;
+    if (scratch_bytes < sort_scratch_bytes(cap)) {
+        set_error("sort scratch too small: %zu < %zu", scratch_bytes, sort_scratch_bytes(cap));
+        return SLS_E_SCRATCH;
+    }
+    const int nchunks = (int)(((uint64_t)cap + kSortWaveItems - 1) / kSortWaveItems);
+    const int nblocks = (nchunks + kSortWavesPerBlock - 1) / kSortWavesPerBlock;
+    uint32_t *cnt = (uint32_t *)scratch;
+    uint32_t *totals = cnt + (size_t)256 * nchunks;
+    const int npasses = (nbits + 7) / 8;
+    KeyT *kb[2] = { keys, keys_tmp };
+    uint32_t *vb[2] = { vals, vals_tmp };
+    for (int p = 0; p < npasses; ++p) {
+        const int shift = 8 * p;
+        const int src = p & 1, dst = src ^ 1;
+        {
+            ScopedTimer tm(T_SORT_HIST, st);
+            hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblocks), dim3(256), 0, st, (const KeyT *)kb[src],
+                               count_ptr, cap, shift, cnt, nchunks);
+        }
+        SLS_LAUNCH_CHECK("sort_hist_kernel");
+        {
+            ScopedTimer tm(T_SORT_ROWSCAN, st);
+            hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(256), 0, st, cnt, count_ptr, cap, nchunks, totals);
+        }
+        SLS_LAUNCH_CHECK("sort_rowscan_kernel");
+        {
+            ScopedTimer tm(T_SORT_SCATTER, st);
+            hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblocks), dim3(256), 0, st, (const KeyT *)kb[src],
+                               (const uint32_t *)vb[src], kb[dst], vb[dst], count_ptr, cap, shift,
+                               (const uint32_t *)cnt, (const uint32_t *)totals, nchunks);
+        }
+        SLS_LAUNCH_CHECK("sort_scatter_kernel");
+    }
+    *result_in_tmp = npasses & 1;
+    return SLS_OK;
+}
+
+int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                         const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch, size_t scratch_bytes,
+                         int *result_in_tmp, hipStream_t st)
+{
+    return radix_sort_pairs_t<uint32_t>(keys, vals, keys_tmp, vals_tmp, count_ptr, cap, nbits, scratch,
+                                        scratch_bytes, result_in_tmp, st);
 }
 
 // ---------------------------------------------------------------------------
-size_t sort_scratch_bytes(uint64_t R)
+// Depth ordering of the surfels: key = depth bits (positive floats order like
+// their bit patterns), culled surfels (tiles_touched == 0) get the largest key
+// so they end up behind every visible one.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__restrict__ depth,
+                                                         const uint32_t *__restrict__ tiles,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                         uint32_t *__restrict__ n_dev)
 {
-    const uint64_t nchunks = (R + kSortWaveItems - 1) / kSortWaveItems;
-    return (size_t)(256 * (nchunks ? nchunks : 1) + 256) * sizeof(uint32_t);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *n_dev = (uint32_t)N;
+    if (i >= N) return;
+    keys[i] = tiles[i] ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
+    vals[i] = (uint32_t)i;
+}
+
+// A2 on the depth-ordered surfels, level 1: per-block sums of tiles[order[i]]
+__global__ __launch_bounds__(256) void gather_block_sums_kernel(int N, const uint32_t *__restrict__ order,
+                                                                const uint32_t *__restrict__ tiles,
+                                                                uint32_t *__restrict__ block_sums)
+{
+    __shared__ uint32_t s_part[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (i < N) ? tiles[order[i]] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// level 2: one block turns block_sums[] into exclusive prefixes, publishes R
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *block_sums, int nblocks, uint32_t *total_out)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < nblocks) block_sums[i] = carry + wave_prefix + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+// level 3: inclusive scan inside each 256-surfel block (depth order) + prefix;
+// offsets[] is indexed by DEPTH-ORDER position.
+__global__ __launch_bounds__(256) void gather_scan_final_kernel(int N, const uint32_t *__restrict__ order,
+                                                                const uint32_t *__restrict__ tiles,
+                                                                const uint32_t *__restrict__ block_prefix,
+                                                                uint32_t *__restrict__ offsets)
+{
+    __shared__ uint32_t s_wave[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v = (i < N) ? tiles[order[i]] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_prefix = 0;
+    for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+    if (i < N) offsets[i] = block_prefix[blockIdx.x] + wave_prefix + incl;
+}
+
+// ---------------------------------------------------------------------------
+// A3: thread i handles the surfel at depth-order position i and walks its tile
+// rectangle (row-major: y outer, x inner, x wrapping modulo the grid width in
+// 360-degree mode, D5/D9).  Instances beyond `cap` are dropped and flagged.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const uint32_t *__restrict__ order,
+                                                         const int4 *__restrict__ rect,
+                                                         const uint32_t *__restrict__ tiles,
+                                                         const uint32_t *__restrict__ offsets, uint32_t cap,
+                                                         uint32_t *__restrict__ tkeys, uint32_t *__restrict__ vals,
+                                                         uint32_t *__restrict__ overflow)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t g = order[i];
+    const uint32_t t = tiles[g];
+    if (!t) return;
+    const uint32_t end = offsets[i];
+    if (end > cap) {
+        if (overflow) *overflow = 1u;
+        return;
+    }
+    uint32_t off = end - t;
+    const int4 rc = rect[g];
+    for (int y = 0; y < rc.w; ++y) {
+        const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
+        for (int k = 0; k < rc.y; ++k) {
+            int tx = rc.x + k;
+            if (tx >= GX) tx -= GX;
+            tkeys[off] = row + (uint32_t)tx;
+            vals[off] = g;
+            ++off;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A5: [start, end) of every tile in the sorted list; optionally materialises
+// the 64-bit keys (tile << 32 | depth bits) the list is ordered by.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t *__restrict__ tkeys,
+                                                          const uint32_t *__restrict__ vals,
+                                                          const uint32_t *__restrict__ count_ptr, uint32_t cap,
+                                                          const float *__restrict__ depth, uint2 *__restrict__ ranges,
+                                                          uint64_t *__restrict__ keys64)
+{
+    const uint32_t R = load_count(count_ptr, cap);
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= R) return;
+    const uint32_t t = tkeys[j];
+    if (j == 0 || tkeys[j - 1] != t) ranges[t].x = j;
+    if (j + 1 == R || tkeys[j + 1] != t) ranges[t].y = j + 1;
+    if (keys64) keys64[j] = ((uint64_t)t << 32) | (uint64_t)__float_as_uint(depth[vals[j]]);
 }
 
 static int bits_for(uint32_t max_value)
@@ -214,75 +397,91 @@ static int bits_for(uint32_t max_value)
     return b;
 }
 
-// Stable LSD radix sort of (u64 key, u32 value) pairs on the low `nbits` key
-// bits.  Ping-pongs between (keys, vals) and (keys_tmp, vals_tmp); *result_in_tmp
-// says where the sorted data ended up.
-int radix_sort_pairs(uint64_t *keys, uint32_t *vals, uint64_t *keys_tmp, uint32_t *vals_tmp, uint64_t R,
-                     int nbits, void *scratch, size_t scratch_bytes, int *result_in_tmp, hipStream_t st)
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+// Depth order of the surfels + scan of tiles_touched in that order.
+//   order   : N u32, surfel index at each depth-order position
+//   offsets : N u32, inclusive scan of tiles_touched[order[.]]
+//   total   : device u32 = R
+// scratch: order keys (N) | tmp keys (N) | tmp vals (N) | block sums | N on device | sort scratch
+size_t order_scratch_bytes(int N)
 {
-    *result_in_tmp = 0;
-    if (R == 0) return SLS_OK;
-    if (scratch_bytes < sort_scratch_bytes(R)) {
-        set_error("sort scratch too small: %zu < %zu", scratch_bytes, sort_scratch_bytes(R));
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n);
+}
+
+int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
+                            uint32_t *total_out, void *scratch, size_t scratch_bytes, hipStream_t st)
+{
+    if (scratch_bytes < order_scratch_bytes(N)) {
+        set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
         return SLS_E_SCRATCH;
     }
-    const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
-    const int nblocks = (nchunks + kSortWavesPerBlock - 1) / kSortWavesPerBlock;
-    uint32_t *cnt = (uint32_t *)scratch;
-    uint32_t *totals = cnt + (size_t)256 * nchunks;
-    const int npasses = (nbits + 7) / 8;
-    uint64_t *kb[2] = { keys, keys_tmp };
-    uint32_t *vb[2] = { vals, vals_tmp };
-    for (int p = 0; p < npasses; ++p) {
-        const int shift = 8 * p;
-        const int src = p & 1, dst = src ^ 1;
-        {
-            ScopedTimer tm(T_SORT_HIST, st);
-            hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(256), 0, st, kb[src], R, shift, cnt, nchunks);
-        }
-        SLS_LAUNCH_CHECK("sort_hist_kernel");
-        {
-            ScopedTimer tm(T_SORT_ROWSCAN, st);
-            hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(256), 0, st, cnt, nchunks, totals);
-        }
-        SLS_LAUNCH_CHECK("sort_rowscan_kernel");
-        {
-            ScopedTimer tm(T_SORT_SCATTER, st);
-            hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(256), 0, st, kb[src], vb[src], kb[dst],
-                               vb[dst], R, shift, cnt, totals, nchunks);
-        }
-        SLS_LAUNCH_CHECK("sort_scatter_kernel");
+    const int nb = (N + 255) / 256;
+    uint32_t *keys = (uint32_t *)scratch;
+    uint32_t *keys_tmp = keys + N;
+    uint32_t *vals_tmp = keys_tmp + N;
+    uint32_t *block_sums = vals_tmp + N;
+    uint32_t *n_dev = block_sums + nb;          // device copy of N for the count_ptr protocol
+    void *sort_scratch = (void *)(n_dev + 32);
+    const size_t sort_bytes = sort_scratch_bytes((uint64_t)N);
+    {
+        ScopedTimer tm(T_EMIT_KEYS, st);
+        hipLaunchKernelGGL(depth_keys_kernel, dim3(nb), dim3(256), 0, st, N, depth, tiles, keys, order, n_dev);
     }
-    *result_in_tmp = npasses & 1;
+    SLS_LAUNCH_CHECK("depth_keys_kernel");
+    int which = 0;
+    int rc = radix_sort_pairs_t<uint32_t>(keys, order, keys_tmp, vals_tmp, n_dev, (uint32_t)N, 32, sort_scratch,
+                                          sort_bytes, &which, st);
+    if (rc) return rc;
+    if (which != 0) {   // 4 passes: the result is back in (keys, order)
+        set_error("internal: depth order ended in the temporary buffer");
+        return SLS_E_ARG;
+    }
+    ScopedTimer tm(T_SCAN, st);
+    hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
+                       block_sums);
+    SLS_LAUNCH_CHECK("gather_block_sums_kernel");
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, total_out);
+    SLS_LAUNCH_CHECK("scan_block_sums_kernel");
+    hipLaunchKernelGGL(gather_scan_final_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
+                       (const uint32_t *)block_sums, offsets);
+    SLS_LAUNCH_CHECK("gather_scan_final_kernel");
     return SLS_OK;
 }
 
-int launch_bin_sort(const DevCam &cam, int N, uint64_t R, const int32_t *rect, const uint32_t *tiles,
-                    const float *depth, const uint32_t *offsets, uint64_t *keys, uint32_t *vals,
-                    uint64_t *keys_tmp, uint32_t *vals_tmp, void *scratch, size_t scratch_bytes,
-                    int *sorted_in_tmp, uint32_t *ranges, hipStream_t st)
+// Emission in depth order + stable sort by tile + ranges.
+//   tkeys/vals, tkeys_tmp/vals_tmp : cap u32 each (ping-pong)
+//   count_ptr: device R; cap: host-side capacity of the buffers (>= R, or the
+//   overflow flag is raised and the excess instances are dropped)
+int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
+                    const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
+                    uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
+                    size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
+                    uint32_t *overflow, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
     SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
     *sorted_in_tmp = 0;
-    if (R == 0) return SLS_OK;
+    if (cap == 0 || N == 0) return SLS_OK;
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
-        hipLaunchKernelGGL(emit_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, (const int4 *)rect,
-                           tiles, offsets, depth, keys, vals);
+        hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
+                           (const int4 *)rect, tiles, offsets, cap, tkeys, vals, overflow);
     }
-    SLS_LAUNCH_CHECK("emit_keys_kernel");
-
-    const int total_bits = 32 + bits_for((uint32_t)(T - 1));
+    SLS_LAUNCH_CHECK("emit_tiles_kernel");
+    const int tile_bits = bits_for((uint32_t)(T - 1));
     int which = 0;
-    int rc = radix_sort_pairs(keys, vals, keys_tmp, vals_tmp, R, total_bits, scratch, scratch_bytes, &which, st);
+    int rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
+                                          scratch_bytes, &which, st);
     if (rc) return rc;
-    uint64_t *kb[2] = { keys, keys_tmp };
     *sorted_in_tmp = which;
     {
         ScopedTimer tm(T_TILE_RANGES, st);
-        hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st,
-                           kb[which], R, (uint2 *)ranges);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, st,
+                           (const uint32_t *)(which ? tkeys_tmp : tkeys), (const uint32_t *)(which ? vals_tmp : vals),
+                           count_ptr, cap, depth, (uint2 *)ranges, keys64_out);
     }
     SLS_LAUNCH_CHECK("tile_ranges_kernel");
     return SLS_OK;

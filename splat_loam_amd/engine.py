@@ -1,0 +1,173 @@
+"""MappingEngine: one native call per mapping iteration.
+
+`Mapper.optimize` (slam/mapper.py:150-204) spends its time in ~120 small torch
+kernels, a dozen allocations and several device->host syncs per iteration around
+the rasterizer.  The engine keeps the model's four raw parameter tensors where
+they are (torch Parameters), owns the flat gradient / Adam-state buckets and one
+workspace, and issues `sls_mapping_step` — activations, rasterizer forward,
+loss, backward, regulariser and Adam enqueued back to back on the stream with no
+host sync; the iteration's status (instance count, overflow flag, loss terms) is
+read once at the end, which is the same single sync per iteration the reference
+has (`loss_total.item()`, slam/mapper.py:206-209).
+
+Keyframe-parallel mode: every rank calls step() on ITS keyframe
+with the same replicated model; the flat 10*N gradient bucket (+1 overflow word)
+is all-reduced in one RCCL collective and every rank applies the same guarded
+Adam update.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _abi
+from .fused import camera_aux
+from .rasterizer import GaussianRasterizationSettings, get_camera
+
+
+class MappingEngine:
+    def __init__(self, model, cfg, lrs=(5e-4, 5e-2, 5e-3, 1e-3), betas=(0.9, 0.999), eps=1e-15,
+                 capacity_factor: float = 1.3):
+        self.model, self.cfg = model, cfg
+        self.lrs, self.betas, self.eps = tuple(lrs), tuple(betas), float(eps)
+        self.capacity_factor = float(capacity_factor)
+        p = model._xyz
+        if not p.is_cuda:
+            raise RuntimeError("MappingEngine needs ROCm device parameters; there is no CPU fallback")
+        self.dev = p.device
+        self.N = int(p.shape[0])
+        n10 = 10 * self.N
+        # flat buckets, one extra word at the end of grads carries the overflow flag through the all-reduce
+        self.grads = torch.zeros((n10 + 1,), dtype=torch.float32, device=self.dev)
+        self.exp_avg = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
+        self.exp_avg_sq = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
+        self.status = torch.zeros((8,), dtype=torch.int32, device=self.dev)
+        self.flag = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        self.t = 0
+        self.capacity = 0
+        self.workspace = None
+        self.allmap_ptr = C.c_void_p(0)
+        self.last = None
+
+    # views of the flat gradient bucket in the optimiser's group order
+    def grad_views(self):
+        N = self.N
+        g = self.grads
+        return {"xyz": g[0:3 * N].view(N, 3), "opacity": g[3 * N:4 * N].view(N, 1),
+                "scaling": g[4 * N:6 * N].view(N, 2), "rotation": g[6 * N:10 * N].view(N, 4)}
+
+    def _ensure_workspace(self, H, W, capacity):
+        lib = _abi.lib()
+        if self.workspace is None or capacity > self.capacity:
+            self.capacity = int(capacity)
+            nbytes = int(lib.sls_mapping_workspace_bytes(self.N, H, W, self.capacity))
+            self.workspace = None     # release before re-allocating
+            self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
+        base = self.workspace.data_ptr()
+        return (base + 255) & ~255, self.workspace.numel() - 256
+
+    def _config(self, apply_adam, with_regulariser):
+        c, cfg = _abi.SlsMappingConfig(), self.cfg
+        c.lambda_alpha, c.lambda_normal = cfg.opt_lambda_alpha, cfg.opt_lambda_normal
+        c.scaling_max = cfg.opt_scaling_max
+        c.scaling_max_penalty = cfg.opt_scaling_max_penalty if with_regulariser else 0.0
+        c.depth_ratio = cfg.depth_ratio
+        c.lr_xyz, c.lr_opacity, c.lr_scaling, c.lr_rotation = self.lrs
+        c.apply_adam = 1 if apply_adam else 0
+        c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
+        return c
+
+    def _params(self):
+        m = self.model
+        ps = (m._xyz, m._scaling, m._rotation, m._opacity)
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.shape[0] != self.N:
+                raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
+        return ps
+
+    def _enqueue(self, camera, apply_adam, with_regulariser):
+        lib = _abi.lib()
+        H, W = int(camera.image_height), int(camera.image_width)
+        settings = GaussianRasterizationSettings(H, W, 1.0, camera.world_view_transform, camera.projection_matrix)
+        ce = get_camera(settings, self.dev)
+        aux = camera_aux(camera)
+        if self.capacity == 0:
+            self.capacity = max(4 * self.N, 1 << 16)
+        ws_ptr, ws_bytes = self._ensure_workspace(H, W, self.capacity)
+        xyz, scaling, rotation, opacity = self._params()
+        cfg = self._config(apply_adam, with_regulariser)
+        _abi.check(lib.sls_mapping_step(
+            C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
+            self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
+            aux.gt.data_ptr(), aux.valid.data_ptr(), aux.n_valid, ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
+            aux.col_h.data_ptr(), aux.row_h.data_ptr(), C.byref(cfg), self.capacity, ws_ptr, ws_bytes,
+            self.status.data_ptr(), C.byref(self.allmap_ptr), torch.cuda.current_stream(self.dev).cuda_stream),
+            "sls_mapping_step")
+
+    def _read_status(self):
+        h = self.status.cpu()                       # the one sync of the iteration
+        R, overflow = int(h[0].item()) & 0xFFFFFFFF, int(h[1].item())
+        f = h.view(torch.float32)
+        return {"R": R, "overflow": bool(overflow), "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
+                "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
+
+    @torch.no_grad()
+    def step(self, camera, group=None, sync: bool = True):
+        """One mapping iteration on `camera`.  Returns the status dict (sync=True)
+        or None (sync=False: fire-and-forget; overflow is then detected at the
+        next synchronous step, the skipped Adam update keeps the model intact)."""
+        sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+        while True:
+            if not sharded:
+                self._enqueue(camera, apply_adam=True, with_regulariser=True)
+            else:
+                rank = dist.get_rank(group)
+                self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0))
+                # overflow word rides at the end of the gradient bucket: one collective
+                self.grads[-1:] = self.status[1:2].to(torch.float32)
+                dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+                self.flag.copy_((self.grads[-1:] > 0).to(torch.int32))
+                self._adam_guarded()
+            if not sync:
+                self.t += 1
+                return None
+            st = self._read_status()
+            if sharded:
+                st["overflow"] = bool(int(self.flag.item()))
+            if not st["overflow"]:
+                self.t += 1
+                self.last = st
+                return st
+            # grow and repeat the iteration (parameters were not touched)
+            need = st["R"]
+            if sharded:
+                t = torch.tensor([need], dtype=torch.int64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                need = int(t.item())
+            self.capacity = int(max(need, self.capacity) * self.capacity_factor) + 1024
+            self.workspace = None
+
+    def _adam_guarded(self):
+        lib = _abi.lib()
+        N = self.N
+        xyz, scaling, rotation, opacity = self._params()
+        arr = (_abi.SlsAdamGroup * 4)()
+        spec = ((xyz, 0, 3 * N, self.lrs[0]), (opacity, 3 * N, N, self.lrs[1]),
+                (scaling, 4 * N, 2 * N, self.lrs[2]), (rotation, 6 * N, 4 * N, self.lrs[3]))
+        for k, (p, off, n, lr) in enumerate(spec):
+            arr[k].param = p.data_ptr()
+            arr[k].grad = self.grads.data_ptr() + 4 * off
+            arr[k].exp_avg = self.exp_avg.data_ptr() + 4 * off
+            arr[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * off
+            arr[k].numel = n
+            arr[k].lr = lr
+        _abi.check(lib.sls_adam_step_guarded(arr, 4, self.betas[0], self.betas[1], self.eps, self.t + 1,
+                                             self.flag.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream),
+                   "sls_adam_step_guarded")
+
+    def allmap(self, H, W) -> torch.Tensor:
+        """Copy of the last iteration's allmap (7,H,W) out of the workspace."""
+        off = int(self.allmap_ptr.value) - self.workspace.data_ptr()
+        return self.workspace[off:off + 7 * H * W * 4].view(torch.float32).view(7, H, W).clone()

@@ -107,12 +107,13 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 class ForwardState:
     """Everything the backward (and the tests) need from one forward."""
-    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "depth", "offsets", "keys", "vals",
+    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "depth", "order", "offsets", "keys", "vals",
                  "ranges", "pix_state", "pix_contrib", "tile_consumed", "allmap")
 
 
-def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations) -> ForwardState:
-    """preprocess -> scan -> [host reads R] -> keys -> radix sort -> ranges -> render."""
+def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
+                      want_keys: bool = False) -> ForwardState:
+    """preprocess -> depth order -> scan -> [host reads R] -> binning -> stable sort by tile -> ranges -> render."""
     for name, t in (("means3D", means3D), ("opacities", opacities), ("scales", scales), ("rotations", rotations)):
         _need_cuda(t, name)
     lib = _abi.lib()
@@ -142,20 +143,22 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.rect = torch.empty((N, 4), dtype=i32, device=dev)
     s.tiles = torch.empty((N,), dtype=u32, device=dev)
     s.depth = torch.empty((N,), dtype=f32, device=dev)
+    s.order = torch.empty((N,), dtype=u32, device=dev)
     s.offsets = torch.empty((N,), dtype=u32, device=dev)
     total = torch.zeros((1,), dtype=u32, device=dev)
     sb = int(lib.sls_stage1_scratch_bytes(N))
     scratch1 = torch.empty((max(sb, 4),), dtype=torch.uint8, device=dev)
     _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                       opacities.data_ptr(), s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
-                                      s.tiles.data_ptr(), s.depth.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
-                                      scratch1.data_ptr(), sb, st), "sls_forward_stage1")
+                                      s.tiles.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(),
+                                      total.data_ptr(), scratch1.data_ptr(), sb, st), "sls_forward_stage1")
     dbg()
     R = int(total.item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
     s.R = R
     Ra = max(R, 1)
-    keys_a = torch.empty((Ra,), dtype=torch.int64, device=dev)
-    keys_b = torch.empty((Ra,), dtype=torch.int64, device=dev)
+    keys_a = torch.empty((Ra,), dtype=u32, device=dev)
+    keys_b = torch.empty((Ra,), dtype=u32, device=dev)
+    keys64 = torch.empty((Ra,), dtype=torch.int64, device=dev) if want_keys else None
     vals_a = torch.empty((Ra,), dtype=u32, device=dev)
     vals_b = torch.empty((Ra,), dtype=u32, device=dev)
     ssb = int(lib.sls_sort_scratch_bytes(R))
@@ -167,18 +170,19 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.tile_consumed = torch.empty((T,), dtype=u32, device=dev)
     in_tmp = C.c_int(0)
     _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
-                                      s.depth.data_ptr(), s.offsets.data_ptr(), keys_a.data_ptr(), vals_a.data_ptr(),
-                                      keys_b.data_ptr(), vals_b.data_ptr(), sort_scratch.data_ptr(), ssb,
-                                      C.byref(in_tmp), s.ranges.data_ptr(), ce.col_cs.data_ptr(),
+                                      s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
+                                      keys_a.data_ptr(), vals_a.data_ptr(), keys_b.data_ptr(), vals_b.data_ptr(),
+                                      sort_scratch.data_ptr(), ssb, C.byref(in_tmp),
+                                      keys64.data_ptr() if want_keys else None, s.ranges.data_ptr(),
+                                      ce.col_cs.data_ptr(),
                                       ce.row_cs.data_ptr(), s.allmap.data_ptr(), s.pix_state.data_ptr(),
                                       s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(), st), "sls_forward_stage2")
     dbg()
-    if in_tmp.value:
-        s.keys, s.vals = keys_b, vals_b
-    else:
-        s.keys, s.vals = keys_a, vals_a
+    s.vals = vals_b if in_tmp.value else vals_a
+    s.keys = keys64        # 64-bit (tile << 32 | depth bits) keys, only when asked for (tests)
     if R == 0:
-        s.keys, s.vals = s.keys[:0], s.vals[:0]
+        s.vals = s.vals[:0]
+        s.keys = keys64[:0] if want_keys else None
     return s
 
 

@@ -26,7 +26,7 @@ def hip_forward(device, sc, view, proj, H, W, scale_modifier=1.0):
         viewmatrix=torch.tensor(view, device=device), projmatrix=torch.tensor(proj, device=device),
         prefiltered=False, debug=True)
     t = {k: torch.tensor(sc[k], device=device) for k in ("means", "scales", "rots", "opac")}
-    st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"])
+    st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"], want_keys=True)
     torch.cuda.synchronize()
     return st, t
 

@@ -31,7 +31,13 @@ def _compare_forward(oracle32, st, ost, cam, name):
     assert np.array_equal(u32(st.tiles), pre["tiles"]), f"{name}: tiles_touched"
     assert np.array_equal(u32(st.depth), pre["depth"].view(np.uint32)), f"{name}: depth key bits"
     assert st.R == ost["binned"]["R"], f"{name}: R"
-    assert np.array_equal(u32(st.offsets), np.cumsum(pre["tiles"], dtype=np.uint64).astype(np.uint32))
+    order = u32(st.order)
+    vis = pre["tiles"] > 0
+    nvis = int(vis.sum())
+    ref_order = np.lexsort((np.arange(len(vis)), pre["depth"].view(np.uint32)))        # (depth bits, index)
+    ref_order = ref_order[vis[ref_order]]
+    assert np.array_equal(order[:nvis], ref_order.astype(np.uint32)), f"{name}: depth order"
+    assert np.array_equal(u32(st.offsets), np.cumsum(pre["tiles"][order], dtype=np.uint64).astype(np.uint32))
     assert np.array_equal(st.keys.cpu().numpy().view(np.uint64), ost["binned"]["keys"]), f"{name}: sorted keys"
     assert np.array_equal(u32(st.vals), ost["binned"]["vals"]), f"{name}: sorted values"
     assert np.array_equal(u32(st.ranges), ost["binned"]["ranges"]), f"{name}: tile ranges"
@@ -367,3 +373,48 @@ def test_fused_step_matches_unfused_step(device):
         # near-zero gradient amplify rounding differences; bound the drift by a
         # fraction of the distance actually travelled
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.05 * moved, k
+
+
+def test_mapping_engine_matches_unfused_step(device):
+    """sls_mapping_step (one native call per iteration, raw parameters, no host
+    sync inside) == optimize_step (torch activations + torch render/loss + torch
+    Adam): same loss, same gradients, same parameter trajectory; the instance
+    buffers overflow once on purpose and the iteration is repeated."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig, mapping_loss
+    from splat_loam_amd.renderer import render
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 6000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=14, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    valid = valid.copy(); valid[0, :2, :9] = 0
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+    cfg = MappingConfig()
+    a = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"] * 1.7, sc["opac"], device=str(device))
+    b = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"] * 1.7, sc["opac"], device=str(device))
+    a.training_setup(fused=False)
+    eng = MappingEngine(b, cfg)
+    eng.capacity = 2048            # far too small: forces the overflow / retry path
+    names = ("_xyz", "_scaling", "_rotation", "_opacity")
+    init = {k: getattr(a, k).detach().clone() for k in names}
+    for it in range(3):
+        a.optimizer.zero_grad(set_to_none=True)
+        loss = mapping_loss(render(cam, a, cfg.depth_ratio), cam, a, cfg)
+        loss.backward()
+        st = eng.step(cam)
+        assert not st["overflow"] and st["R"] > 2048
+        assert abs(st["loss"] - float(loss)) <= 1e-4 * abs(float(loss)), (it, st, float(loss))
+        gv = eng.grad_views()
+        for k, p in (("xyz", a._xyz), ("opacity", a._opacity), ("scaling", a._scaling), ("rotation", a._rotation)):
+            ref = p.grad
+            scale = float(ref.abs().max())
+            assert float((gv[k] - ref).abs().max()) <= 2e-4 * scale, (it, k)
+        with torch.no_grad():
+            a.optimizer.step()
+    for k in names:
+        pa, pb = getattr(a, k).detach(), getattr(b, k).detach()
+        moved = float((pa - init[k]).abs().max())
+        assert moved > 0 and float((pa - pb).abs().max()) <= 0.05 * moved, k
+    am = eng.allmap(H, W)
+    assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
