@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--async-steps", action="store_true",
                     help="engine mode: do not read the status word after every iteration (the reference syncs once "
                          "per iteration for its loss EMA, slam/mapper.py:206-209; default keeps that sync)")
+    ap.add_argument("--variant", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
+                    help="tuning: tile-kernel variants (sls_debug_variant)")
+    ap.add_argument("--pad-lds", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
+                    help="tuning: unused dynamic LDS bytes for the tile kernels (caps workgroups per CU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +100,10 @@ def main():
     from splat_loam_amd.scene import Camera, SurfelModel
 
     lib = _abi.lib()
+    if args.pad_lds:
+        lib.sls_debug_pad_lds(args.pad_lds[0], args.pad_lds[1])
+    if args.variant:
+        lib.sls_debug_variant(args.variant[0], args.variant[1])
     N, H, W = args.n, args.height, args.width
     scene = synth.make_scene(N, H, W, seed=0)
     poses = synth.keyframe_poses(max(world, 1))

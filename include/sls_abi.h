@@ -236,6 +236,15 @@ int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
  * load balance across tiles.  Pass nulls to switch it off (the default). */
 int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles);
 
+/* Tuning/diagnostic: choose the tile-kernel variant (0 = one workgroup per tile with
+ * shared LDS staging, 1 = one independent wave per 8x8 sub-tile; negative = keep).
+ * Both produce the same results; tests run both. */
+int sls_debug_variant(int fwd_variant, int bwd_variant);
+
+/* Tuning: bytes of unused dynamic LDS requested by the tile kernels; caps the
+ * workgroups resident per CU so that later workgroups are dispatched dynamically. */
+int sls_debug_pad_lds(int fwd_bytes, int bwd_bytes);
+
 /* Device self-test of the wave64 primitives (DPP reduction, ballot ranking).
  * Returns 0 if they behave as the kernels assume.  Synchronises. */
 int sls_selftest(void *stream);

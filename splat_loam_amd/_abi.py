@@ -83,6 +83,8 @@ _PROTOS = {
     "sls_timing_enable": (C.c_int, [C.c_int]),
     "sls_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sls_debug_wave_cycles": (C.c_int, [_VP, _VP]),
+    "sls_debug_variant": (C.c_int, [C.c_int, C.c_int]),
+    "sls_debug_pad_lds": (C.c_int, [C.c_int, C.c_int]),
     "sls_selftest": (C.c_int, [_VP]),
 }
 

@@ -57,6 +57,7 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st);
 extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
+extern int g_fwd_variant, g_bwd_variant, g_pad_lds_fwd, g_pad_lds_bwd;
 size_t knn_scratch_bytes(int M);
 int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
 
@@ -305,6 +306,20 @@ int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles)
 {
     g_dbg_fwd_cycles = fwd_cycles;
     g_dbg_bwd_cycles = bwd_cycles;
+    return SLS_OK;
+}
+
+int sls_debug_variant(int fwd_variant, int bwd_variant)
+{
+    if (fwd_variant >= 0) g_fwd_variant = fwd_variant;
+    if (bwd_variant >= 0) g_bwd_variant = bwd_variant;
+    return SLS_OK;
+}
+
+int sls_debug_pad_lds(int fwd_bytes, int bwd_bytes)
+{
+    g_pad_lds_fwd = fwd_bytes;
+    g_pad_lds_bwd = bwd_bytes;
     return SLS_OK;
 }
 

@@ -418,3 +418,22 @@ def test_mapping_engine_matches_unfused_step(device):
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.05 * moved, k
     am = eng.allmap(H, W)
     assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
+
+
+@pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1)], ids=["workgroup-per-tile", "wave-per-subtile"])
+def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
+    """Both implementations of the tile kernels (shared-LDS workgroup per tile /
+    independent wave per 8x8 sub-tile) pass the same parity bar."""
+    from splat_loam_amd import _abi
+    lib = _abi.lib()
+    lib.sls_debug_variant(fwd_variant, bwd_variant)
+    try:
+        N, H, W = 20000, 64, 512
+        sc, view, proj = scene_and_camera(N, H, W, seed=21, range_lo=2.0, range_hi=30.0)
+        st, t = hip_forward(device, sc, view, proj, H, W)
+        cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+        ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+        _compare_forward(oracle32, st, ost, cam, f"variant{fwd_variant}")
+        _compare_backward(oracle32, st, t, ost, sc, f"variant{bwd_variant}")
+    finally:
+        lib.sls_debug_variant(1, 1)
