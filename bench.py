@@ -88,11 +88,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # ranks > devices only in the single-GPU self-test (gloo)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("SLS_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            assert world <= ndev, f"{world} ranks but {ndev} GPUs visible"
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from splat_loam_amd import _abi, synth

@@ -12,7 +12,9 @@ namespace sls {
 // launchers implemented in the other translation units
 int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
-                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, hipStream_t st);
+                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
+                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st);
+void depth_order_key_buffers(int N, void *scratch, uint32_t **keys, uint32_t **n_dev);
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
                           const float *scales, const float *rots, const float *opac, const int32_t *radii,
                           const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
@@ -20,7 +22,8 @@ int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int
 size_t sort_scratch_bytes(uint64_t cap);
 size_t order_scratch_bytes(int N);
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
-                            uint32_t *total_out, void *scratch, size_t scratch_bytes, hipStream_t st);
+                            uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
+                            hipStream_t st);
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
                     const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
@@ -112,10 +115,16 @@ int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const 
                     order && offsets && scratch,
                 "null pointer");
     const DevCam dc = make_devcam(*cam);
+    if (scratch_bytes < order_scratch_bytes(N)) {
+        set_error("stage1 scratch too small");
+        return SLS_E_SCRATCH;
+    }
+    uint32_t *okeys, *n_dev;
+    depth_order_key_buffers(N, scratch, &okeys, &n_dev);
     int rc = launch_preprocess_fwd(dc, 0, 0.0f, 0.0f, nullptr, N, means3D, scales, rotations, opacities, rec, radii,
-                                   rect, tiles_touched, depth, st);
+                                   rect, tiles_touched, depth, okeys, order, n_dev, st);
     if (rc) return rc;
-    return launch_depth_order_scan(N, depth, tiles_touched, order, offsets, total_out, scratch, scratch_bytes, st);
+    return launch_depth_order_scan(N, depth, tiles_touched, order, offsets, total_out, scratch, scratch_bytes, 1, st);
 }
 
 size_t sls_sort_scratch_bytes(uint64_t R) { return sort_scratch_bytes(R); }
@@ -208,12 +217,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
 
     // ---- forward ---------------------------------------------------------------
+    uint32_t *okeys, *n_dev;
+    depth_order_key_buffers(N, w.order_scratch, &okeys, &n_dev);
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, &status_dev->loss_reg, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   st);
+                                   okeys, w.order, n_dev, st);
     if (rc) return rc;
     rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
-                                 w.order_scratch_bytes, st);
+                                 w.order_scratch_bytes, 1, st);
     if (rc) return rc;
     int in_tmp = 0;
     rc = launch_bin_sort(dc, N, &status_dev->R, cap, w.order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,

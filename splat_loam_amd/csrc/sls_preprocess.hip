@@ -137,11 +137,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     DevCam cam, RegArgs ra, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
     const float4 *__restrict__ rots, const float *__restrict__ opac,
     float4 *__restrict__ rec, int *__restrict__ radii, int4 *__restrict__ rect,
-    uint32_t *__restrict__ tiles, float *__restrict__ depth)
+    uint32_t *__restrict__ tiles, float *__restrict__ depth, uint32_t *__restrict__ order_keys,
+    uint32_t *__restrict__ order_vals, uint32_t *__restrict__ n_dev)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
     float my_reg = 0.0f;
+    if (i == 0 && n_dev) *n_dev = (uint32_t)N;
     if (i < N) {
         float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
         int r_out = 0;
@@ -207,6 +209,24 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                     float th2, daz2;
                     ball_extent(sqrtf(rho_max) * smax, g.rho, g.rxy, th2, daz2);
                     const float r2 = sqrtf(0.5f * rho_max);
+                    // Tighter bound for the 3D branch: the hit point is p + u su Tu + v sv Tv with
+                    // u^2+v^2 <= rho_max, an ellipse; its (az, el) extent to first order, plus a bound
+                    // on the second-order remainder of atan2 (|Hessian| <= 1/r^2 on the segment).
+                    // min(ball bound, ellipse bound) is still conservative.
+                    const float kk = sqrtf(rho_max), rad = kk * smax;
+                    if (g.rxy > 2.0f * rad && g.rxy > 0.5f * g.rho) {
+                        const float au = (g.p[0] * g.Tu[1] - g.p[1] * g.Tu[0]) / g.rxy2;
+                        const float av = (g.p[0] * g.Tv[1] - g.p[1] * g.Tv[0]) / g.rxy2;
+                        const float rat_xy = rad / (g.rxy - rad);
+                        const float az_ell = kk * sqrtf(g.su * g.su * au * au + g.sv * g.sv * av * av) + 0.75f * rat_xy * rat_xy;
+                        const float zr = g.p[2] / (g.rxy * g.rho2);
+                        const float eu = -zr * (g.p[0] * g.Tu[0] + g.p[1] * g.Tu[1]) + g.rxy / g.rho2 * g.Tu[2];
+                        const float ev = -zr * (g.p[0] * g.Tv[0] + g.p[1] * g.Tv[1]) + g.rxy / g.rho2 * g.Tv[2];
+                        const float rat = rad / (g.rho - rad);
+                        const float el_ell = kk * sqrtf(g.su * g.su * eu * eu + g.sv * g.sv * ev * ev) + 1.5f * rat * rat;
+                        daz2 = fminf(daz2, az_ell * 1.02f);
+                        th2 = fminf(th2, el_ell * 1.02f);
+                    }
                     ex = fmaxf(fabsf(cam.fx) * daz2, r2) * 1.001f + 0.05f;
                     ey = fmaxf(fabsf(cam.fy) * th2, r2) * 1.001f + 0.05f;
                 }
@@ -223,8 +243,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         rect[i] = rc;
         tiles[i] = my_tiles;
         depth[i] = dep;
+        if (order_keys) {   // input of the depth-order sort: culled surfels go behind every visible one
+            order_keys[i] = my_tiles ? __float_as_uint(dep) : 0xFFFFFFFFu;
+            order_vals[i] = (uint32_t)i;
+        }
     }
-    (void)my_tiles;
     if (ra.pen != 0.0f && ra.reg_out) {   // block reduction of the regulariser, one atomic per block
         __shared__ float s_part[4];
         float v = my_reg;
@@ -351,14 +374,16 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(DevCam cam, int N, co
 // ---------------------------------------------------------------------------
 int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
-                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, hipStream_t st)
+                          int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
+                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st)
 {
     const int nb = (N + 255) / 256;
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
-                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth);
+                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, order_keys,
+                       order_vals, n_dev);
     SLS_LAUNCH_CHECK("preprocess_fwd_kernel");
     return SLS_OK;
 }

@@ -411,8 +411,17 @@ size_t order_scratch_bytes(int N)
     return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n);
 }
 
+// where preprocess may write the sort input directly (saves the depth_keys launch)
+void depth_order_key_buffers(int N, void *scratch, uint32_t **keys, uint32_t **n_dev)
+{
+    const int nb = (N + 255) / 256;
+    *keys = (uint32_t *)scratch;
+    *n_dev = *keys + 3 * (size_t)N + nb;
+}
+
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
-                            uint32_t *total_out, void *scratch, size_t scratch_bytes, hipStream_t st)
+                            uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
+                            hipStream_t st)
 {
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
@@ -426,11 +435,11 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     uint32_t *n_dev = block_sums + nb;          // device copy of N for the count_ptr protocol
     void *sort_scratch = (void *)(n_dev + 32);
     const size_t sort_bytes = sort_scratch_bytes((uint64_t)N);
-    {
+    if (!keys_prefilled) {
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(depth_keys_kernel, dim3(nb), dim3(256), 0, st, N, depth, tiles, keys, order, n_dev);
+        SLS_LAUNCH_CHECK("depth_keys_kernel");
     }
-    SLS_LAUNCH_CHECK("depth_keys_kernel");
     int which = 0;
     int rc = radix_sort_pairs_t<uint32_t>(keys, order, keys_tmp, vals_tmp, n_dev, (uint32_t)N, 32, sort_scratch,
                                           sort_bytes, &which, st);

@@ -437,3 +437,59 @@ def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, 
         _compare_backward(oracle32, st, t, ost, sc, f"variant{bwd_variant}")
     finally:
         lib.sls_debug_variant(1, 1)
+
+
+def _engine_rank(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 in this test
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=31, range_lo=2.0, range_hi=15.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[rank], data_device="cuda:0")
+    model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+    eng = MappingEngine(model, MappingConfig())
+    if rank == 1:
+        eng.capacity = 1024           # one rank overflows: BOTH must skip Adam and repeat
+    st = eng.step(cam)
+    g1 = eng.grads[:-1].cpu().numpy()
+    st = eng.step(cam)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
+             rot=model._rotation.detach().cpu().numpy(), g=eng.grads.cpu().numpy(), g1=g1, R=st["R"], t=eng.t)
+    dist.destroy_process_group()
+
+
+def test_engine_keyframe_parallel_two_ranks(device, tmp_path):
+    """Keyframe-parallel engine with 2 ranks (gloo, one GPU): the all-reduced gradient
+    equals the sum of the two keyframes' gradients (regulariser once), replicas stay
+    bit-identical, an overflow on one rank makes every rank repeat the iteration."""
+    import socket
+    import torch.multiprocessing as mp
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_engine_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert int(r0["t"]) == int(r1["t"]) == 2
+    for k in ("xyz", "rot", "g", "g1"):
+        assert np.array_equal(r0[k], r1[k]), f"replicas diverged: {k}"
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=31, range_lo=2.0, range_hi=15.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    total = 0.0
+    for rank in range(2):
+        cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[rank], data_device=str(device))
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+        eng = MappingEngine(model, MappingConfig())
+        eng._enqueue(cam, apply_adam=False, with_regulariser=(rank == 0))
+        torch.cuda.synchronize()
+        total = total + eng.grads[:-1].cpu().numpy().astype(np.float64)
+    scale = np.abs(total).max()
+    assert np.abs(r0["g1"] - total).max() <= 1e-5 * scale
