@@ -228,7 +228,7 @@ int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t 
  * out (later launches untimed). */
 int sls_timing_slots(void);
 const char *sls_timing_name(int slot);
-int sls_timing_enable(int on);
+int sls_timing_enable(int mode);   /* 0 off, 1 every launch, 2 the two tile kernels only */
 int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
 
 /* Diagnostic: when non-null, the tile kernels write the shader-clock cycles each

@@ -28,6 +28,7 @@ static const char *kTimerNames[T_COUNT] = {
 constexpr int kTimerPool = 8192;
 struct TimerState {
     bool enabled = false;
+    int mode = 0;          // 1: every launch, 2: the two tile kernels only
     int used = 0;
     int created = 0;
     hipEvent_t start[kTimerPool], stop[kTimerPool];
@@ -35,16 +36,19 @@ struct TimerState {
 };
 static TimerState g_timer;
 
+static inline bool timer_wants(int slot)
+{
+    return g_timer.enabled && (g_timer.mode == 1 || slot == T_RENDER_FWD || slot == T_RENDER_BWD);
+}
 void timer_begin(int slot, hipStream_t st)
 {
-    if (!g_timer.enabled || g_timer.used >= g_timer.created) return;
+    if (!timer_wants(slot) || g_timer.used >= g_timer.created) return;
     g_timer.slot[g_timer.used] = slot;
     (void)hipEventRecord(g_timer.start[g_timer.used], st);
 }
 void timer_end(int slot, hipStream_t st)
 {
-    (void)slot;
-    if (!g_timer.enabled || g_timer.used >= g_timer.created) return;
+    if (!timer_wants(slot) || g_timer.used >= g_timer.created) return;
     (void)hipEventRecord(g_timer.stop[g_timer.used], st);
     ++g_timer.used;
 }
@@ -335,6 +339,7 @@ int sls_timing_enable(int on)
         }
     }
     g_timer.enabled = on != 0;
+    g_timer.mode = on;
     g_timer.used = 0;
     return SLS_OK;
 }
