@@ -169,6 +169,24 @@ __device__ __forceinline__ float readlane63(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Sort key of the depth ordering: positive floats order like their bit patterns; subtracting
+// the pattern of 2^-3 (below the 0.2 m near cut) leaves 29 significant bits for ranges up to
+// 2^3 * 2^-3 * 2^(2^5)... i.e. any finite LiDAR range; culled surfels get the largest key so
+// they sort behind every visible one.  Monotone, so the order equals the order of the raw bits.
+__host__ __device__ inline uint32_t depth_order_key(float depth, bool visible)
+{
+    constexpr uint32_t kBase = 0x3E000000u;             // bits of 0.125f
+    constexpr uint32_t kMax = (1u << 29) - 1u;
+    if (!visible) return kMax;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t b = __float_as_uint(depth);
+#else
+    uint32_t b; __builtin_memcpy(&b, &depth, 4);
+#endif
+    const uint32_t k = b > kBase ? b - kBase : 0u;
+    return k < kMax - 1u ? k : kMax - 1u;
+}
+
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8
 // (speed only, never correctness); give each XCD a contiguous run of tiles so
 // neighbouring tiles, which share surfel records, share an L2.

@@ -14,7 +14,8 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st);
-void depth_order_key_buffers(int N, void *scratch, uint32_t **keys, uint32_t **n_dev);
+void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
+                             uint32_t **n_dev);
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
                           const float *scales, const float *rots, const float *opac, const int32_t *radii,
                           const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
@@ -119,10 +120,10 @@ int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const 
         set_error("stage1 scratch too small");
         return SLS_E_SCRATCH;
     }
-    uint32_t *okeys, *n_dev;
-    depth_order_key_buffers(N, scratch, &okeys, &n_dev);
+    uint32_t *okeys, *ovals, *n_dev;
+    depth_order_key_buffers(N, scratch, order, &okeys, &ovals, &n_dev);
     int rc = launch_preprocess_fwd(dc, 0, 0.0f, 0.0f, nullptr, N, means3D, scales, rotations, opacities, rec, radii,
-                                   rect, tiles_touched, depth, okeys, order, n_dev, st);
+                                   rect, tiles_touched, depth, okeys, ovals, n_dev, st);
     if (rc) return rc;
     return launch_depth_order_scan(N, depth, tiles_touched, order, offsets, total_out, scratch, scratch_bytes, 1, st);
 }
@@ -217,11 +218,11 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
 
     // ---- forward ---------------------------------------------------------------
-    uint32_t *okeys, *n_dev;
-    depth_order_key_buffers(N, w.order_scratch, &okeys, &n_dev);
+    uint32_t *okeys, *ovals, *n_dev;
+    depth_order_key_buffers(N, w.order_scratch, w.order, &okeys, &ovals, &n_dev);
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, &status_dev->loss_reg, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   okeys, w.order, n_dev, st);
+                                   okeys, ovals, n_dev, st);
     if (rc) return rc;
     rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st);

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         tiles[i] = my_tiles;
         depth[i] = dep;
         if (order_keys) {   // input of the depth-order sort: culled surfels go behind every visible one
-            order_keys[i] = my_tiles ? __float_as_uint(dep) : 0xFFFFFFFFu;
+            order_keys[i] = depth_order_key(dep, my_tiles != 0);
             order_vals[i] = (uint32_t)i;
         }
     }

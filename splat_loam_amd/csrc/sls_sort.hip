@@ -30,6 +30,8 @@ namespace sls {
 constexpr int kSortRounds = 16;
 constexpr int kSortWaveItems = kWave * kSortRounds;  // 1024 items per wave
 constexpr int kSortWavesPerBlock = 4;
+constexpr int kSortMaxBins = 2048;   // 11-bit digits at most
+constexpr int kDepthKeyBits = 29;    // compressed depth key, see depth_order_key()
 
 __device__ __forceinline__ uint32_t load_count(const uint32_t *count_ptr, uint32_t cap)
 {
@@ -40,18 +42,19 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *count_ptr, uint32
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
-template <typename KeyT>
+template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *__restrict__ keys,
                                                         const uint32_t *__restrict__ count_ptr, uint32_t cap,
                                                         int shift, uint32_t *__restrict__ cnt, int nchunks_cap)
 {
-    __shared__ uint32_t s_hist[kSortWavesPerBlock][256];
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t s_hist[kSortWavesPerBlock][BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s_hist[wave][lane + 64 * k] = 0;
+    for (int k = 0; k < BINS / 64; ++k) s_hist[wave][lane + 64 * k] = 0;
     if (chunk >= nchunks) return;
     const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
     KeyT k[kSortRounds];
@@ -64,11 +67,11 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *__restrict__
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
         const uint32_t idx = base + (uint32_t)r * 64;
-        if (idx < R) atomicAdd(&s_hist[wave][(uint32_t)(k[r] >> shift) & 255u], 1u);
+        if (idx < R) atomicAdd(&s_hist[wave][(uint32_t)(k[r] >> shift) & (uint32_t)(BINS - 1)], 1u);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < BINS / 64; ++q) {
         const int d = lane + 64 * q;
         cnt[(size_t)d * nchunks_cap + chunk] = s_hist[wave][d];
     }
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
 }
 
 // step 3: stable scatter
-template <typename KeyT>
+template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restrict__ keys_in,
                                                            const uint32_t *__restrict__ vals_in,
                                                            KeyT *__restrict__ keys_out,
@@ -119,15 +122,19 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
                                                            int shift, const uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ totals, int nchunks_cap)
 {
-    __shared__ uint32_t s_cursor[kSortWavesPerBlock][256];
-    __shared__ uint32_t s_digit_base[256];
+    constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread
+    __shared__ uint32_t s_cursor[kSortWavesPerBlock][BINS];
+    __shared__ uint32_t s_digit_base[BINS];
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
     if ((int)(blockIdx.x * kSortWavesPerBlock) >= nchunks) return;   // whole block beyond the data
-    {   // exclusive scan of the 256 digit totals (one per thread)
-        const uint32_t v = totals[threadIdx.x];
+    {   // exclusive scan of the BINS digit totals (PER consecutive ones per thread)
+        uint32_t loc[PER];
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { loc[k] = v; v += totals[threadIdx.x * PER + k]; }
         uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -138,13 +145,14 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
         __syncthreads();
         uint32_t wave_prefix = 0;
         for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-        s_digit_base[threadIdx.x] = wave_prefix + incl - v;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s_digit_base[threadIdx.x * PER + k] = wave_prefix + incl - v + loc[k];
         __syncthreads();
     }
     const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
     if (chunk >= nchunks) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < BINS / 64; ++q) {
         const int d = lane + 64 * q;
         s_cursor[wave][d] = s_digit_base[d] + cnt[(size_t)d * nchunks_cap + chunk];
     }
@@ -164,10 +172,10 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
     for (int r = 0; r < kSortRounds; ++r) {
         const uint32_t idx = base + (uint32_t)r * 64;
         const bool valid = idx < R;
-        const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+        const uint32_t digit = (uint32_t)(k[r] >> shift) & (uint32_t)(BINS - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (digit >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
@@ -190,7 +198,46 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
 size_t sort_scratch_bytes(uint64_t cap)
 {
     const uint64_t nchunks = (cap + kSortWaveItems - 1) / kSortWaveItems;
-    return (size_t)(256 * (nchunks ? nchunks : 1) + 256) * sizeof(uint32_t);
+    return (size_t)(kSortMaxBins * (nchunks ? nchunks : 1) + kSortMaxBins) * sizeof(uint32_t);
+}
+
+// digit width: as few passes as 11-bit digits allow, then the narrowest digit that still fits
+static void sort_plan(int nbits, int &npasses, int &bits)
+{
+    npasses = (nbits + 10) / 11;
+    bits = (nbits + npasses - 1) / npasses;
+    if (bits < 8) bits = 8;
+}
+int sort_passes(int nbits)
+{
+    int np, b;
+    sort_plan(nbits, np, b);
+    return np;
+}
+
+template <typename KeyT, int BITS>
+static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout, const uint32_t *count_ptr,
+                      uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int nblocks,
+                      hipStream_t st)
+{
+    {
+        ScopedTimer tm(T_SORT_HIST, st);
+        hipLaunchKernelGGL((sort_hist_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, count_ptr, cap, shift,
+                           cnt, nchunks);
+    }
+    SLS_LAUNCH_CHECK("sort_hist_kernel");
+    {
+        ScopedTimer tm(T_SORT_ROWSCAN, st);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, st, cnt, count_ptr, cap, nchunks, totals);
+    }
+    SLS_LAUNCH_CHECK("sort_rowscan_kernel");
+    {
+        ScopedTimer tm(T_SORT_SCATTER, st);
+        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, vin, kout, vout,
+                           count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks);
+    }
+    SLS_LAUNCH_CHECK("sort_scatter_kernel");
+    return SLS_OK;
 }
 
 // Stable LSD radix sort of (key, u32 value) pairs on the low `nbits` key bits.
@@ -211,31 +258,22 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
     const int nchunks = (int)(((uint64_t)cap + kSortWaveItems - 1) / kSortWaveItems);
     const int nblocks = (nchunks + kSortWavesPerBlock - 1) / kSortWavesPerBlock;
     uint32_t *cnt = (uint32_t *)scratch;
-    uint32_t *totals = cnt + (size_t)256 * nchunks;
-    const int npasses = (nbits + 7) / 8;
+    int npasses, bits;
+    sort_plan(nbits, npasses, bits);
+    uint32_t *totals = cnt + ((size_t)1 << bits) * nchunks;
     KeyT *kb[2] = { keys, keys_tmp };
     uint32_t *vb[2] = { vals, vals_tmp };
     for (int p = 0; p < npasses; ++p) {
-        const int shift = 8 * p;
+        const int shift = bits * p;
         const int src = p & 1, dst = src ^ 1;
-        {
-            ScopedTimer tm(T_SORT_HIST, st);
-            hipLaunchKernelGGL(sort_hist_kernel<KeyT>, dim3(nblocks), dim3(256), 0, st, (const KeyT *)kb[src],
-                               count_ptr, cap, shift, cnt, nchunks);
+        int rc;
+        switch (bits) {
+        case 8: rc = radix_pass<KeyT, 8>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
+        case 9: rc = radix_pass<KeyT, 9>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
+        case 10: rc = radix_pass<KeyT, 10>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
+        default: rc = radix_pass<KeyT, 11>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
         }
-        SLS_LAUNCH_CHECK("sort_hist_kernel");
-        {
-            ScopedTimer tm(T_SORT_ROWSCAN, st);
-            hipLaunchKernelGGL(sort_rowscan_kernel, dim3(256), dim3(256), 0, st, cnt, count_ptr, cap, nchunks, totals);
-        }
-        SLS_LAUNCH_CHECK("sort_rowscan_kernel");
-        {
-            ScopedTimer tm(T_SORT_SCATTER, st);
-            hipLaunchKernelGGL(sort_scatter_kernel<KeyT>, dim3(nblocks), dim3(256), 0, st, (const KeyT *)kb[src],
-                               (const uint32_t *)vb[src], kb[dst], vb[dst], count_ptr, cap, shift,
-                               (const uint32_t *)cnt, (const uint32_t *)totals, nchunks);
-        }
-        SLS_LAUNCH_CHECK("sort_scatter_kernel");
+        if (rc) return rc;
     }
     *result_in_tmp = npasses & 1;
     return SLS_OK;
@@ -262,7 +300,7 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__r
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) *n_dev = (uint32_t)N;
     if (i >= N) return;
-    keys[i] = tiles[i] ? __float_as_uint(depth[i]) : 0xFFFFFFFFu;
+    keys[i] = depth_order_key(depth[i], tiles[i] != 0);
     vals[i] = (uint32_t)i;
 }
 
@@ -353,19 +391,23 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
     const uint32_t t = tiles[g];
     if (!t) return;
     const uint32_t end = offsets[i];
-    if (end > cap) {
-        if (overflow) *overflow = 1u;
-        return;
-    }
     uint32_t off = end - t;
+    if (end > cap) {
+        // The buffers are too small: flag it (the caller repeats the iteration with more room) but
+        // still fill every slot below cap, so that nothing downstream reads an uninitialised entry.
+        if (overflow) *overflow = 1u;
+        if (off >= cap) return;
+    }
     const int4 rc = rect[g];
     for (int y = 0; y < rc.w; ++y) {
         const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
         for (int k = 0; k < rc.y; ++k) {
             int tx = rc.x + k;
             if (tx >= GX) tx -= GX;
-            tkeys[off] = row + (uint32_t)tx;
-            vals[off] = g;
+            if (off < cap) {
+                tkeys[off] = row + (uint32_t)tx;
+                vals[off] = g;
+            }
             ++off;
         }
     }
@@ -412,10 +454,14 @@ size_t order_scratch_bytes(int N)
 }
 
 // where preprocess may write the sort input directly (saves the depth_keys launch)
-void depth_order_key_buffers(int N, void *scratch, uint32_t **keys, uint32_t **n_dev)
+void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
+                             uint32_t **n_dev)
 {
     const int nb = (N + 255) / 256;
     *keys = (uint32_t *)scratch;
+    // with an odd number of passes the sorted values land in the "other" buffer, so the
+    // identity permutation starts in the scratch buffer and the result ends in `order`
+    *vals0 = (sort_passes(kDepthKeyBits) & 1) ? *keys + 2 * (size_t)N : order;
     *n_dev = *keys + 3 * (size_t)N + nb;
 }
 
@@ -435,17 +481,19 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     uint32_t *n_dev = block_sums + nb;          // device copy of N for the count_ptr protocol
     void *sort_scratch = (void *)(n_dev + 32);
     const size_t sort_bytes = sort_scratch_bytes((uint64_t)N);
+    const bool odd = (sort_passes(kDepthKeyBits) & 1) != 0;
+    uint32_t *v0 = odd ? vals_tmp : order, *v1 = odd ? order : vals_tmp;
     if (!keys_prefilled) {
         ScopedTimer tm(T_EMIT_KEYS, st);
-        hipLaunchKernelGGL(depth_keys_kernel, dim3(nb), dim3(256), 0, st, N, depth, tiles, keys, order, n_dev);
+        hipLaunchKernelGGL(depth_keys_kernel, dim3(nb), dim3(256), 0, st, N, depth, tiles, keys, v0, n_dev);
         SLS_LAUNCH_CHECK("depth_keys_kernel");
     }
     int which = 0;
-    int rc = radix_sort_pairs_t<uint32_t>(keys, order, keys_tmp, vals_tmp, n_dev, (uint32_t)N, 32, sort_scratch,
+    int rc = radix_sort_pairs_t<uint32_t>(keys, v0, keys_tmp, v1, n_dev, (uint32_t)N, kDepthKeyBits, sort_scratch,
                                           sort_bytes, &which, st);
     if (rc) return rc;
-    if (which != 0) {   // 4 passes: the result is back in (keys, order)
-        set_error("internal: depth order ended in the temporary buffer");
+    if ((which != 0) != odd) {
+        set_error("internal: depth order ended in the wrong buffer");
         return SLS_E_ARG;
     }
     ScopedTimer tm(T_SCAN, st);
