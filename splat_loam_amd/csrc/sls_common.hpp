@@ -117,31 +117,42 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 }
 
 // Reduce-scatter of 16 per-lane values over the wave: returns, in EVERY lane l,
-// the wave-wide sum of component reduce16_component(l).  Each step halves the
-// number of live values by exchanging one half with a partner lane (DPP
-// quad_perm / row_half_mirror / row_mirror — all involutions), so the whole
-// 16 x 64 reduction costs ~70 instructions instead of 16 full wave sums.
-// The selection bits are chosen so partners always hold the same subset.
-__device__ __forceinline__ int reduce16_component(int lane)
-{
-    const int s0 = (lane ^ (lane >> 2)) & 1, s1 = ((lane >> 1) ^ (lane >> 2)) & 1;
-    const int s2 = ((lane >> 2) ^ (lane >> 3)) & 1, s3 = (lane >> 3) & 1;
-    return 8 * s0 + 4 * s1 + 2 * s2 + s3;
-}
+// the wave-wide sum of component reduce16_component(l) = l >> 2.  Each level
+// halves the number of live values by exchanging one half with a partner lane:
+//   lanes l / l^32 and rows r / r^1 with the gfx950 v_permlane32_swap /
+//   v_permlane16_swap (one swap serves two values, no selects), then row_mirror
+//   and row_half_mirror DPP inside a row, then a quad all-reduce.
+// 35 VALU instructions for the whole 16 x 64 reduction.
+__device__ __forceinline__ int reduce16_component(int lane) { return lane >> 2; }
+
+// a <- [a.lo | b.lo], b <- [a.hi | b.hi] (halves of 32 lanes) for four / two register pairs.
+// The leading s_nop covers the VALU-write -> permlane-swap-read hazard (inline asm is opaque
+// to the compiler's hazard recogniser).
+#define SLS_SWAP4(op, a0, b0, a1, b1, a2, b2, a3, b3)                                              \
+    asm volatile("s_nop 1\n\t" op " %0, %1\n\t" op " %2, %3\n\t" op " %4, %5\n\t" op " %6, %7"      \
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
 __device__ __forceinline__ float wave_reduce16(const float (&x)[16], int lane)
 {
-    const bool s0 = ((lane ^ (lane >> 2)) & 1) != 0, s1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
-    const bool s2 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0, s3 = ((lane >> 3) & 1) != 0;
-    float y[8], z[4], w[2];
+    float a[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = (s0 ? x[i + 8] : x[i]) + dpp_mov0<0xB1, 0xF>(s0 ? x[i] : x[i + 8]);
+    for (int i = 0; i < 16; ++i) a[i] = x[i];
+    // lanes < 32 keep components 0..7, lanes >= 32 components 8..15
+    SLS_SWAP4("v_permlane32_swap_b32", a[0], a[8], a[1], a[9], a[2], a[10], a[3], a[11]);
+    SLS_SWAP4("v_permlane32_swap_b32", a[4], a[12], a[5], a[13], a[6], a[14], a[7], a[15]);
+    float y[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) z[i] = (s1 ? y[i + 4] : y[i]) + dpp_mov0<0x4E, 0xF>(s1 ? y[i] : y[i + 4]);
+    for (int i = 0; i < 8; ++i) y[i] = a[i] + a[i + 8];
+    // even rows keep y[0..3], odd rows y[4..7]
+    SLS_SWAP4("v_permlane16_swap_b32", y[0], y[4], y[1], y[5], y[2], y[6], y[3], y[7]);
+    float z[4], w[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) w[i] = (s2 ? z[i + 2] : z[i]) + dpp_mov0<0x141, 0xF>(s2 ? z[i] : z[i + 2]);
-    float v = (s3 ? w[1] : w[0]) + dpp_mov0<0x140, 0xF>(s3 ? w[0] : w[1]);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    for (int i = 0; i < 4; ++i) z[i] = y[i] + y[i + 4];
+    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w[i] = (s3 ? z[i + 2] : z[i]) + dpp_mov0<0x140, 0xF>(s3 ? z[i] : z[i + 2]);   // row_mirror
+    float v = (s2 ? w[1] : w[0]) + dpp_mov0<0x141, 0xF>(s2 ? w[0] : w[1]);                                    // row_half_mirror
+    v += dpp_mov0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
     return v;
 }
 

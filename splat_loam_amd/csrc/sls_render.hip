@@ -241,18 +241,26 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kSubPerTile = kTilePix / 64;
 
+// Workgroup -> (tile, sub-tile).  The dispatcher places block b on XCD b % 8.  All sub-tiles
+// of a tile stay on one XCD (they share the tile's list and records through its L2), and
+// each XCD gets runs of 4 neighbouring tiles taken round-robin from the WHOLE image, so that
+// the expensive image rows (long lists) are spread over all XCDs instead of filling one.
+template <int PER_TILE>
+__device__ __forceinline__ void tile_of_block(int b, int T, int &tile, int &sub)
+{
+    if (T % 32 == 0) {
+        const int xcd = b % 8, i = b / 8;
+        const int ts = i / PER_TILE;                 // tile slot inside this XCD
+        tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        sub = i % PER_TILE;
+    } else {
+        tile = b / PER_TILE;
+        sub = b % PER_TILE;
+    }
+}
 __device__ __forceinline__ void wave_tile_of_block(int b, int T, int &tile, int &sub)
 {
-    // XCD-aware: block b runs on XCD b % 8; give each XCD a contiguous run of tiles and
-    // keep the sub-tiles of a tile on one XCD (they share the tile's list and records)
-    if (T % 8 == 0) {
-        const int xcd = b % 8, i = b / 8;
-        tile = xcd * (T / 8) + i / kSubPerTile;
-        sub = i % kSubPerTile;
-    } else {
-        tile = b / kSubPerTile;
-        sub = b % kSubPerTile;
-    }
+    tile_of_block<kSubPerTile>(b, T, tile, sub);
 }
 
 #define SLS_WIDX1(i_, first, r_, limit) vals[(first) + (uint32_t)min((r_) * 64 + ((i_) * 64 + lane) / kRec4, (limit) - 1)]
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(
     bool done = !inside;
     bool wave_done = __all(done);
 
+    uint32_t st_staged = 0, st_pass = 0, st_contrib = 0, st_lanes = 0;   // diagnostics only
     const int nr = (n + 63) / 64;
     SLS_STAGE_DECL
     if (nr > 0 && !wave_done) {
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(
         bool pass = false;
         if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
         uint64_t mask = __ballot(pass);
+        if (dbg_cycles) { st_staged += (uint32_t)cnt; st_pass += (uint32_t)__builtin_popcountll(mask); }
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -330,10 +340,16 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(
             const float4 q3 = s_rec[j * kRec4 + 3], q4 = s_rec[j * kRec4 + 4];
             Eval e;
             eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
-            const float testT = Tr * (1.0f - e.alpha);
             const bool live = !done && !e.skip;
+            if (!__ballot(live)) continue;          // inside the support box but below 1/255 everywhere
+            const float testT = Tr * (1.0f - e.alpha);
             const bool term = live && (testT < SLS_T_MIN);
             const bool upd = live && !term;
+            if (dbg_cycles) {
+                const uint64_t um = __ballot(upd);
+                st_contrib += um ? 1u : 0u;
+                st_lanes += (uint32_t)__builtin_popcountll(um);
+            }
             const float w = upd ? e.alpha * Tr : 0.0f;
             const float dep = upd ? e.depth : 1.0f;
             const float A = 1.0f - Tr;
@@ -373,7 +389,12 @@ __global__ __launch_bounds__(64) void render_fwd_wave_kernel(
         for (int off = 32; off > 0; off >>= 1) c = max(c, (uint32_t)__shfl_down(c, off, 64));
         if (lane == 0) atomicMax(&tile_consumed[tile], c);
     }
-    if (dbg_cycles && lane == 0) dbg_cycles[tile * kSubPerTile + sub] = (uint32_t)(clock64() - t_start);
+    if (dbg_cycles && lane == 0) {
+        dbg_cycles[tile * kSubPerTile + sub] = (uint32_t)(clock64() - t_start);
+        uint32_t *st = dbg_cycles + (size_t)T * kSubPerTile;   // 4 counters after the per-wave cycles
+        atomicAdd(&st[0], st_staged); atomicAdd(&st[1], st_pass);
+        atomicAdd(&st[2], st_contrib); atomicAdd(&st[3], st_lanes);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(kThreads) void render_bwd_kernel(
                 gl[14] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dx : 0.0f;
                 gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
                 const float tot = wave_reduce16(gl, lane);
-                if (lane < 16 && tot != 0.0f) atomicAdd(&s_grad[j * kGrec + my_comp], tot);
+                if ((lane & 3) == 0 && tot != 0.0f) atomicAdd(&s_grad[j * kGrec + my_comp], tot);
             }
         }
         __syncthreads();
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(64) void render_bwd_wave_kernel(
                 gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
                 const float tot = wave_reduce16(gl, lane);
                 const uint32_t gidx = (uint32_t)__builtin_amdgcn_readlane((int)my_idx, j);
-                if (lane < 16 && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + my_comp], tot);
+                if ((lane & 3) == 0 && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + my_comp], tot);
             }
         }
     }

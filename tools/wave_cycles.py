@@ -12,19 +12,23 @@ view, proj = synth.camera_matrices(sc["K"])
 s = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=dev), torch.tensor(proj, device=dev))
 t = {k: torch.tensor(sc[k], device=dev) for k in ("means", "scales", "rots", "opac")}
 tw, th = _abi.tile_size(); T = (W // tw) * (H // th); wpt = tw * th // 64
-f = torch.zeros(T * wpt, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
+f = torch.zeros(T * wpt + 4, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
 _abi.lib().sls_debug_wave_cycles(f.data_ptr(), b.data_ptr())
-for _ in range(2):
+for it in range(2):
+    f[-4:] = 0
     st = rasterize_forward(s, t["means"], t["opac"], t["scales"], t["rots"])
     rasterize_backward(st, t["means"], t["scales"], t["rots"], torch.randn(7, H, W, device=dev))
 torch.cuda.synchronize()
 _abi.lib().sls_debug_wave_cycles(None, None)
 cons = st.tile_consumed.cpu().numpy().view(np.uint32)
 for name, a in (("fwd", f), ("bwd", b)):
-    c = a.cpu().numpy().astype(np.int64).reshape(T, wpt)
+    c = a.cpu().numpy().astype(np.int64)[:T * wpt].reshape(T, wpt)
     tile = c.max(1)
     print(name, "wave cycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max()))
     print(name, "per tile-row max:", tile.reshape(H // th, W // tw).max(1), "mean:", tile.reshape(H // th, W // tw).mean(1).astype(int))
     k = np.argsort(tile)[-5:]
     print(name, "slowest tiles", k, "cycles", tile[k], "consumed", cons[k])
 print("consumed mean", cons.mean(), "max", cons.max(), "sum", cons.sum())
+st = f.cpu().numpy()[-4:].astype(np.int64)
+print("fwd waves: staged %d, passed the box cull %d (%.1f%%), with >=1 contributing pixel %d (%.1f%% of passed), "
+      "contributing lanes per evaluated surfel %.1f" % (st[0], st[1], 100.0 * st[1] / st[0], st[2], 100.0 * st[2] / st[1], st[3] / st[1]))
