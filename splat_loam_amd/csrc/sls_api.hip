@@ -150,6 +150,10 @@ __global__ void selftest_kernel(int *out)
     uint32_t seen = 0;
     for (int l = 0; l < 64; l += 4) seen |= 1u << reduce16_component(l);
     if (seen != 0xFFFFu) bad |= 64;
+    // block variant: lane (pixel p, slot s) gets component p summed over the 16 lanes of slot s
+    const float b16 = block_reduce16(x, lane);
+    if (b16 != (float)(124 + 4 * (lane & 3)) * (float)((lane >> 2) + 1)) bad |= 256;
+    if (dpp_xor4((float)lane) != (float)(lane ^ 4)) bad |= 512;
     int xa, xb, ya, yb;
     const uint64_t mm = __ballot(lane == 10 || lane == 29 || lane == 52);   // (2,1) (5,3) (4,6)
     if (!mask_bbox8x8(mm, xa, xb, ya, yb) || xa != 2 || xb != 5 || ya != 1 || yb != 6) bad |= 128;

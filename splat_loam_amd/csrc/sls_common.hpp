@@ -156,6 +156,37 @@ __device__ __forceinline__ float wave_reduce16(const float (&x)[16], int lane)
     return v;
 }
 
+// lane <- lane ^ 4 inside a row (two bank-masked DPP moves).
+__device__ __forceinline__ float dpp_xor4(float v)
+{
+    int a = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);   // row_shl:4 -> banks 0,2
+    a = __builtin_amdgcn_update_dpp(a, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);       // row_shr:4 -> banks 1,3
+    return __builtin_bit_cast(float, a);
+}
+
+// Block variant (lane = 4 * pixel + slot): reduce-scatter of 16 per-lane values over the 16
+// PIXELS of each slot.  Lane (pixel p, slot s) receives the sum over the 16 lanes of slot s of
+// component p.  Levels: lane^32 and lane^16 with permlane swaps, lane^8 (row_ror:8), lane^4.
+__device__ __forceinline__ float block_reduce16(const float (&x)[16], int lane)
+{
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = x[i];
+    SLS_SWAP4("v_permlane32_swap_b32", a[0], a[8], a[1], a[9], a[2], a[10], a[3], a[11]);
+    SLS_SWAP4("v_permlane32_swap_b32", a[4], a[12], a[5], a[13], a[6], a[14], a[7], a[15]);
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = a[i] + a[i + 8];
+    SLS_SWAP4("v_permlane16_swap_b32", y[0], y[4], y[1], y[5], y[2], y[6], y[3], y[7]);
+    float z[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = y[i] + y[i + 4];
+    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w[i] = (s3 ? z[i + 2] : z[i]) + dpp_mov0<0x128, 0xF>(s3 ? z[i] : z[i + 2]);   // row_ror:8
+    return (s2 ? w[1] : w[0]) + dpp_xor4(s2 ? w[0] : w[1]);
+}
+
 // Bounding box (in lane coordinates of an 8x8 sub-tile, lane = y*8 + x) of the
 // lanes set in `m`; all scalar work.  Empty mask -> returns false.
 __device__ __forceinline__ bool mask_bbox8x8(uint64_t m, int &xmin, int &xmax, int &ymin, int &ymax)

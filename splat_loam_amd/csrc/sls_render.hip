@@ -22,7 +22,7 @@
 //     across waves with LDS float atomics (16 lanes, 16 distinct addresses) and
 //     flushed with one global float atomic per touched (tile, surfel, field).
 // No MFMA: there is no dense contraction here (BASELINE.json north_star).
-#include "sls_common.hpp"
+#include "sls_tile.hpp"
 
 namespace sls {
 
@@ -31,68 +31,9 @@ constexpr int kBatch = kThreads;            // records staged per batch (one ind
 constexpr int kRounds = kBatch / 64;
 constexpr int kSubX = kTileW / 8;           // wave sub-tiles per tile row
 
-struct Eval {
-    float dl0, dl1, dl2, rinv, hu, hv, u, v, t, dx, dy, depth, G, og, alpha;
-    bool use3d, skip;
-};
-
-// One (pixel, surfel) evaluation; identical in forward and backward.
-__device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
-                                            const float4 q4, float d0, float d1, float d2, float pc, float pr,
-                                            float wrapW, float invW, float near_c, Eval &e)
-{
-    e.dl0 = d0 - q3.x; e.dl1 = d1 - q3.y; e.dl2 = d2 - q3.z;
-    const float nd = q2.x * d0 + q2.y * d1 + q2.z * d2;
-    const bool valid3d = nd < 0.0f;
-    e.rinv = __builtin_amdgcn_rcpf(nd);
-    e.hu = q0.x * e.dl0 + q0.y * e.dl1 + q0.z * e.dl2;
-    e.hv = q1.x * e.dl0 + q1.y * e.dl1 + q1.z * e.dl2;
-    e.u = e.hu * e.rinv;
-    e.v = e.hv * e.rinv;
-    e.t = q0.w * e.rinv;
-    const float rho3 = e.u * e.u + e.v * e.v;
-    // D5 wrapped azimuth difference, branch-free: wrapW = W (360-degree image) or 0
-    const float dx0 = pc - q4.x;
-    e.dx = dx0 - wrapW * __builtin_rintf(dx0 * invW);
-    e.dy = pr - q4.y;
-    const float rho2 = SLS_FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
-    e.use3d = valid3d && (rho3 <= rho2);
-    const float rho = e.use3d ? rho3 : rho2;
-    e.depth = e.use3d ? e.t : q1.w;
-    e.G = __expf(-0.5f * rho);
-    e.og = q2.w * e.G;
-    e.alpha = fminf(SLS_ALPHA_MAX, e.og);
-    e.skip = (e.depth < near_c) || (e.alpha < SLS_ALPHA_MIN);
-}
-
-// Conservative test: can the surfel (centre q4.xy, support half-extents q4.zw)
-// reach a pixel of the box centred (bcx, bcy) with half-extents (bhx, bhy)?
-__device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy, float bhx, float bhy,
-                                          float wrapW, float invW)
-{
-    const float dx0 = bcx - q4.x;
-    const float dxc = dx0 - wrapW * __builtin_rintf(dx0 * invW);
-    return (fabsf(dxc) <= q4.z + bhx) && (fabsf(bcy - q4.y) <= q4.w + bhy);
-}
-
-// Box of the active lanes of an 8x8 sub-tile at (x0, y0); false if none.
-__device__ __forceinline__ bool active_box(uint64_t m, int x0, int y0, float &bcx, float &bcy, float &bhx,
-                                           float &bhy)
-{
-    int xa, xb, ya, yb;
-    if (!mask_bbox8x8(m, xa, xb, ya, yb)) return false;
-    bcx = (float)x0 + 0.5f * (float)(xa + xb);
-    bhx = 0.5f * (float)(xb - xa);
-    bcy = (float)y0 + 0.5f * (float)(ya + yb);
-    bhy = 0.5f * (float)(yb - ya);
-    return true;
-}
-
 // Two-deep staging pipeline shared by both kernels (macros so that the small
 // arrays stay in registers).  `first` is the list offset of the tile, `limit`
 // the number of usable entries (>= 1 whenever used).
-static_assert(kRec4 == 5, "staging macros are written out for 5 float4 per record");
-#define SLS_STAGE_DECL float4 sp0, sp1, sp2, sp3, sp4; uint32_t si0, si1, si2, si3, si4;
 #define SLS_IDX1(i_, first, b, limit) vals[(first) + (uint32_t)min((b) * kBatch + ((i_) * kThreads + tid) / kRec4, (limit) - 1)]
 #define SLS_STAGE_LOAD_IDX(first, b, limit)                                                    \
     si0 = SLS_IDX1(0, first, b, limit); si1 = SLS_IDX1(1, first, b, limit);                     \
@@ -241,40 +182,10 @@ __global__ __launch_bounds__(kThreads) void render_fwd_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kSubPerTile = kTilePix / 64;
 
-// Workgroup -> (tile, sub-tile).  The dispatcher places block b on XCD b % 8.  All sub-tiles
-// of a tile stay on one XCD (they share the tile's list and records through its L2), and
-// each XCD gets runs of 4 neighbouring tiles taken round-robin from the WHOLE image, so that
-// the expensive image rows (long lists) are spread over all XCDs instead of filling one.
-template <int PER_TILE>
-__device__ __forceinline__ void tile_of_block(int b, int T, int &tile, int &sub)
-{
-    if (T % 32 == 0) {
-        const int xcd = b % 8, i = b / 8;
-        const int ts = i / PER_TILE;                 // tile slot inside this XCD
-        tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
-        sub = i % PER_TILE;
-    } else {
-        tile = b / PER_TILE;
-        sub = b % PER_TILE;
-    }
-}
 __device__ __forceinline__ void wave_tile_of_block(int b, int T, int &tile, int &sub)
 {
     tile_of_block<kSubPerTile>(b, T, tile, sub);
 }
-
-#define SLS_WIDX1(i_, first, r_, limit) vals[(first) + (uint32_t)min((r_) * 64 + ((i_) * 64 + lane) / kRec4, (limit) - 1)]
-#define SLS_WSTAGE_LOAD_IDX(first, r_, limit)                                                  \
-    si0 = SLS_WIDX1(0, first, r_, limit); si1 = SLS_WIDX1(1, first, r_, limit);                 \
-    si2 = SLS_WIDX1(2, first, r_, limit); si3 = SLS_WIDX1(3, first, r_, limit);                 \
-    si4 = SLS_WIDX1(4, first, r_, limit);
-#define SLS_WREC1(i_, idx_) rec[(size_t)(idx_) * kRec4 + (((i_) * 64 + lane) % kRec4)]
-#define SLS_WSTAGE_LOAD_REC()                                                                  \
-    sp0 = SLS_WREC1(0, si0); sp1 = SLS_WREC1(1, si1); sp2 = SLS_WREC1(2, si2);                  \
-    sp3 = SLS_WREC1(3, si3); sp4 = SLS_WREC1(4, si4);
-#define SLS_WSTAGE_STORE()                                                                     \
-    s_rec[0 * 64 + lane] = sp0; s_rec[1 * 64 + lane] = sp1; s_rec[2 * 64 + lane] = sp2;         \
-    s_rec[3 * 64 + lane] = sp3; s_rec[4 * 64 + lane] = sp4;
 
 __global__ __launch_bounds__(64) void render_fwd_wave_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
@@ -687,8 +598,16 @@ __global__ __launch_bounds__(64) void render_bwd_wave_kernel(
     if (dbg_cycles && lane == 0) dbg_cycles[tile * kSubPerTile + sub] = (uint32_t)(clock64() - t_start);
 }
 
-// kernel variants (sls_debug_variant): 0 = one workgroup per tile, 1 = one wave per sub-tile
-int g_fwd_variant = 1, g_bwd_variant = 1;
+// kernel variants (sls_debug_variant): 0 = one workgroup per tile, 1 = one wave per 8x8 sub-tile,
+// 2 / 3 = one wave per 4x4 / 8x2 pixel block x 4 surfel slots (sls_render_block.hip)
+int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
+                            const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
+                            uint32_t *pix_contrib, uint32_t *tile_consumed, int shape, hipStream_t st);
+int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
+                            const float *col_cs, const float *row_cs, const float *pix_state,
+                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, int shape,
+                            hipStream_t st);
+int g_fwd_variant = 3, g_bwd_variant = 3;
 // unused dynamic LDS requested at launch (caps the workgroups resident per CU)
 int g_pad_lds_fwd = 0, g_pad_lds_bwd = 0;
 
@@ -701,6 +620,9 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
+    if (g_fwd_variant >= 2)
+        return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
+                                       tile_consumed, g_fwd_variant - 2, st);
     if (g_fwd_variant == 1) {
         if (tile_consumed) SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
         ScopedTimer tm(T_RENDER_FWD, st);
@@ -723,6 +645,9 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
+    if (g_bwd_variant >= 2)
+        return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
+                                       grec, g_bwd_variant - 2, st);
     ScopedTimer tm(T_RENDER_BWD, st);
     if (g_bwd_variant == 1) {
         hipLaunchKernelGGL(render_bwd_wave_kernel, dim3(T * kSubPerTile), dim3(64), g_pad_lds_bwd, st, cam,

@@ -1,0 +1,424 @@
+// sls_render_block.hip — tile kernels, "pixel block x surfel slot" variant.
+// SURVEY.md §8a rows A6/A7; maths in DESIGN.md §2; same inputs, outputs and
+// per-pixel state as the kernels of sls_render.hip (the variants are
+// interchangeable: forward of one, backward of the other).
+//
+// Why: with one pixel per lane a wave evaluates ONE surfel per ~110-instruction
+// step and the kernel time is the serial instruction stream of the longest
+// wave (2048 waves for 1024 SIMDs, nothing to backfill).  Here a wave owns a
+// BW x BH = 16 pixel block and evaluates FOUR consecutive list entries per
+// step: lane = 4 * pixel + slot.  The front-to-back dependence between the four
+// slots of a pixel is resolved inside the quad with DPP (exclusive transmittance
+// product, exclusive sums of the distortion moments, first-terminating-slot
+// mask), which costs ~35 instructions per step, so
+//   * the serial chain per wave is ~4x shorter and there are 4x more waves
+//     (8 per SIMD): the SIMDs stay busy and the image rows balance;
+//   * the support-box cull works on 4x4 pixels instead of 8x8, so far fewer
+//     lanes evaluate a surfel that cannot touch them;
+//   * backward: the 16 gradient fields are reduced over the 16 pixels of a slot
+//     with ONE reduce-scatter per step (4 surfels) instead of one per surfel,
+//     and one 64-lane float atomic instruction flushes 4 surfels x 16 fields.
+// Survivors of the cull are compacted into a wave-private LDS list (ballot +
+// mbcnt), a step takes the next four.
+#include "sls_tile.hpp"
+
+namespace sls {
+
+extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
+
+template <int CTRL>
+__device__ __forceinline__ float dppq(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppq_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kQuadShr1 = 0x90;   // quad_perm [0,0,1,2]: slot s reads slot s-1 (slot 0 itself)
+constexpr int kQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += dppq<kQuadXor1>(v);
+    v += dppq<kQuadXor2>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t quad_max(uint32_t v)
+{
+    v = max(v, dppq_u<kQuadXor1>(v));
+    v = max(v, dppq_u<kQuadXor2>(v));
+    return v;
+}
+// Exclusive prefix over the 4 slots of a quad (k1,k2,k3 = 1.0f where slot >= 1,2,3 else 0)
+// and the quad total, summed in slot order.
+__device__ __forceinline__ void quad_excl_total(float x, float k1, float k2, float k3, float &excl, float &total)
+{
+    excl = k1 * dppq<0x00>(x);
+    excl = fmaf(k2, dppq<0x55>(x), excl);
+    excl = fmaf(k3, dppq<0xAA>(x), excl);
+    total = dppq<0xFF>(excl + x);
+}
+
+// Box (pixel coordinates, centre + half extents) of the pixels whose slot-0 lane
+// is set in `m`, for a BW-wide block at (x0, y0); all scalar work.
+template <int BW, int BH>
+__device__ __forceinline__ bool block_active_box(uint64_t m, int x0, int y0, float &bcx, float &bcy, float &bhx,
+                                                 float &bhy)
+{
+    m &= 0x1111111111111111ull;
+    if (m == 0) return false;
+    constexpr int kRowBits = 4 * BW;
+    uint64_t c = m;
+#pragma unroll
+    for (int r = 1; r < BH; ++r) c |= m >> (kRowBits * r);
+    const uint32_t cols = (uint32_t)(c & ((kRowBits == 32) ? 0xFFFFFFFFull : ((1ull << (kRowBits & 31)) - 1ull)));
+    const int xa = __builtin_ctz(cols) >> 2, xb = (31 - __builtin_clz(cols)) >> 2;
+    const int ya = __builtin_ctzll(m) / kRowBits, yb = (63 - __builtin_clzll(m)) / kRowBits;
+    bcx = (float)x0 + 0.5f * (float)(xa + xb);
+    bhx = 0.5f * (float)(xb - xa);
+    bcy = (float)y0 + 0.5f * (float)(ya + yb);
+    bhy = 0.5f * (float)(yb - ya);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// A6 forward
+// ---------------------------------------------------------------------------
+template <int BW, int BH, bool DBG>
+__global__ __launch_bounds__(64) void render_fwd_block_kernel(
+    DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
+    const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
+    float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
+    uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles)
+{
+    static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
+    constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
+    __shared__ float4 s_rec[64 * kRec4];
+    __shared__ uint32_t s_list[64];
+    const uint64_t t_start = DBG ? clock64() : 0;
+    const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
+    const int T = cam.GX * cam.GY;
+    int tile, sub;
+    tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
+    const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
+    const int px = x0 + (p % BW), py = y0 + (p / BW);
+    const bool inside = (px < cam.W) && (py < cam.H);
+    const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
+
+    float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
+    if (inside) {
+        const float2 c = col_cs[px], r = row_cs[py];
+        d0 = c.x * r.x; d1 = c.y * r.x; d2 = r.y;
+    }
+    const float pc = (float)px, pr = (float)py;
+    const float mscale = cam.far_c / (cam.far_c - cam.near_c);
+    const float k1 = slot >= 1 ? 1.0f : 0.0f, k2 = slot >= 2 ? 1.0f : 0.0f, k3 = slot >= 3 ? 1.0f : 0.0f;
+    const uint32_t below = (1u << slot) - 1u, upto = (2u << slot) - 1u;   // quad bits of the earlier slots (and self)
+
+    // replicated over the quad: Tr, M1, M2, done.  Per-lane partial sums: D, N*, dist.
+    float Tr = 1.0f, M1 = 0.0f, M2 = 0.0f;
+    float D = 0.0f, N0 = 0.0f, N1 = 0.0f, N2 = 0.0f, dist = 0.0f, med = 0.0f;
+    uint32_t medc = 0, last = 0, cons = 0;
+    bool done = !inside;
+    bool wave_done = __all(done);
+    uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0;   // diagnostics only
+
+    const int nr = (n + 63) / 64;
+    SLS_STAGE_DECL
+    if (nr > 0 && !wave_done) {
+        SLS_WSTAGE_LOAD_IDX(range.x, 0, n)
+        SLS_WSTAGE_LOAD_REC()
+        if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, 1, n) }
+    }
+    for (int r = 0; r < nr && !wave_done; ++r) {
+        float bcx, bcy, bhx, bhy;
+        if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        // single wave: LDS operations complete in program order, no barrier needed
+        SLS_WSTAGE_STORE()
+        if (r + 1 < nr) {
+            SLS_WSTAGE_LOAD_REC()
+            if (r + 2 < nr) { SLS_WSTAGE_LOAD_IDX(range.x, r + 2, n) }
+        }
+        const int cnt = min(64, n - r * 64);
+        __builtin_amdgcn_wave_barrier();
+        bool pass = false;
+        if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+        const uint64_t mask = __ballot(pass);
+        const int npass = __builtin_popcountll(mask);
+        if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        if (DBG) { st_staged += (uint32_t)cnt; st_pass += (uint32_t)npass; }
+        for (int k = 0; k < npass; k += 4) {
+            const bool valid = (k + slot) < npass;
+            const int j = (int)s_list[min(k + slot, npass - 1)];
+            const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
+            const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
+            const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
+            Eval e;
+            eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
+            const bool live = valid && !done && !e.skip;
+            if (DBG) { st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(__ballot(live)); }
+            if (!__ballot(live)) continue;
+            // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k
+            const float f = live ? 1.0f - e.alpha : 1.0f;
+            // (the DPP moves must execute in all lanes: never inside a conditional expression)
+            float E = Tr, I = Tr * f, sh;
+            sh = dppq<kQuadShr1>(I); E = slot >= 1 ? sh : E; I = E * f;
+            sh = dppq<kQuadShr1>(I); E = slot >= 2 ? sh : E; I = E * f;
+            sh = dppq<kQuadShr1>(I); E = slot >= 3 ? sh : E; I = E * f;
+            const bool term = live && (I < SLS_T_MIN);
+            const uint32_t nib = (uint32_t)(__ballot(term) >> (lane & 60)) & 15u;   // terminating slots of my pixel
+            const bool first_term = term && !(nib & below);
+            const bool upd = live && !(nib & upto);
+            const float w = upd ? e.alpha * E : 0.0f;
+            const float dep = upd ? e.depth : 1.0f;
+            const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
+            const float mw = m * w, mmw = m * mw;
+            float e1, t1, e2, t2;
+            quad_excl_total(mw, k1, k2, k3, e1, t1);
+            quad_excl_total(mmw, k1, k2, k3, e2, t2);
+            const float A = 1.0f - E;
+            dist += (m * m * A + (M2 + e2) - 2.0f * m * (M1 + e1)) * w;
+            M1 += t1;
+            M2 += t2;
+            D += dep * w;
+            N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
+            const bool is_med = upd && (E > 0.5f);
+            med = is_med ? dep : med;
+            medc = is_med ? contributor : medc;
+            last = upd ? contributor : last;
+            cons = first_term ? contributor : cons;
+            // new transmittance: in front of the first terminating slot, else behind slot 3
+            const float cand = first_term ? E : ((slot == 3 && nib == 0u) ? I : 0.0f);
+            Tr = quad_sum(cand);
+            done = done || (nib != 0u);
+            if (__all(done)) { wave_done = true; break; }
+        }
+    }
+
+    // combine the four slots of a pixel
+    D = quad_sum(D); N0 = quad_sum(N0); N1 = quad_sum(N1); N2 = quad_sum(N2); dist = quad_sum(dist);
+    last = quad_max(last);
+    const uint32_t medc_q = quad_max(medc);
+    med = quad_sum((medc == medc_q && medc != 0u) ? med : 0.0f);
+    if (inside && slot == 0) {
+        const size_t P = (size_t)cam.H * cam.W;
+        const size_t pix = (size_t)py * cam.W + px;
+        allmap[SLS_CH_DEPTH * P + pix] = D;
+        allmap[SLS_CH_ALPHA * P + pix] = 1.0f - Tr;
+        allmap[(SLS_CH_NORMAL + 0) * P + pix] = N0;
+        allmap[(SLS_CH_NORMAL + 1) * P + pix] = N1;
+        allmap[(SLS_CH_NORMAL + 2) * P + pix] = N2;
+        allmap[SLS_CH_MEDIAN * P + pix] = med;
+        allmap[SLS_CH_DIST * P + pix] = dist;
+        pix_state[pix] = make_float4(Tr, M1, M2, 0.0f);
+        pix_contrib[pix] = make_uint2(last, medc_q);
+    }
+    if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
+        uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c = max(c, (uint32_t)__shfl_down(c, off, 64));
+        if (lane == 0) atomicMax(&tile_consumed[tile], c);
+    }
+    if (DBG && lane == 0) {
+        dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
+        uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
+        atomicAdd(&st[0], st_staged); atomicAdd(&st[1], st_pass);
+        atomicAdd(&st[2], st_steps); atomicAdd(&st[3], st_lanes);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// A7 backward.  Back to front, four list entries per step: slot 0 holds the
+// LAST entry of the four.  T_i = T_{i+1} / (1 - alpha_i) is multiplied up in
+// that order inside the quad, S (the suffix sum of w g) is an exclusive quad
+// prefix.  The 16 gradient fields are reduced over the 16 pixels of a slot with
+// block_reduce16 and flushed with one 64-lane global float atomic per step.
+// ---------------------------------------------------------------------------
+template <int BW, int BH>
+__global__ __launch_bounds__(64) void render_bwd_block_kernel(
+    DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
+    const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
+    const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
+    const float *__restrict__ dL_dallmap, float *__restrict__ grec, uint32_t *__restrict__ dbg_cycles)
+{
+    static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
+    constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
+    __shared__ float4 s_rec[64 * kRec4];
+    __shared__ uint32_t s_list[64];
+    __shared__ uint32_t s_gidx[64];
+    const uint64_t t_start = dbg_cycles ? clock64() : 0;
+    const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
+    const int T = cam.GX * cam.GY;
+    int tile, sub;
+    tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
+    const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
+    const uint2 range = ranges[tile];
+    const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
+    const int px = x0 + (p % BW), py = y0 + (p / BW);
+    const bool inside = (px < cam.W) && (py < cam.H);
+    const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
+    const float pc = (float)px, pr = (float)py;
+    const float mscale = cam.far_c / (cam.far_c - cam.near_c);
+    const float k1 = slot >= 1 ? 1.0f : 0.0f, k2 = slot >= 2 ? 1.0f : 0.0f, k3 = slot >= 3 ? 1.0f : 0.0f;
+
+    float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
+    uint32_t last = 0, medc = 0;
+    float Tf = 1.0f, M1 = 0.0f, M2 = 0.0f;
+    float dD = 0, dA = 0, dN0 = 0, dN1 = 0, dN2 = 0, dMed = 0, dDist = 0;
+    if (inside) {
+        const float2 c = col_cs[px], r = row_cs[py];
+        d0 = c.x * r.x; d1 = c.y * r.x; d2 = r.y;
+        const size_t P = (size_t)cam.H * cam.W;
+        const size_t pix = (size_t)py * cam.W + px;
+        const uint2 pcn = pix_contrib[pix];
+        last = pcn.x; medc = pcn.y;
+        const float4 ps = pix_state[pix];
+        Tf = ps.x; M1 = ps.y; M2 = ps.z;
+        dD = dL_dallmap[SLS_CH_DEPTH * P + pix];
+        dA = dL_dallmap[SLS_CH_ALPHA * P + pix];
+        dN0 = dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix];
+        dN1 = dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix];
+        dN2 = dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix];
+        dMed = dL_dallmap[SLS_CH_MEDIAN * P + pix];
+        dDist = dL_dallmap[SLS_CH_DIST * P + pix];
+    }
+    const float Af = 1.0f - Tf;
+    uint32_t wmax = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, off, 64));
+    const int tmax = (int)wmax;
+    if (tmax > 0) {
+        const int nr = (tmax + 63) / 64;
+        SLS_STAGE_DECL
+        SLS_WSTAGE_LOAD_IDX(range.x, nr - 1, tmax)
+        SLS_WSTAGE_LOAD_REC()
+        uint32_t next_idx = vals[range.x + (uint32_t)min((nr - 1) * 64 + lane, tmax - 1)];   // surfel of entry (r*64 + lane)
+        if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, nr - 2, tmax) }
+        float Tr = Tf, S = 0.0f;   // replicated over the quad
+        for (int r = nr - 1; r >= 0; --r) {
+            SLS_WSTAGE_STORE()
+            s_gidx[lane] = next_idx;
+            if (r > 0) {
+                SLS_WSTAGE_LOAD_REC()
+                next_idx = vals[range.x + (uint32_t)((r - 1) * 64 + lane)];
+                if (r > 1) { SLS_WSTAGE_LOAD_IDX(range.x, r - 2, tmax) }
+            }
+            const int cnt = min(64, tmax - r * 64);
+            const uint32_t c_lo = (uint32_t)(r * 64 + 1);
+            float bcx, bcy, bhx, bhy;
+            if (!block_active_box<BW, BH>(__ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
+            __builtin_amdgcn_wave_barrier();
+            bool pass = false;
+            if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+            const uint64_t mask = __ballot(pass);
+            const int npass = __builtin_popcountll(mask);
+            // survivors in DESCENDING list order
+            if (pass) s_list[npass - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < npass; k += 4) {
+                const bool valid = (k + slot) < npass;
+                const int j = (int)s_list[min(k + slot, npass - 1)];
+                const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
+                const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
+                const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
+                Eval e;
+                eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
+                const bool act = valid && inside && (contributor <= last) && !e.skip;
+                if (!__ballot(act)) continue;
+                const float om = act ? 1.0f - e.alpha : 1.0f;
+                const float rom = __builtin_amdgcn_rcpf(om);
+                // T in front of each entry: Ti = Tr * prod_{slots <= mine} rom, multiplied up in slot order
+                // (the DPP moves must execute in all lanes: never inside a conditional expression)
+                float Ti = Tr * rom, sh;
+                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 1 ? sh : Ti;
+                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 2 ? sh : Ti;
+                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 3 ? sh : Ti;
+                Tr = dppq<0xFF>(Ti);
+                const float w = act ? e.alpha * Ti : 0.0f;
+                const float dep = act ? e.depth : 1.0f;
+                const float rdep = __builtin_amdgcn_rcpf(dep);
+                const float m = mscale * (1.0f - cam.near_c * rdep);
+                const float dm_dd = mscale * cam.near_c * rdep * rdep;
+                const float gk = dD * dep + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA +
+                                 dDist * (M2 + m * m * Af - 2.0f * m * M1);
+                float Se, St;
+                quad_excl_total(w * gk, k1, k2, k3, Se, St);
+                const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
+                S += St;
+                float dL_ddepth = w * dD + dDist * 2.0f * w * (m * Af - M1) * dm_dd;
+                dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
+                const bool unclamped = e.og < SLS_ALPHA_MAX;
+                const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
+                const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
+                const bool a3 = act && e.use3d, a2 = act && !e.use3d;
+                const float dL_du = dL_drho * 2.0f * e.u, dL_dv = dL_drho * 2.0f * e.v;
+                const float dL_dhu = a3 ? dL_du * e.rinv : 0.0f, dL_dhv = a3 ? dL_dv * e.rinv : 0.0f;
+                const float dL_drinv = dL_du * e.hu + dL_dv * e.hv + dL_ddepth * q0.w;
+                const float dL_dnd = a3 ? -dL_drinv * e.rinv * e.rinv : 0.0f;
+                float gl[kGrec];
+                gl[0] = dL_dhu * e.dl0; gl[1] = dL_dhu * e.dl1; gl[2] = dL_dhu * e.dl2;
+                gl[3] = a3 ? dL_ddepth * e.rinv : 0.0f;
+                gl[4] = dL_dhv * e.dl0; gl[5] = dL_dhv * e.dl1; gl[6] = dL_dhv * e.dl2;
+                gl[7] = a2 ? dL_ddepth : 0.0f;
+                gl[8] = w * dN0 + dL_dnd * d0; gl[9] = w * dN1 + dL_dnd * d1; gl[10] = w * dN2 + dL_dnd * d2;
+                gl[11] = dL_do;
+                gl[12] = dL_dhu;
+                gl[13] = dL_dhv;
+                gl[14] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dx : 0.0f;
+                gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
+                const float tot = block_reduce16(gl, lane);     // field p of the surfel in my slot
+                const uint32_t gidx = s_gidx[j];
+                if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + p], tot);
+            }
+        }
+    }
+    if (dbg_cycles && lane == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
+}
+
+// ---------------------------------------------------------------------------
+int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
+                            const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
+                            uint32_t *pix_contrib, uint32_t *tile_consumed, int shape, hipStream_t st)
+{
+    const int T = cam.GX * cam.GY;
+    if (tile_consumed) SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
+    ScopedTimer tm(T_RENDER_FWD, st);
+    const dim3 grid(T * (kTilePix / 16)), block(64);
+#define SLS_FWD_BLOCK(BW_, BH_, DBG_)                                                                             \
+    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
+                       vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
+                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles)
+    if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true); else SLS_FWD_BLOCK(4, 4, true); }
+    else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false); else SLS_FWD_BLOCK(4, 4, false); }
+#undef SLS_FWD_BLOCK
+    SLS_LAUNCH_CHECK("render_fwd_block_kernel");
+    return SLS_OK;
+}
+
+int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
+                            const float *col_cs, const float *row_cs, const float *pix_state,
+                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, int shape,
+                            hipStream_t st)
+{
+    const int T = cam.GX * cam.GY;
+    ScopedTimer tm(T_RENDER_BWD, st);
+    const dim3 grid(T * (kTilePix / 16)), block(64);
+    if (shape == 1)
+        hipLaunchKernelGGL((render_bwd_block_kernel<8, 2>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
+                           (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
+                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, g_dbg_bwd_cycles);
+    else
+        hipLaunchKernelGGL((render_bwd_block_kernel<4, 4>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
+                           (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
+                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, g_dbg_bwd_cycles);
+    SLS_LAUNCH_CHECK("render_bwd_block_kernel");
+    return SLS_OK;
+}
+
+}  // namespace sls

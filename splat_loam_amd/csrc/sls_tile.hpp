@@ -1,0 +1,102 @@
+// sls_tile.hpp — device helpers shared by the tile kernels (sls_render.hip,
+// sls_render_block.hip): the (pixel, surfel) evaluation, the support-box cull
+// and the wave-private LDS staging of a tile's list.  Maths in DESIGN.md §2.
+#pragma once
+#include "sls_common.hpp"
+
+namespace sls {
+
+struct Eval {
+    float dl0, dl1, dl2, rinv, hu, hv, u, v, t, dx, dy, depth, G, og, alpha;
+    bool use3d, skip;
+};
+
+// One (pixel, surfel) evaluation; identical in forward and backward.
+__device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                            const float4 q4, float d0, float d1, float d2, float pc, float pr,
+                                            float wrapW, float invW, float near_c, Eval &e)
+{
+    e.dl0 = d0 - q3.x; e.dl1 = d1 - q3.y; e.dl2 = d2 - q3.z;
+    const float nd = q2.x * d0 + q2.y * d1 + q2.z * d2;
+    const bool valid3d = nd < 0.0f;
+    e.rinv = __builtin_amdgcn_rcpf(nd);
+    e.hu = q0.x * e.dl0 + q0.y * e.dl1 + q0.z * e.dl2;
+    e.hv = q1.x * e.dl0 + q1.y * e.dl1 + q1.z * e.dl2;
+    e.u = e.hu * e.rinv;
+    e.v = e.hv * e.rinv;
+    e.t = q0.w * e.rinv;
+    const float rho3 = e.u * e.u + e.v * e.v;
+    // D5 wrapped azimuth difference, branch-free: wrapW = W (360-degree image) or 0
+    const float dx0 = pc - q4.x;
+    e.dx = dx0 - wrapW * __builtin_rintf(dx0 * invW);
+    e.dy = pr - q4.y;
+    const float rho2 = SLS_FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
+    e.use3d = valid3d && (rho3 <= rho2);
+    const float rho = e.use3d ? rho3 : rho2;
+    e.depth = e.use3d ? e.t : q1.w;
+    e.G = __expf(-0.5f * rho);
+    e.og = q2.w * e.G;
+    e.alpha = fminf(SLS_ALPHA_MAX, e.og);
+    e.skip = (e.depth < near_c) || (e.alpha < SLS_ALPHA_MIN);
+}
+
+// Conservative test: can the surfel (centre q4.xy, support half-extents q4.zw)
+// reach a pixel of the box centred (bcx, bcy) with half-extents (bhx, bhy)?
+__device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy, float bhx, float bhy,
+                                          float wrapW, float invW)
+{
+    const float dx0 = bcx - q4.x;
+    const float dxc = dx0 - wrapW * __builtin_rintf(dx0 * invW);
+    return (fabsf(dxc) <= q4.z + bhx) && (fabsf(bcy - q4.y) <= q4.w + bhy);
+}
+
+// Box of the active lanes of an 8x8 sub-tile at (x0, y0); false if none.
+__device__ __forceinline__ bool active_box(uint64_t m, int x0, int y0, float &bcx, float &bcy, float &bhx,
+                                           float &bhy)
+{
+    int xa, xb, ya, yb;
+    if (!mask_bbox8x8(m, xa, xb, ya, yb)) return false;
+    bcx = (float)x0 + 0.5f * (float)(xa + xb);
+    bhx = 0.5f * (float)(xb - xa);
+    bcy = (float)y0 + 0.5f * (float)(ya + yb);
+    bhy = 0.5f * (float)(yb - ya);
+    return true;
+}
+
+// Workgroup -> (tile, sub-tile).  The dispatcher places block b on XCD b % 8.  All sub-tiles
+// of a tile stay on one XCD (they share the tile's list and records through its L2), and
+// each XCD gets runs of 4 neighbouring tiles taken round-robin from the WHOLE image, so that
+// the expensive image rows (long lists) are spread over all XCDs instead of filling one.
+template <int PER_TILE>
+__device__ __forceinline__ void tile_of_block(int b, int T, int &tile, int &sub)
+{
+    if (T % 32 == 0) {
+        const int xcd = b % 8, i = b / 8;
+        const int ts = i / PER_TILE;                 // tile slot inside this XCD
+        tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        sub = i % PER_TILE;
+    } else {
+        tile = b / PER_TILE;
+        sub = b % PER_TILE;
+    }
+}
+// Wave-private two-deep staging of 64 list entries per round (macros so that the
+// small arrays stay in registers): lane k of load i fetches float4 #(k mod 5) of
+// entry #(k div 5), the LDS image is written with stride-1 ds_write_b128.
+// `first` is the list offset of the tile, `limit` the number of usable entries.
+static_assert(kRec4 == 5, "staging macros are written out for 5 float4 per record");
+#define SLS_STAGE_DECL float4 sp0, sp1, sp2, sp3, sp4; uint32_t si0, si1, si2, si3, si4;
+#define SLS_WIDX1(i_, first, r_, limit) vals[(first) + (uint32_t)min((r_) * 64 + ((i_) * 64 + lane) / kRec4, (limit) - 1)]
+#define SLS_WSTAGE_LOAD_IDX(first, r_, limit)                                                  \
+    si0 = SLS_WIDX1(0, first, r_, limit); si1 = SLS_WIDX1(1, first, r_, limit);                 \
+    si2 = SLS_WIDX1(2, first, r_, limit); si3 = SLS_WIDX1(3, first, r_, limit);                 \
+    si4 = SLS_WIDX1(4, first, r_, limit);
+#define SLS_WREC1(i_, idx_) rec[(size_t)(idx_) * kRec4 + (((i_) * 64 + lane) % kRec4)]
+#define SLS_WSTAGE_LOAD_REC()                                                                  \
+    sp0 = SLS_WREC1(0, si0); sp1 = SLS_WREC1(1, si1); sp2 = SLS_WREC1(2, si2);                  \
+    sp3 = SLS_WREC1(3, si3); sp4 = SLS_WREC1(4, si4);
+#define SLS_WSTAGE_STORE()                                                                     \
+    s_rec[0 * 64 + lane] = sp0; s_rec[1 * 64 + lane] = sp1; s_rec[2 * 64 + lane] = sp2;         \
+    s_rec[3 * 64 + lane] = sp3; s_rec[4 * 64 + lane] = sp4;
+
+}  // namespace sls

@@ -420,7 +420,8 @@ def test_mapping_engine_matches_unfused_step(device):
     assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
 
 
-@pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1)], ids=["workgroup-per-tile", "wave-per-subtile"])
+@pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (3, 3)],
+                         ids=["workgroup-per-tile", "wave-per-subtile", "block4x4-fwd", "block4x4-bwd", "block4x4", "block8x2"])
 def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
     """Both implementations of the tile kernels (shared-LDS workgroup per tile /
     independent wave per 8x8 sub-tile) pass the same parity bar."""
@@ -436,7 +437,7 @@ def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, 
         _compare_forward(oracle32, st, ost, cam, f"variant{fwd_variant}")
         _compare_backward(oracle32, st, t, ost, sc, f"variant{bwd_variant}")
     finally:
-        lib.sls_debug_variant(1, 1)
+        lib.sls_debug_variant(3, 3)
 
 
 def _engine_rank(rank, world, port, out_dir):
