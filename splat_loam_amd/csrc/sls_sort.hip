@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
                                                            uint32_t *__restrict__ vals_out,
                                                            const uint32_t *__restrict__ count_ptr, uint32_t cap,
                                                            int shift, const uint32_t *__restrict__ cnt,
-                                                           const uint32_t *__restrict__ totals, int nchunks_cap)
+                                                           const uint32_t *__restrict__ totals, int nchunks_cap,
+                                                           uint2 *__restrict__ ranges_out, int nranges)
 {
     constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread
     __shared__ uint32_t s_cursor[kSortWavesPerBlock][BINS];
@@ -147,6 +148,15 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
         for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
 #pragma unroll
         for (int k = 0; k < PER; ++k) s_digit_base[threadIdx.x * PER + k] = wave_prefix + incl - v + loc[k];
+        // single-pass sort by tile id: the digit bases ARE the tile ranges (A5)
+        if (ranges_out && blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int d = threadIdx.x * PER + k;
+                const uint32_t b0 = wave_prefix + incl - v + loc[k], c = totals[d];
+                if (d < nranges) ranges_out[d] = c ? make_uint2(b0, b0 + c) : make_uint2(0u, 0u);
+            }
+        }
         __syncthreads();
     }
     const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
@@ -218,7 +228,7 @@ int sort_passes(int nbits)
 template <typename KeyT, int BITS>
 static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout, const uint32_t *count_ptr,
                       uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int nblocks,
-                      hipStream_t st)
+                      uint2 *ranges_out, int nranges, hipStream_t st)
 {
     {
         ScopedTimer tm(T_SORT_HIST, st);
@@ -234,7 +244,8 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
     {
         ScopedTimer tm(T_SORT_SCATTER, st);
         hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, vin, kout, vout,
-                           count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks);
+                           count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks, ranges_out,
+                           nranges);
     }
     SLS_LAUNCH_CHECK("sort_scatter_kernel");
     return SLS_OK;
@@ -243,11 +254,15 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
 // Stable LSD radix sort of (key, u32 value) pairs on the low `nbits` key bits.
 // Item count = min(*count_ptr, cap), read on the device.  Ping-pongs between
 // (keys, vals) and (keys_tmp, vals_tmp); *result_in_tmp says where the sorted
-// data ended up.
+// data ended up.  ranges_out (single-pass sorts only): [start, end) of every key
+// value < nranges in the sorted output ((0,0) for absent values).
+// (Counting the next pass's digits inside the scatter / the producer with global
+// atomics was measured and is slower than the histogram kernel: +35 us per pass.)
 template <typename KeyT>
 static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32_t *vals_tmp,
                               const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
-                              size_t scratch_bytes, int *result_in_tmp, hipStream_t st)
+                              size_t scratch_bytes, int *result_in_tmp, hipStream_t st,
+                              uint2 *ranges_out = nullptr, int nranges = 0)
 {
     *result_in_tmp = 0;
     if (cap == 0 || nbits <= 0) return SLS_OK;
@@ -260,6 +275,10 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
     uint32_t *cnt = (uint32_t *)scratch;
     int npasses, bits;
     sort_plan(nbits, npasses, bits);
+    if (ranges_out && npasses != 1) {
+        set_error("internal: ranges need a single-pass sort");
+        return SLS_E_ARG;
+    }
     uint32_t *totals = cnt + ((size_t)1 << bits) * nchunks;
     KeyT *kb[2] = { keys, keys_tmp };
     uint32_t *vb[2] = { vals, vals_tmp };
@@ -267,12 +286,15 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         const int shift = bits * p;
         const int src = p & 1, dst = src ^ 1;
         int rc;
+#define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
+                                        nblocks, ranges_out, nranges, st)
         switch (bits) {
-        case 8: rc = radix_pass<KeyT, 8>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
-        case 9: rc = radix_pass<KeyT, 9>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
-        case 10: rc = radix_pass<KeyT, 10>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
-        default: rc = radix_pass<KeyT, 11>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, nblocks, st); break;
+        case 8: rc = SLS_PASS(8); break;
+        case 9: rc = SLS_PASS(9); break;
+        case 10: rc = SLS_PASS(10); break;
+        default: rc = SLS_PASS(11); break;
         }
+#undef SLS_PASS
         if (rc) return rc;
     }
     *result_in_tmp = npasses & 1;
@@ -319,46 +341,24 @@ __global__ __launch_bounds__(256) void gather_block_sums_kernel(int N, const uin
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
-// level 2: one block turns block_sums[] into exclusive prefixes, publishes R
-__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t *block_sums, int nblocks, uint32_t *total_out)
-{
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? block_sums[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-        const uint32_t carry = s_carry;
-        if (i < nblocks) block_sums[i] = carry + wave_prefix + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-// level 3: inclusive scan inside each 256-surfel block (depth order) + prefix;
+// level 2: inclusive scan inside each 256-surfel block (depth order) on top of the
+// sum of the preceding blocks' totals, which every block adds up itself (a few KB
+// of L2 reads; no separate single-block scan launch).  The last block publishes R.
 // offsets[] is indexed by DEPTH-ORDER position.
 __global__ __launch_bounds__(256) void gather_scan_final_kernel(int N, const uint32_t *__restrict__ order,
                                                                 const uint32_t *__restrict__ tiles,
-                                                                const uint32_t *__restrict__ block_prefix,
-                                                                uint32_t *__restrict__ offsets)
+                                                                const uint32_t *__restrict__ block_sums,
+                                                                uint32_t *__restrict__ offsets,
+                                                                uint32_t *__restrict__ total_out)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_pre[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += block_sums[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
     const uint32_t v = (i < N) ? tiles[order[i]] : 0u;
     uint32_t incl = v;
 #pragma unroll
@@ -367,10 +367,13 @@ __global__ __launch_bounds__(256) void gather_scan_final_kernel(int N, const uin
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
+    if (lane == 0) s_pre[wave] = pre;
     __syncthreads();
     uint32_t wave_prefix = 0;
     for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-    if (i < N) offsets[i] = block_prefix[blockIdx.x] + wave_prefix + incl;
+    const uint32_t block_prefix = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+    if (i < N) offsets[i] = block_prefix + wave_prefix + incl;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = block_prefix + wave_prefix + incl;
 }
 
 // ---------------------------------------------------------------------------
@@ -500,10 +503,8 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
                        block_sums);
     SLS_LAUNCH_CHECK("gather_block_sums_kernel");
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, total_out);
-    SLS_LAUNCH_CHECK("scan_block_sums_kernel");
     hipLaunchKernelGGL(gather_scan_final_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
-                       (const uint32_t *)block_sums, offsets);
+                       (const uint32_t *)block_sums, offsets, total_out);
     SLS_LAUNCH_CHECK("gather_scan_final_kernel");
     return SLS_OK;
 }
@@ -519,28 +520,37 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     uint32_t *overflow, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
-    SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
     *sorted_in_tmp = 0;
-    if (cap == 0 || N == 0) return SLS_OK;
+    if (cap == 0 || N == 0) {
+        SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
+        return SLS_OK;
+    }
+    if (scratch_bytes < sort_scratch_bytes(cap)) {
+        set_error("sort scratch too small: %zu < %zu", scratch_bytes, sort_scratch_bytes(cap));
+        return SLS_E_SCRATCH;
+    }
+    const int tile_bits = bits_for((uint32_t)(T - 1));
+    // one pass over the tile ids (T <= 2048): the sort's digit bases are the ranges
+    const bool fused_ranges = sort_passes(tile_bits) == 1 && keys64_out == nullptr;
+    if (!fused_ranges) SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
                            (const int4 *)rect, tiles, offsets, cap, tkeys, vals, overflow);
     }
     SLS_LAUNCH_CHECK("emit_tiles_kernel");
-    const int tile_bits = bits_for((uint32_t)(T - 1));
     int which = 0;
     int rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
-                                          scratch_bytes, &which, st);
+                                          scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T);
     if (rc) return rc;
     *sorted_in_tmp = which;
-    {
+    if (!fused_ranges) {
         ScopedTimer tm(T_TILE_RANGES, st);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, st,
                            (const uint32_t *)(which ? tkeys_tmp : tkeys), (const uint32_t *)(which ? vals_tmp : vals),
                            count_ptr, cap, depth, (uint2 *)ranges, keys64_out);
+        SLS_LAUNCH_CHECK("tile_ranges_kernel");
     }
-    SLS_LAUNCH_CHECK("tile_ranges_kernel");
     return SLS_OK;
 }
 
