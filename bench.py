@@ -96,9 +96,12 @@ def main():
     ap.add_argument("--mode", choices=("engine", "fused", "unfused"), default="engine",
                     help="engine: one native sls_mapping_step per iteration (default); fused: torch autograd around "
                          "the HIP rasterizer + HIP loss consumer; unfused: torch render()/loss glue (same maths)")
-    ap.add_argument("--async-steps", action="store_true",
-                    help="engine mode: do not read the status word after every iteration (the reference syncs once "
-                         "per iteration for its loss EMA, slam/mapper.py:206-209; default keeps that sync)")
+    ap.add_argument("--status-read", choices=("lagged", "sync", "async"), default="lagged",
+                    help="engine mode, how the per-iteration status (loss terms, R, overflow) reaches the host.  The "
+                         "reference reads its loss once per iteration (slam/mapper.py:206-209).  lagged (default, 1 GPU): "
+                         "every iteration's status is read, but after the NEXT iteration has been enqueued, so the GPU "
+                         "queue never drains; sync: read before enqueuing the next one; async: never read")
+    ap.add_argument("--async-steps", action="store_true", help="alias of --status-read async")
     ap.add_argument("--variant", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
                     help="tuning: tile-kernel variants (sls_debug_variant)")
     ap.add_argument("--pad-lds", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
@@ -147,9 +150,11 @@ def main():
         from splat_loam_amd.engine import MappingEngine
         engine = MappingEngine(model, cfg)
 
+    status_read = {"sync": True, "async": False, "lagged": "lagged"}["async" if args.async_steps else args.status_read]
+
     def step():
         if engine is not None:
-            return engine.step(cam, sync=not args.async_steps)
+            return engine.step(cam, sync=status_read)
         if args.mode == "unfused":
             return optimize_step_sharded(model, cam, cfg)
         return optimize_step_fused(model, cam, cfg)
@@ -161,18 +166,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if engine is not None:
+        engine.flush()
     barrier()
     timing = not args.no_timing
     if timing:
-        # events around the two tile kernels only (4 per step): the dominant kernel is timed live
-        # inside the timed region without the ~0.2 ms/step that 60 event records per step would add
-        lib.sls_timing_enable(2)
+        # events around the dominant kernel only (2 per step, ~10 us): it is timed live inside the
+        # timed region without the ~0.2 ms/step that 60 event records per step would add
+        lib.sls_timing_enable(3)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if engine is not None:
+        engine.flush()          # the last iteration's status is read inside the timed region too
     barrier()
     dt = time.perf_counter() - t0
-    if engine is not None and args.async_steps:
+    if engine is not None and status_read is False:
         assert not engine._read_status()["overflow"], "instance buffers overflowed during the timed region"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -188,7 +197,7 @@ def main():
 
     kernels, live = {}, {}
     if timing:
-        live = collect()                     # tile kernels, measured inside the timed region
+        live = collect()                     # render_bwd, measured inside the timed region
         lib.sls_timing_enable(1)             # every launch, in an extra un-timed pass of the same steps
         for _ in range(args.steps):
             step()
@@ -273,7 +282,10 @@ def main():
                                   "fused": " (torch autograd + HIP loss consumer)",
                                   "unfused": " (torch loss glue)"}[args.mode],
                    "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff,
-                   "parallelism": f"keyframe-dp{world}"},
+                   "parallelism": f"keyframe-dp{world}",
+                   "status_read": ("sync" if (world > 1 and status_read == "lagged") else
+                                   {True: "sync", False: "async", "lagged": "lagged-1"}[status_read])
+                   if engine is not None else "torch"},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,
     }
     print(json.dumps(out))

@@ -228,7 +228,7 @@ int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t 
  * out (later launches untimed). */
 int sls_timing_slots(void);
 const char *sls_timing_name(int slot);
-int sls_timing_enable(int mode);   /* 0 off, 1 every launch, 2 the two tile kernels only */
+int sls_timing_enable(int mode);   /* 0 off, 1 every launch, 2 the two tile kernels only, 3 render_bwd only */
 int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
 
 /* Diagnostic: when non-null, the tile kernels write the shader-clock cycles each
@@ -237,8 +237,9 @@ int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
 int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles);
 
 /* Tuning/diagnostic: choose the tile-kernel variant (0 = one workgroup per tile with
- * shared LDS staging, 1 = one independent wave per 8x8 sub-tile; negative = keep).
- * Both produce the same results; tests run both. */
+ * shared LDS staging, 1 = one independent wave per 8x8 sub-tile, 2 / 3 = one wave per
+ * 4x4 / 8x2 pixel block x 4 surfel slots [3 is the default]; negative = keep).
+ * All produce the same results; tests run them all. */
 int sls_debug_variant(int fwd_variant, int bwd_variant);
 
 /* Tuning: bytes of unused dynamic LDS requested by the tile kernels; caps the

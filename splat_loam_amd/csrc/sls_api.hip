@@ -28,7 +28,7 @@ static const char *kTimerNames[T_COUNT] = {
 constexpr int kTimerPool = 8192;
 struct TimerState {
     bool enabled = false;
-    int mode = 0;          // 1: every launch, 2: the two tile kernels only
+    int mode = 0;          // 1: every launch, 2: the two tile kernels only, 3: render_bwd only
     int used = 0;
     int created = 0;
     hipEvent_t start[kTimerPool], stop[kTimerPool];
@@ -38,7 +38,10 @@ static TimerState g_timer;
 
 static inline bool timer_wants(int slot)
 {
-    return g_timer.enabled && (g_timer.mode == 1 || slot == T_RENDER_FWD || slot == T_RENDER_BWD);
+    if (!g_timer.enabled) return false;
+    if (g_timer.mode == 1) return true;
+    if (g_timer.mode == 2) return slot == T_RENDER_FWD || slot == T_RENDER_BWD;
+    return slot == T_RENDER_BWD;
 }
 void timer_begin(int slot, hipStream_t st)
 {

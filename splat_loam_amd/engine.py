@@ -50,6 +50,11 @@ class MappingEngine:
         self.workspace = None
         self.allmap_ptr = C.c_void_p(0)
         self.last = None
+        # lagged status read (sync="lagged"): two status slots on the device, pinned mirrors, events
+        self._lag_dev = torch.zeros((2, 8), dtype=torch.int32, device=self.dev)
+        self._lag_host = torch.zeros((2, 8), dtype=torch.int32).pin_memory()
+        self._lag_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self._lag_pending = None          # (slot, camera) of the iteration whose status was not read yet
 
     # views of the flat gradient bucket in the optimiser's group order
     def grad_views(self):
@@ -87,7 +92,7 @@ class MappingEngine:
                 raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
         return ps
 
-    def _enqueue(self, camera, apply_adam, with_regulariser):
+    def _enqueue(self, camera, apply_adam, with_regulariser, status=None):
         lib = _abi.lib()
         H, W = int(camera.image_height), int(camera.image_width)
         settings = GaussianRasterizationSettings(H, W, 1.0, camera.world_view_transform, camera.projection_matrix)
@@ -103,11 +108,15 @@ class MappingEngine:
             self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
             aux.gt.data_ptr(), aux.valid.data_ptr(), aux.n_valid, ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
             aux.col_h.data_ptr(), aux.row_h.data_ptr(), C.byref(cfg), self.capacity, ws_ptr, ws_bytes,
-            self.status.data_ptr(), C.byref(self.allmap_ptr), torch.cuda.current_stream(self.dev).cuda_stream),
+            (self.status if status is None else status).data_ptr(), C.byref(self.allmap_ptr),
+            torch.cuda.current_stream(self.dev).cuda_stream),
             "sls_mapping_step")
 
     def _read_status(self):
-        h = self.status.cpu()                       # the one sync of the iteration
+        return self._parse_status(self.status.cpu())   # the one sync of the iteration
+
+    @staticmethod
+    def _parse_status(h):
         R, overflow = int(h[0].item()) & 0xFFFFFFFF, int(h[1].item())
         f = h.view(torch.float32)
         return {"R": R, "overflow": bool(overflow), "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
@@ -117,8 +126,16 @@ class MappingEngine:
     def step(self, camera, group=None, sync: bool = True):
         """One mapping iteration on `camera`.  Returns the status dict (sync=True)
         or None (sync=False: fire-and-forget; overflow is then detected at the
-        next synchronous step, the skipped Adam update keeps the model intact)."""
+        next synchronous step, the skipped Adam update keeps the model intact).
+        sync="lagged" (single GPU): the iteration is enqueued BEFORE the status of
+        the previous one is read, so the GPU queue never runs dry while the host
+        waits for a loss value; returns the PREVIOUS iteration's status (None on
+        the first call) — finish with flush()."""
         sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+        if sync == "lagged" and not sharded:
+            return self._step_lagged(camera)
+        if self._lag_pending is not None:
+            self.flush()
         while True:
             if not sharded:
                 self._enqueue(camera, apply_adam=True, with_regulariser=True)
@@ -148,6 +165,46 @@ class MappingEngine:
                 need = int(t.item())
             self.capacity = int(max(need, self.capacity) * self.capacity_factor) + 1024
             self.workspace = None
+
+    def _step_lagged(self, camera):
+        slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
+        self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot])
+        self.t += 1
+        self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
+        self._lag_ev[slot].record(torch.cuda.current_stream(self.dev))
+        prev, self._lag_pending = self._lag_pending, (slot, camera)
+        return None if prev is None else self._lag_collect(prev, redo_current=True)
+
+    def _lag_collect(self, prev, redo_current):
+        pslot, pcam = prev
+        self._lag_ev[pslot].synchronize()
+        st = self._parse_status(self._lag_host[pslot].clone())
+        if not st["overflow"]:
+            self.last = st
+            return st
+        # The instance buffers were too small: that iteration skipped its Adam update on the
+        # device, and so did the one enqueued after it (same capacity).  Drain, grow, redo.
+        cur, self._lag_pending = self._lag_pending, None
+        torch.cuda.current_stream(self.dev).synchronize()
+        cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
+        cur_void = cur_st is not None and cur_st["overflow"]
+        self.t -= 2 if cur_void else 1
+        need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
+        self.capacity = int(need * self.capacity_factor) + 1024
+        self.workspace = None
+        st = self.step(pcam, sync=True)
+        if cur_void and redo_current:
+            self._step_lagged(cur[1])
+        elif cur_st is not None and not cur_void:
+            self.last = cur_st          # (another keyframe that fitted: it did run, nothing to repeat)
+        return st
+
+    def flush(self):
+        """Status of the last lagged iteration (None if nothing is pending)."""
+        if self._lag_pending is None:
+            return None
+        prev, self._lag_pending = self._lag_pending, None
+        return self._lag_collect(prev, redo_current=False)
 
     def _adam_guarded(self):
         lib = _abi.lib()

@@ -420,6 +420,40 @@ def test_mapping_engine_matches_unfused_step(device):
     assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
 
 
+def test_mapping_engine_lagged_status_read(device):
+    """sync="lagged" (status of iteration k read after iteration k+1 was enqueued)
+    walks the same parameter trajectory and reports the same losses as the
+    synchronous mode, also across an overflow of the instance buffers."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 6000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=15, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+    cfg = MappingConfig()
+    models = [SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+              for _ in range(2)]
+    ref, lag = MappingEngine(models[0], cfg), MappingEngine(models[1], cfg)
+    lag.capacity = 2048            # overflows on the first two (pipelined) iterations
+    n_it = 6
+    ref_losses = [ref.step(cam)["loss"] for _ in range(n_it)]
+    lag_losses = []
+    for _ in range(n_it):
+        st = lag.step(cam, sync="lagged")
+        if st is not None:
+            lag_losses.append(st["loss"])
+    lag_losses.append(lag.flush()["loss"])
+    assert lag.flush() is None and lag.t == ref.t == n_it and lag.capacity > 2048
+    assert len(lag_losses) == n_it
+    for a, b in zip(ref_losses, lag_losses):
+        assert abs(a - b) <= 1e-5 * abs(a), (ref_losses, lag_losses)
+    for k in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        pa, pb = getattr(models[0], k).detach(), getattr(models[1], k).detach()
+        assert float((pa - pb).abs().max()) <= 1e-5 * max(float(pa.abs().max()), 1.0), k
+
+
 @pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (3, 3)],
                          ids=["workgroup-per-tile", "wave-per-subtile", "block4x4-fwd", "block4x4-bwd", "block4x4", "block8x2"])
 def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
