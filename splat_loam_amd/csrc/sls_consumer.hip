@@ -167,7 +167,7 @@ size_t consumer_scratch_bytes(int H, int W) { return sizeof(float4) * 3 * (size_
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st)
+                    hipStream_t st, bool sums_zeroed)
 {
     if (scratch_bytes < consumer_scratch_bytes(H, W)) {
         set_error("consumer scratch too small");
@@ -186,7 +186,7 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
     a.sums = sums;
     a.dL_dallmap = dL_dallmap;
     ScopedTimer tm(T_CONSUMER, st);
-    SLS_HIP_CHECK(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
+    if (!sums_zeroed) SLS_HIP_CHECK(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
     const dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(consumer_b_kernel, grid, dim3(256), 0, st, a);
     SLS_LAUNCH_CHECK("consumer_b_kernel");

@@ -31,14 +31,14 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
                     uint32_t *overflow, hipStream_t st);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
-                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t);
+                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st);
+                    hipStream_t st, bool sums_zeroed = false);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                 const uint32_t *skip_flag, hipStream_t stream);
 
@@ -50,7 +50,7 @@ struct MapWs {
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
-    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec;
+    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes;
     size_t total;
 };
 
@@ -83,11 +83,13 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.allmap = (float *)take(P * 7 * 4);
     w.pix_state = (float *)take(P * 16);
     w.pix_contrib = (uint32_t *)take(P * 8);
-    w.tile_consumed = (uint32_t *)take(T * 4);
     w.dL_dallmap = (float *)take(P * 7 * 4);
     w.consumer_scratch_bytes = consumer_scratch_bytes(H, W);
     w.consumer_scratch = take(w.consumer_scratch_bytes);
+    // zeroed together, with one memset per iteration: [tile_consumed | grec]
+    w.tile_consumed = (uint32_t *)take(T * 4);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
+    w.zero_bytes = (size_t)((char *)w.grec - (char *)w.tile_consumed) + n * SLS_GREC_STRIDE * 4;
     w.total = off;
     return w;
 }
@@ -216,6 +218,10 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const uint32_t cap = (uint32_t)R_capacity;
     if (allmap_out) *allmap_out = w.allmap;
     SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
+    {   // everything else that accumulates: the tiles' consumed counters and the gradient records
+        ScopedTimer tm(T_GREC_MEMSET, st);
+        SLS_HIP_CHECK(hipMemsetAsync(w.tile_consumed, 0, w.zero_bytes, st));
+    }
 
     // ---- forward ---------------------------------------------------------------
     uint32_t *okeys, *ovals, *n_dev;
@@ -234,18 +240,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
-                           w.tile_consumed, st);
+                           w.tile_consumed, st, true);
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
                          cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
-                         w.consumer_scratch, w.consumer_scratch_bytes, st);
+                         w.consumer_scratch, w.consumer_scratch_bytes, st, true);   // sums zeroed with the status
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
-    {
-        ScopedTimer tm(T_GREC_MEMSET, st);
-        SLS_HIP_CHECK(hipMemsetAsync(w.grec, 0, sizeof(float) * (size_t)N * SLS_GREC_STRIDE, st));
-    }
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                            w.grec, st);
     if (rc) return rc;

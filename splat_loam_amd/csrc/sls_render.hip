@@ -617,14 +617,16 @@ uint32_t *g_dbg_fwd_cycles = nullptr, *g_dbg_bwd_cycles = nullptr;
 // ---------------------------------------------------------------------------
 int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
-                      uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st)
+                      uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed)
 {
     const int T = cam.GX * cam.GY;
+    // the wave / block kernels combine their sub-tiles with atomicMax: start from zero
+    if (g_fwd_variant >= 1 && tile_consumed && !consumed_zeroed)
+        SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     if (g_fwd_variant >= 2)
         return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
                                        tile_consumed, g_fwd_variant - 2, st);
     if (g_fwd_variant == 1) {
-        if (tile_consumed) SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
         ScopedTimer tm(T_RENDER_FWD, st);
         hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(T * kSubPerTile), dim3(64), g_pad_lds_fwd, st, cam, (const uint2 *)ranges,
                            vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,

@@ -387,7 +387,6 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             uint32_t *pix_contrib, uint32_t *tile_consumed, int shape, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
-    if (tile_consumed) SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
 #define SLS_FWD_BLOCK(BW_, BH_, DBG_)                                                                             \

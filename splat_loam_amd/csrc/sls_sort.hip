@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
         if (valid) pos = s_cursor[wave][digit] + rank;
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            keys_out[pos] = k[r];
+            if (keys_out) keys_out[pos] = k[r];     // (a caller that only wants the permutation passes null in the last pass)
             vals_out[pos] = v[r];
             if (rank == count - 1) s_cursor[wave][digit] = pos + 1;
         }
@@ -255,14 +255,15 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
 // Item count = min(*count_ptr, cap), read on the device.  Ping-pongs between
 // (keys, vals) and (keys_tmp, vals_tmp); *result_in_tmp says where the sorted
 // data ended up.  ranges_out (single-pass sorts only): [start, end) of every key
-// value < nranges in the sorted output ((0,0) for absent values).
+// value < nranges in the sorted output ((0,0) for absent values).  drop_sorted_keys: the
+// last pass writes the permuted values only.
 // (Counting the next pass's digits inside the scatter / the producer with global
 // atomics was measured and is slower than the histogram kernel: +35 us per pass.)
 template <typename KeyT>
 static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32_t *vals_tmp,
                               const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
                               size_t scratch_bytes, int *result_in_tmp, hipStream_t st,
-                              uint2 *ranges_out = nullptr, int nranges = 0)
+                              uint2 *ranges_out = nullptr, int nranges = 0, bool drop_sorted_keys = false)
 {
     *result_in_tmp = 0;
     if (cap == 0 || nbits <= 0) return SLS_OK;
@@ -286,7 +287,8 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         const int shift = bits * p;
         const int src = p & 1, dst = src ^ 1;
         int rc;
-#define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kb[dst], vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
+        KeyT *kout = (drop_sorted_keys && p + 1 == npasses) ? nullptr : kb[dst];
+#define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kout, vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
                                         nblocks, ranges_out, nranges, st)
         switch (bits) {
         case 8: rc = SLS_PASS(8); break;
@@ -493,7 +495,7 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     }
     int which = 0;
     int rc = radix_sort_pairs_t<uint32_t>(keys, v0, keys_tmp, v1, n_dev, (uint32_t)N, kDepthKeyBits, sort_scratch,
-                                          sort_bytes, &which, st);
+                                          sort_bytes, &which, st, nullptr, 0, true);   // only the order is used
     if (rc) return rc;
     if ((which != 0) != odd) {
         set_error("internal: depth order ended in the wrong buffer");
@@ -541,7 +543,8 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     SLS_LAUNCH_CHECK("emit_tiles_kernel");
     int which = 0;
     int rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
-                                          scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T);
+                                          scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T,
+                                          fused_ranges);   // nobody reads the sorted tile ids then
     if (rc) return rc;
     *sorted_in_tmp = which;
     if (!fused_ranges) {

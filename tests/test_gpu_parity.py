@@ -297,6 +297,14 @@ def test_full_size_properties(device):
     tile_ids = (keys >> np.uint64(32)).astype(np.int64)
     cnt = np.bincount(tile_ids, minlength=rng.shape[0])
     assert np.array_equal((rng[:, 1] - rng[:, 0]).astype(np.int64), cnt), "ranges partition the list"
+    # production path (no 64-bit keys asked for): ranges come from the tile sort's digit bases,
+    # the sorted tile ids are never written -> same list, same ranges, same image
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, rasterize_forward
+    s2 = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device))
+    st2 = rasterize_forward(s2, t["means"], t["opac"], t["scales"], t["rots"])
+    assert st2.R == st.R and np.array_equal(u32(st2.vals), vals), "fused-ranges path: same sorted list"
+    assert np.array_equal(u32(st2.ranges).reshape(-1, 2), rng), "fused-ranges path: same ranges"
+    assert torch.equal(st2.allmap, st.allmap)
     am = st.allmap.cpu().numpy()
     assert np.isfinite(am).all()
     assert am[1].min() >= 0.0 and am[1].max() <= 1.0, "alpha in [0,1] (fed to BCE, slam/mapper.py:182)"

@@ -41,7 +41,7 @@ for k, v in out.items():
                          "hbm_bytes_corrected": f * 2.0 + w, "hbm_bytes_calibrated": f * f_corr + w * w_corr}
 json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res["calibration"]))
-for k in ("render_fwd_wave_kernel", "render_bwd_wave_kernel", "adam_kernel", "preprocess_fwd_kernel"):
-    if k in res["kernels"]:
+for k in sorted(res["kernels"]):
+    if k.startswith(("render_", "adam_", "preprocess_")):
         print(k, {a: round(b / 1e6, 2) for a, b in res["kernels"][k].items()}, "MB")
 PY
