@@ -109,8 +109,13 @@ int sls_forward_stage1(const SlsCamera *cam, int N,
  * ranges: T*2 uint32 with T = ceil(W/tw)*ceil(H/th).  allmap: 7*H*W floats;
  * pix_state: H*W float4 {T_final, M1, M2, 0}; pix_contrib: H*W uint2
  * {n_contrib, median_contrib}; tile_consumed: T uint32 (list entries consumed
- * before the tile finished, the R_eff of SURVEY §8d). */
+ * before the tile finished, the R_eff of SURVEY §8d).
+ * block_masks (optional, may be null; sls_block_mask_bytes(R, H, W) bytes): forward ->
+ * backward hand-over, one 64-bit word per (tile, 64 list entries, pixel block) naming the
+ * entries that reached a pixel of the block; with it sls_backward evaluates exactly the
+ * (block, surfel) pairs that contributed instead of re-deriving them with a box test. */
 size_t sls_sort_scratch_bytes(uint64_t R);
+size_t sls_block_mask_bytes(uint64_t R, int H, int W);
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
                        const float *rec, const int32_t *rect, const uint32_t *tiles_touched,
                        const float *depth, const uint32_t *order, const uint32_t *offsets,
@@ -120,7 +125,7 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
                        uint64_t *keys64_out,
                        uint32_t *ranges, const float *col_cs, const float *row_cs,
                        float *allmap, float *pix_state, uint32_t *pix_contrib,
-                       uint32_t *tile_consumed, void *stream);
+                       uint32_t *tile_consumed, uint64_t *block_masks, void *stream);
 
 /* ---- backward ----------------------------------------------------------
  * vals_sorted/ranges/rec/pix_* are the forward's buffers (never allmap: the
@@ -136,7 +141,7 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R,
                  const float *pix_state, const uint32_t *pix_contrib,
                  const float *dL_dallmap, float *grec,
                  float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
-                 float *dL_dopacities, void *stream);
+                 float *dL_dopacities, const uint64_t *block_masks, void *stream);
 
 /* ---- fused consumer of allmap: render() post-processing + mapper loss ------
  * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of

@@ -66,12 +66,13 @@ _PROTOS = {
     "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 12 + [_VP, C.c_size_t, _VP]),
     "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 11 +
-                           [_VP, C.c_size_t, C.POINTER(C.c_int), _VP] + [_VP] * 7 + [_VP]),
+                           [_VP, C.c_size_t, C.POINTER(C.c_int), _VP] + [_VP] * 8 + [_VP]),
+    "sls_block_mask_bytes": (C.c_size_t, [C.c_uint64, C.c_int, C.c_int]),
     "sls_mapping_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),
     "sls_mapping_step": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 7 + [C.c_int64, _VP, _VP, C.c_int] +
                          [_VP] * 4 + [C.POINTER(SlsMappingConfig), C.c_uint64, _VP, C.c_size_t, _VP,
                                       C.POINTER(C.c_void_p), _VP]),
-    "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP]),
+    "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 18 + [_VP]),
     "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
     "sls_adam_step_guarded": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP]),

@@ -31,9 +31,12 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
                     uint32_t *overflow, hipStream_t st);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
-                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false);
+                      const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
+                      uint64_t *block_masks = nullptr);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
-                      const float *, const float *, const uint32_t *, const float *, float *, hipStream_t);
+                      const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
+                      const uint64_t *block_masks = nullptr);
+size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
@@ -50,7 +53,7 @@ struct MapWs {
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
-    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes;
+    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks;
     size_t total;
 };
 
@@ -86,6 +89,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.dL_dallmap = (float *)take(P * 7 * 4);
     w.consumer_scratch_bytes = consumer_scratch_bytes(H, W);
     w.consumer_scratch = take(w.consumer_scratch_bytes);
+    w.block_masks = (uint64_t *)take(block_mask_bytes(cap, (int)T));
     // zeroed together, with one memset per iteration: [tile_consumed | grec]
     w.tile_consumed = (uint32_t *)take(T * 4);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
@@ -131,6 +135,10 @@ int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const 
 }
 
 size_t sls_sort_scratch_bytes(uint64_t R) { return sort_scratch_bytes(R); }
+size_t sls_block_mask_bytes(uint64_t R, int H, int W)
+{
+    return block_mask_bytes(R, ((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH));
+}
 
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec, const int32_t *rect,
                        const uint32_t *tiles_touched, const float *depth, const uint32_t *order,
@@ -138,7 +146,7 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
                        uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *sort_scratch, size_t sort_scratch_bytes_,
                        int *sorted_in_tmp, uint64_t *keys64_out, uint32_t *ranges, const float *col_cs,
                        const float *row_cs, float *allmap, float *pix_state, uint32_t *pix_contrib,
-                       uint32_t *tile_consumed, void *stream)
+                       uint32_t *tile_consumed, uint64_t *block_masks, void *stream)
 {
     SLS_REQUIRE(cam && sorted_in_tmp && ranges && col_cs && row_cs && allmap && pix_state && pix_contrib,
                 "null pointer");
@@ -154,14 +162,15 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     if (rc) return rc;
     const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
     return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                             tile_consumed, st);
+                             tile_consumed, st, false, block_masks);
 }
 
 int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
                  const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
                  const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
                  const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, float *dL_dmeans3D,
-                 float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream)
+                 float *dL_dscales, float *dL_drotations, float *dL_dopacities, const uint64_t *block_masks,
+                 void *stream)
 {
     SLS_REQUIRE(cam, "null pointer");
     SLS_REQUIRE(N >= 0, "negative N");
@@ -179,7 +188,7 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
         SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   grec, st);
+                                   grec, st, block_masks);
         if (rc) return rc;
     }
     return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, grec, dL_dmeans3D,
@@ -240,7 +249,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
-                           w.tile_consumed, st, true);
+                           w.tile_consumed, st, true, w.block_masks);
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
@@ -249,7 +258,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
-                           w.grec, st);
+                           w.grec, st, w.block_masks);
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;

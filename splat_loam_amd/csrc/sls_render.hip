@@ -602,11 +602,13 @@ __global__ __launch_bounds__(64) void render_bwd_wave_kernel(
 // 2 / 3 = one wave per 4x4 / 8x2 pixel block x 4 surfel slots (sls_render_block.hip)
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
-                            uint32_t *pix_contrib, uint32_t *tile_consumed, int shape, hipStream_t st);
+                            uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
+                            hipStream_t st);
+size_t block_mask_bytes(uint64_t cap, int T);
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
-                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, int shape,
-                            hipStream_t st);
+                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
+                            const uint64_t *block_masks, int shape, hipStream_t st);
 int g_fwd_variant = 3, g_bwd_variant = 3;
 // unused dynamic LDS requested at launch (caps the workgroups resident per CU)
 int g_pad_lds_fwd = 0, g_pad_lds_bwd = 0;
@@ -617,15 +619,18 @@ uint32_t *g_dbg_fwd_cycles = nullptr, *g_dbg_bwd_cycles = nullptr;
 // ---------------------------------------------------------------------------
 int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
-                      uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed)
+                      uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed,
+                      uint64_t *block_masks)
 {
     const int T = cam.GX * cam.GY;
+    // only the block kernels fill the contribution masks: invalidate the tag otherwise
+    if (g_fwd_variant < 2 && block_masks) SLS_HIP_CHECK(hipMemsetAsync(block_masks, 0, sizeof(uint64_t), st));
     // the wave / block kernels combine their sub-tiles with atomicMax: start from zero
     if (g_fwd_variant >= 1 && tile_consumed && !consumed_zeroed)
         SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     if (g_fwd_variant >= 2)
         return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                                       tile_consumed, g_fwd_variant - 2, st);
+                                       tile_consumed, block_masks, g_fwd_variant - 2, st);
     if (g_fwd_variant == 1) {
         ScopedTimer tm(T_RENDER_FWD, st);
         hipLaunchKernelGGL(render_fwd_wave_kernel, dim3(T * kSubPerTile), dim3(64), g_pad_lds_fwd, st, cam, (const uint2 *)ranges,
@@ -644,12 +649,13 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
 
 int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, const float *pix_state,
-                      const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st)
+                      const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st,
+                      const uint64_t *block_masks)
 {
     const int T = cam.GX * cam.GY;
     if (g_bwd_variant >= 2)
         return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                       grec, g_bwd_variant - 2, st);
+                                       grec, block_masks, g_bwd_variant - 2, st);
     ScopedTimer tm(T_RENDER_BWD, st);
     if (g_bwd_variant == 1) {
         hipLaunchKernelGGL(render_bwd_wave_kernel, dim3(T * kSubPerTile), dim3(64), g_pad_lds_bwd, st, cam,

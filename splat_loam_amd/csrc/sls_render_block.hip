@@ -61,6 +61,21 @@ __device__ __forceinline__ void quad_excl_total(float x, float k1, float k2, flo
     total = dppq<0xFF>(excl + x);
 }
 
+// Forward -> backward hand-over: one 64-bit word per (tile, round of 64 list entries, block)
+// with the entries that contributed to at least one pixel of the block, so that the backward
+// evaluates exactly those (the support-box test alone lets ~40 % useless pairs through).
+// Word 0 is a tag naming the producer's block shape; a tile's rounds start at
+// (first list entry >> 6) + tile, which never collides with its neighbours' rounds.
+__host__ __device__ inline uint64_t block_mask_tag(int bw) { return 0x534C4D41534B0000ull | (uint64_t)bw; }
+__device__ __forceinline__ size_t block_mask_index(uint32_t first, int tile, int r, int per_tile, int sub)
+{
+    return 1 + ((size_t)(first >> 6) + (size_t)tile + (size_t)r) * (size_t)per_tile + (size_t)sub;
+}
+size_t block_mask_bytes(uint64_t cap, int T)
+{
+    return sizeof(uint64_t) * (1 + ((size_t)(cap >> 6) + (size_t)T + 2) * (size_t)(kTilePix / 16));
+}
+
 // Box (pixel coordinates, centre + half extents) of the pixels whose slot-0 lane
 // is set in `m`, for a BW-wide block at (x0, y0); all scalar work.
 template <int BW, int BH>
@@ -87,7 +102,7 @@ __device__ __forceinline__ bool block_active_box(uint64_t m, int x0, int y0, flo
 // A6 forward
 // ---------------------------------------------------------------------------
 template <int BW, int BH, bool DBG>
-__global__ __launch_bounds__(64) void render_fwd_block_kernel(
+__global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restrict__ blk_mask,
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
@@ -97,6 +112,7 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     __shared__ float4 s_rec[64 * kRec4];
     __shared__ uint32_t s_list[64];
+    __shared__ uint32_t s_flag[64];
     const uint64_t t_start = DBG ? clock64() : 0;
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
     uint32_t medc = 0, last = 0, cons = 0;
     bool done = !inside;
     bool wave_done = __all(done);
-    uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0;   // diagnostics only
+    uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0, st_slots = 0, st_geom = 0;   // diagnostics only
 
     const int nr = (n + 63) / 64;
     SLS_STAGE_DECL
@@ -135,9 +151,11 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
         SLS_WSTAGE_LOAD_REC()
         if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, 1, n) }
     }
+    if (blk_mask && blockIdx.x == 0 && lane == 0) blk_mask[0] = block_mask_tag(BW);
     for (int r = 0; r < nr && !wave_done; ++r) {
         float bcx, bcy, bhx, bhy;
         if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
         if (r + 1 < nr) {
@@ -162,7 +180,15 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
             Eval e;
             eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
             const bool live = valid && !done && !e.skip;
-            if (DBG) { st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(__ballot(live)); }
+            if (DBG) {
+                const uint64_t lb = __ballot(live);
+                st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(lb);
+                const uint64_t gb = __ballot(valid && inside && !e.skip);      // ignoring finished pixels
+                for (int q = 0; q < 4; ++q) {
+                    st_slots += (lb & (0x1111111111111111ull << q)) ? 1u : 0u;
+                    st_geom += (gb & (0x1111111111111111ull << q)) ? 1u : 0u;
+                }
+            }
             if (!__ballot(live)) continue;
             // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k
             const float f = live ? 1.0f - e.alpha : 1.0f;
@@ -175,6 +201,7 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
             const uint32_t nib = (uint32_t)(__ballot(term) >> (lane & 60)) & 15u;   // terminating slots of my pixel
             const bool first_term = term && !(nib & below);
             const bool upd = live && !(nib & upto);
+            if (blk_mask && upd) s_flag[j] = 1u;   // (same value from every lane: plain LDS store)
             const float w = upd ? e.alpha * E : 0.0f;
             const float dep = upd ? e.depth : 1.0f;
             const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
@@ -198,6 +225,11 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
             Tr = quad_sum(cand);
             done = done || (nib != 0u);
             if (__all(done)) { wave_done = true; break; }
+        }
+        if (blk_mask) {
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t rmask = __ballot(s_flag[lane] != 0u);
+            if (lane == 0) blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)] = rmask;
         }
     }
 
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(
         dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
         uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
         atomicAdd(&st[0], st_staged); atomicAdd(&st[1], st_pass);
-        atomicAdd(&st[2], st_steps); atomicAdd(&st[3], st_lanes);
+        atomicAdd(&st[2], st_steps); atomicAdd(&st[3], st_lanes); atomicAdd(&st[4], st_slots); atomicAdd(&st[5], st_geom);
     }
 }
 
@@ -245,13 +277,16 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
-    const float *__restrict__ dL_dallmap, float *__restrict__ grec, uint32_t *__restrict__ dbg_cycles)
+    const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
+    uint32_t *__restrict__ dbg_cycles)
 {
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     __shared__ float4 s_rec[64 * kRec4];
     __shared__ uint32_t s_list[64];
     __shared__ uint32_t s_gidx[64];
+    // contribution masks of a forward with the same block shape, else cull here
+    const bool use_mask = blk_mask != nullptr && blk_mask[0] == block_mask_tag(BW);
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
@@ -311,12 +346,20 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             }
             const int cnt = min(64, tmax - r * 64);
             const uint32_t c_lo = (uint32_t)(r * 64 + 1);
-            float bcx, bcy, bhx, bhy;
-            if (!block_active_box<BW, BH>(__ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
-            __builtin_amdgcn_wave_barrier();
-            bool pass = false;
-            if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
-            const uint64_t mask = __ballot(pass);
+            uint64_t mask;
+            if (use_mask) {
+                mask = blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)];
+                if (cnt < 64) mask &= (1ull << cnt) - 1ull;
+            } else {
+                float bcx, bcy, bhx, bhy;
+                if (!block_active_box<BW, BH>(__ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
+                __builtin_amdgcn_wave_barrier();
+                bool pass = false;
+                if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+                mask = __ballot(pass);
+            }
+            if (mask == 0) continue;
+            const bool pass = (mask >> lane) & 1ull;
             const int npass = __builtin_popcountll(mask);
             // survivors in DESCENDING list order
             if (pass) s_list[npass - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
@@ -384,14 +427,15 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
 // ---------------------------------------------------------------------------
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
-                            uint32_t *pix_contrib, uint32_t *tile_consumed, int shape, hipStream_t st)
+                            uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
+                            hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
 #define SLS_FWD_BLOCK(BW_, BH_, DBG_)                                                                             \
-    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
-                       vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
+    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_>), grid, block, 0, st, block_masks, cam,          \
+                       (const uint2 *)ranges, vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
                        (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles)
     if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true); else SLS_FWD_BLOCK(4, 4, true); }
     else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false); else SLS_FWD_BLOCK(4, 4, false); }
@@ -402,8 +446,8 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
-                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, int shape,
-                            hipStream_t st)
+                            const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
+                            const uint64_t *block_masks, int shape, hipStream_t st)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -411,11 +455,13 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     if (shape == 1)
         hipLaunchKernelGGL((render_bwd_block_kernel<8, 2>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
                            (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
-                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, g_dbg_bwd_cycles);
+                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,
+                           g_dbg_bwd_cycles);
     else
         hipLaunchKernelGGL((render_bwd_block_kernel<4, 4>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
                            (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
-                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, g_dbg_bwd_cycles);
+                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,
+                           g_dbg_bwd_cycles);
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");
     return SLS_OK;
 }

@@ -108,7 +108,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 class ForwardState:
     """Everything the backward (and the tests) need from one forward."""
     __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "depth", "order", "offsets", "keys", "vals",
-                 "ranges", "pix_state", "pix_contrib", "tile_consumed", "allmap")
+                 "ranges", "pix_state", "pix_contrib", "tile_consumed", "block_masks", "allmap")
 
 
 def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
@@ -168,6 +168,7 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.pix_state = torch.empty((H * W, 4), dtype=f32, device=dev)
     s.pix_contrib = torch.empty((H * W, 2), dtype=u32, device=dev)
     s.tile_consumed = torch.empty((T,), dtype=u32, device=dev)
+    s.block_masks = torch.empty((int(lib.sls_block_mask_bytes(R, H, W)) // 8,), dtype=torch.int64, device=dev)
     in_tmp = C.c_int(0)
     _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
                                       s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
@@ -176,7 +177,8 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
                                       keys64.data_ptr() if want_keys else None, s.ranges.data_ptr(),
                                       ce.col_cs.data_ptr(),
                                       ce.row_cs.data_ptr(), s.allmap.data_ptr(), s.pix_state.data_ptr(),
-                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(), st), "sls_forward_stage2")
+                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(), s.block_masks.data_ptr(), st),
+               "sls_forward_stage2")
     dbg()
     s.vals = vals_b if in_tmp.value else vals_a
     s.keys = keys64        # 64-bit (tile << 32 | depth bits) keys, only when asked for (tests)
@@ -203,7 +205,8 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
                                 state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
                                 ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
                                 dL.data_ptr(), grec.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(),
-                                drots.data_ptr(), dopac.data_ptr(), _stream(dev)), "sls_backward")
+                                drots.data_ptr(), dopac.data_ptr(), state.block_masks.data_ptr(), _stream(dev)),
+               "sls_backward")
     return dmeans, dscales, drots, dopac, grec
 
 

@@ -15,7 +15,7 @@ fv = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 bv = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 _abi.lib().sls_debug_variant(fv, bv)
 tw, th = _abi.tile_size(); T = (W // tw) * (H // th); wpt = tw * th // 16
-f = torch.zeros(T * wpt + 4, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
+f = torch.zeros(T * wpt + 8, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
 _abi.lib().sls_debug_wave_cycles(f.data_ptr(), b.data_ptr())
 for it in range(2):
     f.zero_()
@@ -34,10 +34,12 @@ for name, a in (("fwd", f), ("bwd", b)):
     print(name, "slowest tiles", k, "cycles", tile[k], "consumed", cons[k])
 print("consumed mean", cons.mean(), "max", cons.max(), "sum", cons.sum())
 per = tw * th // (16 if fv >= 2 else 64)
-st = f.cpu().numpy()[T * per:T * per + 4].astype(np.int64)
+st = f.cpu().numpy()[T * per:T * per + 6].astype(np.int64)
 if fv >= 2:
     print("fwd block waves: staged %d, passed the box cull %d (%.1f%%), steps %d (slot fill %.2f of 4), live lanes per step %.1f"
           % (st[0], st[1], 100.0 * st[1] / st[0], st[2], st[1] / max(st[2], 1), st[3] / max(st[2], 1)))
+    print("   (block, surfel) pairs evaluated %d, with >= 1 live pixel %d (%.1f%%), with >= 1 pixel above 1/255 incl. finished ones %d (%.1f%%)"
+          % (st[1], st[4], 100.0 * st[4] / max(st[1], 1), st[5], 100.0 * st[5] / max(st[1], 1)))
 else:
     print("fwd waves: staged %d, passed the box cull %d (%.1f%%), with >=1 contributing pixel %d (%.1f%% of passed), "
           "contributing lanes per evaluated surfel %.1f" % (st[0], st[1], 100.0 * st[1] / st[0], st[2], 100.0 * st[2] / st[1], st[3] / st[1]))
