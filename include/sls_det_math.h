@@ -13,7 +13,7 @@
  * compare/select); atan2 is a fixed odd polynomial evaluated with fmaf.
  * Max abs error of sls_atan2 vs. the real atan2 is < 4e-7 rad in float
  * (polynomial 1.1e-7 + one ulp at |angle| ~ pi), i.e. < 1.4e-4 px at
- * |fx| = 326 px/rad), see tests/test_det_math.py.
+ * |fx| = 326 px/rad), see tests/test_oracle.py::test_det_atan2_accuracy.
  *
  * Rules for users of this header (both sides):
  *   - compile with -ffp-contract=off (no implicit fma), no fast-math;
