@@ -102,6 +102,9 @@ def main():
                          "every iteration's status is read, but after the NEXT iteration has been enqueued, so the GPU "
                          "queue never drains; sync: read before enqueuing the next one; async: never read")
     ap.add_argument("--async-steps", action="store_true", help="alias of --status-read async")
+    ap.add_argument("--full-sort", action="store_true",
+                    help="engine mode: sort the depth order from scratch every iteration instead of repairing the "
+                         "previous iteration's order (windowed re-sort + exactness check, DESIGN.md section 4)")
     ap.add_argument("--variant", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
                     help="tuning: tile-kernel variants (sls_debug_variant)")
     ap.add_argument("--pad-lds", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
@@ -149,6 +152,7 @@ def main():
     if args.mode == "engine":
         from splat_loam_amd.engine import MappingEngine
         engine = MappingEngine(model, cfg)
+        engine.reuse_depth_order = not args.full_sort
 
     status_read = {"sync": True, "async": False, "lagged": "lagged"}["async" if args.async_steps else args.status_read]
 
@@ -285,7 +289,10 @@ def main():
                    "parallelism": f"keyframe-dp{world}",
                    "status_read": ("sync" if (world > 1 and status_read == "lagged") else
                                    {True: "sync", False: "async", "lagged": "lagged-1"}[status_read])
-                   if engine is not None else "torch"},
+                   if engine is not None else "torch",
+                   "depth_order": ("repaired from the previous iteration, verified exact"
+                                   if (engine is not None and engine.reuse_depth_order and world == 1)
+                                   else "sorted from scratch")},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,
     }
     print(json.dumps(out))

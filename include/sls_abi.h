@@ -88,7 +88,8 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 /* ---- forward, stage 1: preprocess + depth order + scan ---------------------
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
  * tiles_touched: N uint32, depth: N floats (range of the centre, the sort key),
- * order: N uint32 = surfel index at each position of the (depth, index) order,
+ * order: N uint32 = surfel index at each position of the (range, index) order (ALL surfels,
+ *        culled ones included at their range; they have tiles_touched = 0 and emit nothing),
  * offsets: N uint32 = inclusive scan of tiles_touched[order[.]],
  * total_out: 1 uint32 on the DEVICE = number of tile instances R.
  * The caller reads total_out (one D2H sync, as the lineage does) to size the
@@ -175,11 +176,16 @@ typedef struct SlsMappingConfig {
     float lambda_alpha, lambda_normal, scaling_max, scaling_max_penalty, depth_ratio;
     float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
     int32_t apply_adam;   /* 0: gradients only (all-reduce them, then sls_adam_step) */
+    int32_t reuse_depth_order; /* 1: the workspace still holds the depth order of the previous iteration on the
+                                * SAME keyframe and surfel set: repair it (windowed re-sort + verification)
+                                * instead of sorting from scratch.  If the repair does not reach the exact
+                                * order, bit 1 of status.overflow is set, Adam is skipped, repeat with 0. */
     double beta1, beta2, eps;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
-    uint32_t overflow;    /* 1: R > R_capacity, gradients incomplete, Adam skipped */
+    uint32_t overflow;    /* bit 0: R > R_capacity; bit 1: depth-order repair failed (reuse_depth_order).
+                           * Non-zero: results of this iteration are void, Adam was skipped */
     float loss_sums[4];   /* sums of the three pixel terms, pixel-loss total */
     float loss_reg;       /* scale regulariser */
     uint32_t pad;

@@ -212,21 +212,20 @@ __device__ __forceinline__ float readlane63(float v)
 }
 
 // Sort key of the depth ordering: positive floats order like their bit patterns; subtracting
-// the pattern of 2^-3 (below the 0.2 m near cut) leaves 29 significant bits for ranges up to
-// 2^3 * 2^-3 * 2^(2^5)... i.e. any finite LiDAR range; culled surfels get the largest key so
-// they sort behind every visible one.  Monotone, so the order equals the order of the raw bits.
-__host__ __device__ inline uint32_t depth_order_key(float depth, bool visible)
+// the pattern of 2^-3 (below the 0.2 m near cut) leaves 29 significant bits for any finite LiDAR
+// range.  Monotone, so the order of the visible surfels equals the order of their raw depth bits
+// (everything below 2^-3 collapses to 0, NaN / inf / huge to the largest key: culled anyway).
+__host__ __device__ inline uint32_t depth_order_key(float range)
 {
     constexpr uint32_t kBase = 0x3E000000u;             // bits of 0.125f
     constexpr uint32_t kMax = (1u << 29) - 1u;
-    if (!visible) return kMax;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t b = __float_as_uint(depth);
+    const uint32_t b = __float_as_uint(range) & 0x7FFFFFFFu;
 #else
-    uint32_t b; __builtin_memcpy(&b, &depth, 4);
+    uint32_t b; __builtin_memcpy(&b, &range, 4); b &= 0x7FFFFFFFu;
 #endif
     const uint32_t k = b > kBase ? b - kBase : 0u;
-    return k < kMax - 1u ? k : kMax - 1u;
+    return k < kMax ? k : kMax;
 }
 
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8

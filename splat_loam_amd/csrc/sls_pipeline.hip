@@ -24,7 +24,7 @@ size_t sort_scratch_bytes(uint64_t cap);
 size_t order_scratch_bytes(int N);
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st);
+                            hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr);
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
                     const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
@@ -240,7 +240,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                                    okeys, ovals, n_dev, st);
     if (rc) return rc;
     rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
-                                 w.order_scratch_bytes, 1, st);
+                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow);
     if (rc) return rc;
     int in_tmp = 0;
     rc = launch_bin_sort(dc, N, &status_dev->R, cap, w.order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,

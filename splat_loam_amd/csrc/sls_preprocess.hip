@@ -243,8 +243,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         rect[i] = rc;
         tiles[i] = my_tiles;
         depth[i] = dep;
-        if (order_keys) {   // input of the depth-order sort: culled surfels go behind every visible one
-            order_keys[i] = depth_order_key(dep, my_tiles != 0);
+        if (order_keys) {
+            // Input of the depth-order sort.  Culled surfels are keyed by their range as well (they
+            // emit nothing): a surfel that flips between visible and culled then keeps its place in
+            // the order, which keeps the order repairable from one iteration to the next.
+            order_keys[i] = depth_order_key(g.rho);
             order_vals[i] = (uint32_t)i;
         }
     }

@@ -312,28 +312,121 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
 }
 
 // ---------------------------------------------------------------------------
-// Depth ordering of the surfels: key = depth bits (positive floats order like
-// their bit patterns), culled surfels (tiles_touched == 0) get the largest key
-// so they end up behind every visible one.
+// Temporal re-sort of the depth order.  Between two mapping iterations on the
+// same keyframe a surfel moves by at most ~100 positions in the depth order
+// (tools/order_coherence.py), so instead of three radix passes the previous
+// permutation is repaired:
+//   A. windows of kResortWindow positions of the OLD order are sorted by
+//      (new key, surfel index) with a bitonic network in LDS;
+//   B. windows shifted by half a window are merged (each is two sorted halves);
+//   C. the window edges are compared: the result is a permutation that is sorted
+//      inside every shifted window, so strictly increasing edges <=> the exact
+//      (key, index) order.  Otherwise bit 1 of the iteration's overflow word is set:
+//      the Adam update is skipped on the device and the caller repeats the
+//      iteration with the full radix sort (same protocol as a capacity overflow).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void depth_keys_kernel(int N, const float *__restrict__ depth,
-                                                         const uint32_t *__restrict__ tiles,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                         uint32_t *__restrict__ n_dev)
+constexpr int kResortWindow = 1024;
+constexpr int kResortPer = kResortWindow / 256;   // items per thread at load/store
+constexpr uint32_t kResortFailed = 2u;            // bit in SlsMappingStatus.overflow
+
+// Stages of the bitonic network on s_a[0..kResortWindow), from width K0 up to the full window.
+// Wave w owns the pairs of the slice [w * W/4, (w+1) * W/4) whenever the partner distance j fits
+// in it (j <= W/8): those stages need no workgroup barrier (one wave, LDS in program order);
+// only the three stages with j >= W/4 exchange between slices.  Branch-free compare-exchange.
+template <int K0>
+__device__ __forceinline__ void bitonic_lds(uint64_t *s_a)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *n_dev = (uint32_t)N;
-    if (i >= N) return;
-    keys[i] = depth_order_key(depth[i], tiles[i] != 0);
-    vals[i] = (uint32_t)i;
+    constexpr int kSlicePairs = kResortWindow / 8;      // pairs per wave = half its slice
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = K0; k <= kResortWindow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = j >= kResortWindow / 4;
+            if (cross) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kSlicePairs / 64; ++q) {
+                const int pidx = wave * kSlicePairs + q * 64 + lane;
+                const int i = 2 * pidx - (pidx & (j - 1)), l = i + j;
+                const bool desc = (i & k) != 0 && k != kResortWindow;
+                const uint64_t a = s_a[i], b = s_a[l];
+                const bool sw = (a > b) != desc;
+                s_a[i] = sw ? b : a;
+                s_a[l] = sw ? a : b;
+            }
+            if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t *__restrict__ prev_order,
+                                                          const uint32_t *__restrict__ keys_by_surfel,
+                                                          uint64_t *__restrict__ comp)
+{
+    __shared__ uint64_t s_a[kResortWindow];
+    const int base = blockIdx.x * kResortWindow;
+#pragma unroll
+    for (int q = 0; q < kResortPer; ++q) {
+        const int o = q * 256 + threadIdx.x, pos = base + o;
+        uint64_t c = ~0ull;                        // padding behind the end sorts last
+        if (pos < N) {
+            const uint32_t g = min(prev_order[pos], (uint32_t)(N - 1));   // (memory-safe whatever the caller kept)
+            c = ((uint64_t)keys_by_surfel[g] << 32) | g;
+        }
+        s_a[o] = c;
+    }
+    __syncthreads();
+    bitonic_lds<2>(s_a);
+#pragma unroll
+    for (int q = 0; q < kResortPer; ++q) {
+        const int o = q * 256 + threadIdx.x, pos = base + o;
+        if (pos < N) comp[pos] = s_a[o];
+    }
+}
+
+// window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
+__global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
+                                                           uint32_t *__restrict__ order, uint64_t *__restrict__ edges)
+{
+    __shared__ uint64_t s_a[kResortWindow];
+    const int base = blockIdx.x * kResortWindow - kResortWindow / 2;
+#pragma unroll
+    for (int q = 0; q < kResortPer; ++q) {
+        const int o = q * 256 + threadIdx.x;
+        // the second half is loaded back to front: ascending + descending = bitonic
+        const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
+        const int pos = base + src;
+        s_a[o] = pos < 0 ? 0ull : (pos < N ? comp[pos] : ~0ull);
+    }
+    __syncthreads();
+    bitonic_lds<kResortWindow>(s_a);
+#pragma unroll
+    for (int q = 0; q < kResortPer; ++q) {
+        const int o = q * 256 + threadIdx.x, pos = base + o;
+        if (pos >= 0 && pos < N) order[pos] = (uint32_t)s_a[o];
+    }
+    if (threadIdx.x == 0) {   // smallest / largest real element of the window (it holds at least one)
+        const int lo = base < 0 ? -base : 0, hi = min(kResortWindow, N - base) - 1;
+        edges[2 * blockIdx.x + 0] = s_a[lo];
+        edges[2 * blockIdx.x + 1] = s_a[hi];
+    }
+}
+
+// step C, run by block 0 of the scan's first kernel
+__device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restrict__ edges, uint32_t *__restrict__ flag)
+{
+    for (int b = threadIdx.x; b + 1 < nwin; b += 256)
+        if (edges[2 * b + 1] >= edges[2 * (b + 1)]) atomicOr(flag, kResortFailed);
 }
 
 // A2 on the depth-ordered surfels, level 1: per-block sums of tiles[order[i]]
 __global__ __launch_bounds__(256) void gather_block_sums_kernel(int N, const uint32_t *__restrict__ order,
                                                                 const uint32_t *__restrict__ tiles,
-                                                                uint32_t *__restrict__ block_sums)
+                                                                uint32_t *__restrict__ block_sums, int resort_windows,
+                                                                const uint64_t *__restrict__ resort_edges,
+                                                                uint32_t *__restrict__ fail_flag)
 {
     __shared__ uint32_t s_part[4];
+    if (resort_windows > 0 && blockIdx.x == 0) resort_verify(resort_windows, resort_edges, fail_flag);
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t v = (i < N) ? tiles[order[i]] : 0u;
 #pragma unroll
@@ -400,7 +493,7 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
     if (end > cap) {
         // The buffers are too small: flag it (the caller repeats the iteration with more room) but
         // still fill every slot below cap, so that nothing downstream reads an uninitialised entry.
-        if (overflow) *overflow = 1u;
+        if (overflow) atomicOr(overflow, 1u);
         if (off >= cap) return;
     }
     const int4 rc = rect[g];
@@ -455,7 +548,7 @@ static int bits_for(uint32_t max_value)
 size_t order_scratch_bytes(int N)
 {
     const size_t n = (size_t)(N > 0 ? N : 1);
-    return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n);
+    return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n) + 16;
 }
 
 // where preprocess may write the sort input directly (saves the depth_keys launch)
@@ -470,9 +563,12 @@ void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **k
     *n_dev = *keys + 3 * (size_t)N + nb;
 }
 
+// reuse_order != 0: `order` holds the permutation of the previous iteration (same surfels, same
+// keyframe) and the keys were written by preprocess (keys_prefilled): temporal re-sort, failure is
+// reported in *fail_flag (see above).
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st)
+                            hipStream_t st, int reuse_order, uint32_t *fail_flag)
 {
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
@@ -489,21 +585,38 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     const bool odd = (sort_passes(kDepthKeyBits) & 1) != 0;
     uint32_t *v0 = odd ? vals_tmp : order, *v1 = odd ? order : vals_tmp;
     if (!keys_prefilled) {
-        ScopedTimer tm(T_EMIT_KEYS, st);
-        hipLaunchKernelGGL(depth_keys_kernel, dim3(nb), dim3(256), 0, st, N, depth, tiles, keys, v0, n_dev);
-        SLS_LAUNCH_CHECK("depth_keys_kernel");
-    }
-    int which = 0;
-    int rc = radix_sort_pairs_t<uint32_t>(keys, v0, keys_tmp, v1, n_dev, (uint32_t)N, kDepthKeyBits, sort_scratch,
-                                          sort_bytes, &which, st, nullptr, 0, true);   // only the order is used
-    if (rc) return rc;
-    if ((which != 0) != odd) {
-        set_error("internal: depth order ended in the wrong buffer");
+        set_error("internal: the depth keys are written by preprocess");
         return SLS_E_ARG;
+    }
+    int resort_windows = 0;
+    const uint64_t *resort_edges = nullptr;
+    if (reuse_order && keys_prefilled && fail_flag) {
+        // comp: N u64 over the two temporary arrays (8-byte aligned), edges in the sort's count table
+        uint64_t *comp = (uint64_t *)(((uintptr_t)keys_tmp + 7) & ~(uintptr_t)7);
+        uint64_t *edges = (uint64_t *)(((uintptr_t)sort_scratch + 7) & ~(uintptr_t)7);
+        const int nA = (N + kResortWindow - 1) / kResortWindow;
+        const int nB = (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow;   // windows that hold a real element
+        ScopedTimer tm(T_SORT_SCATTER, st);
+        hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(256), 0, st, N, (const uint32_t *)order,
+                           (const uint32_t *)keys, comp);
+        SLS_LAUNCH_CHECK("resort_sort_kernel");
+        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(256), 0, st, N, (const uint64_t *)comp, order, edges);
+        SLS_LAUNCH_CHECK("resort_merge_kernel");
+        resort_windows = nB;
+        resort_edges = edges;
+    } else {
+        int which = 0;
+        int rc = radix_sort_pairs_t<uint32_t>(keys, v0, keys_tmp, v1, n_dev, (uint32_t)N, kDepthKeyBits, sort_scratch,
+                                              sort_bytes, &which, st, nullptr, 0, true);   // only the order is used
+        if (rc) return rc;
+        if ((which != 0) != odd) {
+            set_error("internal: depth order ended in the wrong buffer");
+            return SLS_E_ARG;
+        }
     }
     ScopedTimer tm(T_SCAN, st);
     hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
-                       block_sums);
+                       block_sums, resort_windows, resort_edges, fail_flag);
     SLS_LAUNCH_CHECK("gather_block_sums_kernel");
     hipLaunchKernelGGL(gather_scan_final_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
                        (const uint32_t *)block_sums, offsets, total_out);

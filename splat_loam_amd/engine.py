@@ -55,6 +55,11 @@ class MappingEngine:
         self._lag_host = torch.zeros((2, 8), dtype=torch.int32).pin_memory()
         self._lag_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self._lag_pending = None          # (slot, camera) of the iteration whose status was not read yet
+        # temporal re-sort: the workspace keeps the depth order of the last iteration; it is repaired
+        # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
+        self.reuse_depth_order = True
+        self._order_cam = None            # id() of the camera whose depth order the workspace holds
+        self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
 
     # views of the flat gradient bucket in the optimiser's group order
     def grad_views(self):
@@ -70,11 +75,13 @@ class MappingEngine:
             nbytes = int(lib.sls_mapping_workspace_bytes(self.N, H, W, self.capacity))
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
+            self._order_cam = None    # the depth order lived in the old workspace
         base = self.workspace.data_ptr()
         return (base + 255) & ~255, self.workspace.numel() - 256
 
-    def _config(self, apply_adam, with_regulariser):
+    def _config(self, apply_adam, with_regulariser, reuse_order=False):
         c, cfg = _abi.SlsMappingConfig(), self.cfg
+        c.reuse_depth_order = 1 if reuse_order else 0
         c.lambda_alpha, c.lambda_normal = cfg.opt_lambda_alpha, cfg.opt_lambda_normal
         c.scaling_max = cfg.opt_scaling_max
         c.scaling_max_penalty = cfg.opt_scaling_max_penalty if with_regulariser else 0.0
@@ -102,7 +109,9 @@ class MappingEngine:
             self.capacity = max(4 * self.N, 1 << 16)
         ws_ptr, ws_bytes = self._ensure_workspace(H, W, self.capacity)
         xyz, scaling, rotation, opacity = self._params()
-        cfg = self._config(apply_adam, with_regulariser)
+        reuse = self.reuse_depth_order and apply_adam and self._order_cam == id(camera)
+        cfg = self._config(apply_adam, with_regulariser, reuse)
+        self._order_cam = id(camera)
         _abi.check(lib.sls_mapping_step(
             C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
             self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
@@ -117,9 +126,11 @@ class MappingEngine:
 
     @staticmethod
     def _parse_status(h):
-        R, overflow = int(h[0].item()) & 0xFFFFFFFF, int(h[1].item())
+        R, flags = int(h[0].item()) & 0xFFFFFFFF, int(h[1].item())
         f = h.view(torch.float32)
-        return {"R": R, "overflow": bool(overflow), "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
+        # "overflow": the iteration is void (Adam was skipped) and must be repeated; bit 0 = the
+        # instance buffers were too small, bit 1 = the repaired depth order was not exact
+        return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2), "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
     @torch.no_grad()
@@ -157,14 +168,18 @@ class MappingEngine:
                 self.t += 1
                 self.last = st
                 return st
-            # grow and repeat the iteration (parameters were not touched)
-            need = st["R"]
-            if sharded:
-                t = torch.tensor([need], dtype=torch.int64, device=self.dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-                need = int(t.item())
-            self.capacity = int(max(need, self.capacity) * self.capacity_factor) + 1024
-            self.workspace = None
+            # repeat the iteration (parameters were not touched): with the full sort, and with more
+            # room if the instance buffers were too small
+            self._order_cam = None
+            self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
+            if sharded or st["too_small"]:
+                need = st["R"]
+                if sharded:
+                    t = torch.tensor([need], dtype=torch.int64, device=self.dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                    need = int(t.item())
+                self.capacity = int(max(need, self.capacity) * self.capacity_factor) + 1024
+                self.workspace = None
 
     def _step_lagged(self, camera):
         slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
@@ -189,9 +204,12 @@ class MappingEngine:
         cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
         cur_void = cur_st is not None and cur_st["overflow"]
         self.t -= 2 if cur_void else 1
-        need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
-        self.capacity = int(need * self.capacity_factor) + 1024
-        self.workspace = None
+        self._order_cam = None                      # repeat with the full sort
+        self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
+        if st["too_small"] or (cur_void and cur_st["too_small"]):
+            need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
+            self.capacity = int(need * self.capacity_factor) + 1024
+            self.workspace = None
         st = self.step(pcam, sync=True)
         if cur_void and redo_current:
             self._step_lagged(cur[1])
