@@ -384,10 +384,16 @@ __global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t 
 }
 
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
+// Also produces level 1 of the scan of tiles_touched (the sums of the four aligned 256-blocks a
+// window covers), which saves the gather_block_sums launch.
 __global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
-                                                           uint32_t *__restrict__ order, uint64_t *__restrict__ edges)
+                                                           uint32_t *__restrict__ order, uint64_t *__restrict__ edges,
+                                                           const uint32_t *__restrict__ tiles,
+                                                           uint32_t *__restrict__ block_sums)
 {
+    static_assert(kResortWindow % 512 == 0, "a shifted window must cover whole 256-blocks");
     __shared__ uint64_t s_a[kResortWindow];
+    __shared__ uint32_t s_part[kResortPer][4];
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2;
 #pragma unroll
     for (int q = 0; q < kResortPer; ++q) {
@@ -402,7 +408,21 @@ __global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t
 #pragma unroll
     for (int q = 0; q < kResortPer; ++q) {
         const int o = q * 256 + threadIdx.x, pos = base + o;
-        if (pos >= 0 && pos < N) order[pos] = (uint32_t)s_a[o];
+        uint32_t v = 0;
+        if (pos >= 0 && pos < N) {
+            const uint32_t g = (uint32_t)s_a[o];
+            order[pos] = g;
+            v = tiles[g];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[q][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kResortPer) {
+        const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
+        if (base + (int)threadIdx.x * 256 >= 0 && blk * 256 < N)
+            block_sums[blk] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
     }
     if (threadIdx.x == 0) {   // smallest / largest real element of the window (it holds at least one)
         const int lo = base < 0 ? -base : 0, hi = min(kResortWindow, N - base) - 1;
@@ -421,12 +441,9 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
 // A2 on the depth-ordered surfels, level 1: per-block sums of tiles[order[i]]
 __global__ __launch_bounds__(256) void gather_block_sums_kernel(int N, const uint32_t *__restrict__ order,
                                                                 const uint32_t *__restrict__ tiles,
-                                                                uint32_t *__restrict__ block_sums, int resort_windows,
-                                                                const uint64_t *__restrict__ resort_edges,
-                                                                uint32_t *__restrict__ fail_flag)
+                                                                uint32_t *__restrict__ block_sums)
 {
     __shared__ uint32_t s_part[4];
-    if (resort_windows > 0 && blockIdx.x == 0) resort_verify(resort_windows, resort_edges, fail_flag);
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t v = (i < N) ? tiles[order[i]] : 0u;
 #pragma unroll
@@ -444,10 +461,13 @@ __global__ __launch_bounds__(256) void gather_scan_final_kernel(int N, const uin
                                                                 const uint32_t *__restrict__ tiles,
                                                                 const uint32_t *__restrict__ block_sums,
                                                                 uint32_t *__restrict__ offsets,
-                                                                uint32_t *__restrict__ total_out)
+                                                                uint32_t *__restrict__ total_out, int resort_windows,
+                                                                const uint64_t *__restrict__ resort_edges,
+                                                                uint32_t *__restrict__ fail_flag)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_pre[4];
+    if (resort_windows > 0 && blockIdx.x == 0) resort_verify(resort_windows, resort_edges, fail_flag);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t pre = 0;
@@ -544,7 +564,7 @@ static int bits_for(uint32_t max_value)
 //   order   : N u32, surfel index at each depth-order position
 //   offsets : N u32, inclusive scan of tiles_touched[order[.]]
 //   total   : device u32 = R
-// scratch: order keys (N) | tmp keys (N) | tmp vals (N) | block sums | N on device | sort scratch
+// scratch: order keys (N) | tmp keys (N) | tmp vals (N) | 2 pad | block sums | N on device | sort scratch
 size_t order_scratch_bytes(int N)
 {
     const size_t n = (size_t)(N > 0 ? N : 1);
@@ -560,7 +580,7 @@ void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **k
     // with an odd number of passes the sorted values land in the "other" buffer, so the
     // identity permutation starts in the scratch buffer and the result ends in `order`
     *vals0 = (sort_passes(kDepthKeyBits) & 1) ? *keys + 2 * (size_t)N : order;
-    *n_dev = *keys + 3 * (size_t)N + nb;
+    *n_dev = *keys + 3 * (size_t)N + 2 + nb;   // (2 words of padding: see launch_depth_order_scan)
 }
 
 // reuse_order != 0: `order` holds the permutation of the previous iteration (same surfels, same
@@ -578,7 +598,7 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     uint32_t *keys = (uint32_t *)scratch;
     uint32_t *keys_tmp = keys + N;
     uint32_t *vals_tmp = keys_tmp + N;
-    uint32_t *block_sums = vals_tmp + N;
+    uint32_t *block_sums = vals_tmp + N + 2;    // padding: the 8-byte aligned u64 view of the temporaries may end one word late
     uint32_t *n_dev = block_sums + nb;          // device copy of N for the count_ptr protocol
     void *sort_scratch = (void *)(n_dev + 32);
     const size_t sort_bytes = sort_scratch_bytes((uint64_t)N);
@@ -600,7 +620,8 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(256), 0, st, N, (const uint32_t *)order,
                            (const uint32_t *)keys, comp);
         SLS_LAUNCH_CHECK("resort_sort_kernel");
-        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(256), 0, st, N, (const uint64_t *)comp, order, edges);
+        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(256), 0, st, N, (const uint64_t *)comp, order, edges,
+                           tiles, block_sums);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
         resort_windows = nB;
         resort_edges = edges;
@@ -615,11 +636,13 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         }
     }
     ScopedTimer tm(T_SCAN, st);
-    hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
-                       block_sums, resort_windows, resort_edges, fail_flag);
-    SLS_LAUNCH_CHECK("gather_block_sums_kernel");
+    if (resort_windows == 0) {   // (the merge kernel of the repair already summed the blocks)
+        hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
+                           block_sums);
+        SLS_LAUNCH_CHECK("gather_block_sums_kernel");
+    }
     hipLaunchKernelGGL(gather_scan_final_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
-                       (const uint32_t *)block_sums, offsets, total_out);
+                       (const uint32_t *)block_sums, offsets, total_out, resort_windows, resort_edges, fail_flag);
     SLS_LAUNCH_CHECK("gather_scan_final_kernel");
     return SLS_OK;
 }
