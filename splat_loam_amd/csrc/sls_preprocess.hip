@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t my_tiles = 0;
     float my_reg = 0.0f;
     if (i == 0 && n_dev) *n_dev = (uint32_t)N;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
     if (i < N) {
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
         int r_out = 0;
         int4 rc = make_int4(0, 0, 0, 0);
         float dep = 0.0f;
@@ -237,8 +237,6 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 q4 = make_float4(cpx, cpy, ex, ey);
             }
         }
-        float4 *r = rec + (size_t)i * kRec4;
-        r[0] = q0; r[1] = q1; r[2] = q2; r[3] = q3; r[4] = q4;
         radii[i] = r_out;
         rect[i] = rc;
         tiles[i] = my_tiles;
@@ -249,6 +247,21 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             // the order, which keeps the order repairable from one iteration to the next.
             order_keys[i] = depth_order_key(g.rho);
             order_vals[i] = (uint32_t)i;
+        }
+    }
+    {   // the 80-byte records leave through LDS so that every store instruction writes 1 KB of
+        // consecutive addresses (a direct store would touch 40 cache lines per instruction)
+        __shared__ float4 s_t[4][64 * kRec4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float4 *t = s_t[wave];
+        t[lane * kRec4 + 0] = q0; t[lane * kRec4 + 1] = q1; t[lane * kRec4 + 2] = q2;
+        t[lane * kRec4 + 3] = q3; t[lane * kRec4 + 4] = q4;
+        __builtin_amdgcn_wave_barrier();
+        const size_t base = ((size_t)blockIdx.x * 256 + (size_t)wave * 64) * kRec4, end = (size_t)N * kRec4;
+#pragma unroll
+        for (int k = 0; k < kRec4; ++k) {
+            const size_t idx = base + (size_t)(k * 64 + lane);
+            if (idx < end) rec[idx] = t[k * 64 + lane];
         }
     }
     if (ra.pen != 0.0f && ra.reg_out) {   // block reduction of the regulariser, one atomic per block

@@ -158,12 +158,13 @@ class MappingEngine:
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
                 self.flag.copy_((self.grads[-1:] > 0).to(torch.int32))
                 self._adam_guarded()
+                # any rank's overflow voids the iteration everywhere: fold it into the local status
+                # word on the device, so that the one status read below is the only sync
+                self.status[1:2].copy_(torch.maximum(self.status[1:2], self.flag))
             if not sync:
                 self.t += 1
                 return None
             st = self._read_status()
-            if sharded:
-                st["overflow"] = bool(int(self.flag.item()))
             if not st["overflow"]:
                 self.t += 1
                 self.last = st
