@@ -111,6 +111,8 @@ CASES = [
     ("dense_near", 4000, 64, 512, dict(range_lo=1.0, range_hi=8.0, scale_lo=0.05, scale_hi=0.5)),
     ("ragged_size", 2500, 40, 200, dict(hfov_deg=120.0)),       # H, W not multiples of the tile, no wrap
     ("narrow_fov", 3000, 64, 512, dict(hfov_deg=90.0)),
+    ("many_tiles", 20000, 128, 8192, {}),                       # 4096 tiles: two-pass tile sort + tile_ranges kernel
+    ("aniso_tilted", 6000, 64, 1024, dict(range_lo=1.5, range_hi=12.0, scale_lo=0.01, scale_hi=0.6, max_tilt_deg=80.0)),   # thin, grazing surfels
 ]
 
 
