@@ -83,6 +83,25 @@ def pmc_traffic(slot, N, H, W):
     return None
 
 
+def pmc_valu(slot, N, H, W):
+    """VALU issue utilisation of the kernel behind a timing slot from the committed SQ counter pass
+    (tools/pmc_sq.sh); null when there is none for this workload."""
+    if (N, H, W) != (500_000, 64, 2048):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json")))
+    if not files:
+        return None
+    try:
+        for name, v in json.load(open(files[-1]))["kernels"].items():
+            if name.startswith(slot):
+                return {"valu_issue_busy": v["valu_issue_busy"], "valu_insts": v["SQ_INSTS_VALU"],
+                        "source": os.path.basename(files[-1])}
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,7 +266,10 @@ def main():
         ach = b / (ms / c * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, N, H, W),
-                    "avg_launch_us": round(ms / c * 1e3, 2), "alg_bytes_per_launch": int(b)}
+                    "avg_launch_us": round(ms / c * 1e3, 2), "alg_bytes_per_launch": int(b),
+                    # the tile kernels are VALU-issue bound, not HBM bound: what the
+                    # SQ counters say about the dominant kernel's real limiter
+                    "valu": pmc_valu(dom, N, H, W)}
         fb_ms = sum(kernels[k][0] / kernels[k][1] for k in ("render_fwd", "render_bwd") if k in kernels)
         if fb_ms > 0:
             fb_b = algorithmic_bytes("render_fwd", N, R, R_eff, P, n_pass) + algorithmic_bytes("render_bwd", N, R, R_eff, P, n_pass)

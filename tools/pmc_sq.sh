@@ -30,3 +30,19 @@ for (k, c) in sorted(agg):
 PY
 done
 cat gpurun_out/pmc_sq.txt
+python - <<'PY'
+import re, json
+rows = {}
+for line in open("gpurun_out/pmc_sq.txt"):
+    m = re.match(r"(\S+(?:<[^>]*>)?)\s+(SQ_\w+)\s+(\d+)", line.strip())
+    if m:
+        rows.setdefault(m.group(1).split("<")[0], {})[m.group(2)] = int(m.group(3))
+out = {"note": "SQ counters per launch, tools/one_iter.py (first 4 iterations of the bench scene); SQ_*_CYCLES / ACTIVE / WAIT "
+               "count SIMD issue slots (4 clocks), SQ_BUSY_CYCLES is summed over the 32 shader engines", "kernels": {}}
+for k, v in rows.items():
+    slots = v["SQ_BUSY_CYCLES"] / 32 * 1024 / 4      # issue slots of all SIMDs during the kernel
+    out["kernels"][k] = {**v, "valu_issue_busy": round(v["SQ_ACTIVE_INST_VALU"] / slots, 3),
+                         "valu_slots_per_inst": round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"], 3),
+                         "avg_waves_per_simd": round(v["SQ_WAVE_CYCLES"] / slots, 2)}
+json.dump(out, open("gpurun_out/pmc_sq.json", "w"), indent=1)
+PY
