@@ -180,6 +180,10 @@ typedef struct SlsMappingConfig {
                                 * SAME keyframe and surfel set: repair it (windowed re-sort + verification)
                                 * instead of sorting from scratch.  If the repair does not reach the exact
                                 * order, bit 1 of status.overflow is set, Adam is skipped, repeat with 0. */
+    int32_t keep_grads;   /* apply_adam = 1 only: 1 = also write the gradients to `grads` (with 0 they are
+                           * consumed where they are produced and `grads` is left untouched) */
+    int32_t workspace_ready; /* 0 on the first call with a (new) workspace, 1 afterwards: the call keeps the
+                              * accumulation buffers inside the workspace zeroed for its successor */
     double beta1, beta2, eps;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {

@@ -30,7 +30,7 @@ class SlsMappingConfig(C.Structure):
         ("lambda_alpha", C.c_float), ("lambda_normal", C.c_float), ("scaling_max", C.c_float),
         ("scaling_max_penalty", C.c_float), ("depth_ratio", C.c_float),
         ("lr_xyz", C.c_float), ("lr_opacity", C.c_float), ("lr_scaling", C.c_float), ("lr_rotation", C.c_float),
-        ("apply_adam", C.c_int32), ("reuse_depth_order", C.c_int32),
+        ("apply_adam", C.c_int32), ("reuse_depth_order", C.c_int32), ("keep_grads", C.c_int32), ("workspace_ready", C.c_int32),
         ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
     ]
 

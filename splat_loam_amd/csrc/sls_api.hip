@@ -77,16 +77,8 @@ struct AdamArgs {
     SlsAdamGroup g[kMaxAdamGroups];
     int64_t unit_end[kMaxAdamGroups];   // prefix of ceil(numel/4) units
     int ngroups;
-    float w1, b2, w2, eps, bc2_sqrt, bc1;
+    AdamCoef c;
 };
-
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float step_size, const AdamArgs &a)
-{
-    m = m + (g - m) * a.w1;
-    v = v * a.b2 + (a.w2 * g) * g;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    p = p - step_size * (m / denom);
-}
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units,
                                                    const uint32_t *__restrict__ skip_flag)
@@ -99,7 +91,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_uni
             if (k < a.ngroups - 1 && u >= a.unit_end[k]) gi = k + 1;
         const SlsAdamGroup grp = a.g[gi];
         const int64_t e0 = (u - (gi ? a.unit_end[gi - 1] : 0)) * 4;
-        const float step_size = grp.lr / a.bc1;
+        const float step_size = grp.lr / a.c.bc1;
         const bool vec = (e0 + 4 <= grp.numel) &&
                          ((((uintptr_t)grp.param | (uintptr_t)grp.grad | (uintptr_t)grp.exp_avg | (uintptr_t)grp.exp_avg_sq) & 15) == 0);
         if (vec) {
@@ -107,17 +99,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_uni
             const float4 g = *reinterpret_cast<const float4 *>(grp.grad + e0);
             float4 m = *reinterpret_cast<float4 *>(grp.exp_avg + e0);
             float4 v = *reinterpret_cast<float4 *>(grp.exp_avg_sq + e0);
-            adam_one(p.x, g.x, m.x, v.x, step_size, a);
-            adam_one(p.y, g.y, m.y, v.y, step_size, a);
-            adam_one(p.z, g.z, m.z, v.z, step_size, a);
-            adam_one(p.w, g.w, m.w, v.w, step_size, a);
+            adam_one(p.x, g.x, m.x, v.x, step_size, a.c);
+            adam_one(p.y, g.y, m.y, v.y, step_size, a.c);
+            adam_one(p.z, g.z, m.z, v.z, step_size, a.c);
+            adam_one(p.w, g.w, m.w, v.w, step_size, a.c);
             *reinterpret_cast<float4 *>(grp.param + e0) = p;
             *reinterpret_cast<float4 *>(grp.exp_avg + e0) = m;
             *reinterpret_cast<float4 *>(grp.exp_avg_sq + e0) = v;
         } else {
             for (int64_t e = e0; e < e0 + 4 && e < grp.numel; ++e) {
                 float p = grp.param[e], m = grp.exp_avg[e], v = grp.exp_avg_sq[e];
-                adam_one(p, grp.grad[e], m, v, step_size, a);
+                adam_one(p, grp.grad[e], m, v, step_size, a.c);
                 grp.param[e] = p; grp.exp_avg[e] = m; grp.exp_avg_sq[e] = v;
             }
         }
@@ -246,12 +238,7 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
     }
     for (int i = ngroups; i < kMaxAdamGroups; ++i) a.unit_end[i] = units;
     a.ngroups = ngroups;
-    a.w1 = (float)(1.0 - beta1);
-    a.b2 = (float)beta2;
-    a.w2 = (float)(1.0 - beta2);
-    a.eps = (float)eps;
-    a.bc1 = (float)(1.0 - pow(beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.c = make_adam_coef(beta1, beta2, eps, step);
     if (units == 0) return SLS_OK;
     int64_t blocks = (units + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond

@@ -1,6 +1,7 @@
 // sls_common.hpp — shared by the HIP translation units of libsls_hip.so.
 // gfx950 only: wave = 64 lanes, DPP row_bcast available (GFX9 family).
 #pragma once
+#include <cmath>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -227,6 +228,40 @@ __host__ __device__ inline uint32_t depth_order_key(float range)
     const uint32_t k = b > kBase ? b - kBase : 0u;
     return k < kMax ? k : kMax;
 }
+
+// torch.optim.Adam update of one element (no weight decay, no amsgrad); shared by adam_kernel and
+// by the update fused into preprocess_bwd so that both produce the same bits.
+struct AdamCoef {
+    float w1, b2, w2, eps, bc2_sqrt, bc1;   // 1-beta1, beta2, 1-beta2, eps, sqrt(1-beta2^t), 1-beta1^t
+};
+inline AdamCoef make_adam_coef(double beta1, double beta2, double eps, int64_t step)
+{
+    AdamCoef c;
+    c.w1 = (float)(1.0 - beta1);
+    c.b2 = (float)beta2;
+    c.w2 = (float)(1.0 - beta2);
+    c.eps = (float)eps;
+    c.bc1 = (float)(1.0 - pow(beta1, (double)step));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    return c;
+}
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float step_size, const AdamCoef &a)
+{
+    m = m + (g - m) * a.w1;
+    v = v * a.b2 + (a.w2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - step_size * (m / denom);
+}
+// Adam fused into preprocess_bwd (one keyframe per step, sls_mapping_step): moments in the flat
+// [xyz 3N | opacity N | scaling 2N | rotation 4N] layout of the gradient bucket.
+struct AdamFuse {
+    int enabled, write_grads;
+    int clear_grec;                       // zero every gradient record after reading it (ready for the next iteration)
+    AdamCoef c;
+    float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
+    float *exp_avg, *exp_avg_sq;          // 10*N floats each
+    const uint32_t *skip_flag;            // the iteration's overflow word: non-zero -> no update
+};
 
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8
 // (speed only, never correctness); give each XCD a contiguous run of tiles so

@@ -19,7 +19,7 @@ void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **k
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
                           const float *scales, const float *rots, const float *opac, const int32_t *radii,
                           const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
-                          hipStream_t st);
+                          hipStream_t st, const AdamFuse *fuse = nullptr);
 size_t sort_scratch_bytes(uint64_t cap);
 size_t order_scratch_bytes(int N);
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
@@ -227,7 +227,9 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const uint32_t cap = (uint32_t)R_capacity;
     if (allmap_out) *allmap_out = w.allmap;
     SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
-    {   // everything else that accumulates: the tiles' consumed counters and the gradient records
+    if (!cfg->workspace_ready) {
+        // first use of this workspace: the gradient records must start from zero; afterwards the backward
+        // of the projection leaves them zeroed behind itself (no 64*N-byte memset per iteration)
         ScopedTimer tm(T_GREC_MEMSET, st);
         SLS_HIP_CHECK(hipMemsetAsync(w.tile_consumed, 0, w.zero_bytes, st));
     }
@@ -249,7 +251,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
-                           w.tile_consumed, st, true, w.block_masks);
+                           nullptr, st, true, w.block_masks);   // (nobody reads the consumed counters here)
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
@@ -262,11 +264,26 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
+    // ---- backward of the projection + optimiser -------------------------------------------
+    // One keyframe per step: the Adam update is applied to each surfel right where its gradient is
+    // produced (no gradient bucket round trip, no second pass over the parameters).
+    AdamFuse fuse;
+    memset(&fuse, 0, sizeof(fuse));
+    fuse.clear_grec = 1;
+    const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
+    if (cfg->apply_adam && aligned) {
+        fuse.enabled = 1;
+        fuse.write_grads = cfg->keep_grads;
+        fuse.c = make_adam_coef(cfg->beta1, cfg->beta2, cfg->eps, adam_step);
+        fuse.lr_xyz = cfg->lr_xyz; fuse.lr_opacity = cfg->lr_opacity;
+        fuse.lr_scaling = cfg->lr_scaling; fuse.lr_rotation = cfg->lr_rotation;
+        fuse.exp_avg = exp_avg; fuse.exp_avg_sq = exp_avg_sq;
+        fuse.skip_flag = &status_dev->overflow;
+    }
     rc = launch_preprocess_bwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, N, xyz, scaling_raw, rotation_raw,
-                               opacity_raw, w.radii, w.grec, g_xyz, g_sc, g_rot, g_op, st);
+                               opacity_raw, w.radii, w.grec, g_xyz, g_sc, g_rot, g_op, st, &fuse);
     if (rc) return rc;
-    // ---- optimiser -------------------------------------------------------------------
-    if (cfg->apply_adam) {
+    if (cfg->apply_adam && !fuse.enabled) {
         SlsAdamGroup grp[4];
         memset(grp, 0, sizeof(grp));
         float *params[4] = { xyz, opacity_raw, scaling_raw, rotation_raw };

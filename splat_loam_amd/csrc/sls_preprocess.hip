@@ -7,6 +7,7 @@
 // exactly-rounded operations (include/sls_det_math.h) so that every INTEGER
 // this stage emits — tile rectangle, tiles_touched, radii, depth-key bits —
 // is reproducible bit for bit by a CPU checker.
+#include <cstring>
 #include "sls_common.hpp"
 #include "../../include/sls_det_math.h"
 
@@ -284,11 +285,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
 // With ra.raw the inputs are raw parameters, the activations are re-applied here
 // and the outputs are gradients w.r.t. the RAW parameters (exp / sigmoid /
 // normalize backward + the scale regulariser's gradient), opacity needed too.
+// With af.enabled (raw mode only) the Adam update of the surfel's ten parameters follows at once:
+// the gradients never travel through HBM (af.write_grads = 0) and no separate optimiser launch
+// reads the parameters again.  The parameter pointers are therefore NOT restrict-qualified.
 __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
-    DevCam cam, RegArgs ra, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
-    const float4 *__restrict__ rots, const float *__restrict__ opac, const int *__restrict__ radii,
-    const float4 *__restrict__ grec, float *__restrict__ dmeans, float2 *__restrict__ dscales,
-    float4 *__restrict__ drots, float *__restrict__ dopac)
+    DevCam cam, RegArgs ra, AdamFuse af, int N, float *means, float2 *scales, float4 *rots, float *opac,
+    const int *__restrict__ radii, float4 *grec, float *__restrict__ dmeans,
+    float2 *__restrict__ dscales, float4 *__restrict__ drots, float *__restrict__ dopac)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -296,17 +299,23 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float2 ds = make_float2(0, 0);
     float4 dq = make_float4(0, 0, 0, 0);
     float dop = 0.0f;
-    float2 s = scales[i];
+    const float2 s_in = scales[i];
+    float2 s = s_in;
     const float4 q_in = rots[i];
     float4 q = q_in;
-    float o = ra.raw ? opac[i] : 0.0f;
+    const float o_in = ra.raw ? opac[i] : 0.0f;
+    float o = o_in;
     activate(ra, s, q, o);
+    const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
     if (radii[i] > 0) {
-        const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
         SurfelGeom g;
         surfel_geom(cam, m, s, q, g);
         const float4 g0 = grec[(size_t)i * 4 + 0], g1 = grec[(size_t)i * 4 + 1];
         const float4 g2 = grec[(size_t)i * 4 + 2], g3 = grec[(size_t)i * 4 + 3];
+        if (af.clear_grec) {   // only records of visible surfels are ever touched by the tile kernel
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            grec[(size_t)i * 4 + 0] = z; grec[(size_t)i * 4 + 1] = z; grec[(size_t)i * 4 + 2] = z; grec[(size_t)i * 4 + 3] = z;
+        }
         const float gHu[3] = { g0.x, g0.y, g0.z }, gHv[3] = { g1.x, g1.y, g1.z }, gn[3] = { g2.x, g2.y, g2.z };
         const float gnpv = g0.w, grhoc = g1.w, go = g2.w, Su = g3.x, Sv = g3.y, gcpx = g3.z, gcpy = g3.w;
         float dc[3];
@@ -366,10 +375,41 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         dq.x = (dq.x - dd * q.x) * inv; dq.y = (dq.y - dd * q.y) * inv;
         dq.z = (dq.z - dd * q.z) * inv; dq.w = (dq.w - dd * q.w) * inv;
     }
-    dmeans[3 * i] = dm[0]; dmeans[3 * i + 1] = dm[1]; dmeans[3 * i + 2] = dm[2];
-    dscales[i] = ds;
-    drots[i] = dq;
-    dopac[i] = dop;
+    if (!af.enabled || af.write_grads) {
+        dmeans[3 * i] = dm[0]; dmeans[3 * i + 1] = dm[1]; dmeans[3 * i + 2] = dm[2];
+        dscales[i] = ds;
+        drots[i] = dq;
+        dopac[i] = dop;
+    }
+    if (af.enabled && *af.skip_flag == 0u) {
+        // moments in the bucket layout [xyz 3N | opacity N | scaling 2N | rotation 4N]
+        const size_t n = (size_t)N, ix = 3 * (size_t)i, io = 3 * n + i, is = 4 * n + 2 * (size_t)i, ir = 6 * n + 4 * (size_t)i;
+        float *M = af.exp_avg, *V = af.exp_avg_sq;
+        float p, mm, vv;
+        const float st_x = af.lr_xyz / af.c.bc1, st_o = af.lr_opacity / af.c.bc1;
+        const float st_s = af.lr_scaling / af.c.bc1, st_r = af.lr_rotation / af.c.bc1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p = m[k]; mm = M[ix + k]; vv = V[ix + k];
+            adam_one(p, dm[k], mm, vv, st_x, af.c);
+            means[3 * i + k] = p; M[ix + k] = mm; V[ix + k] = vv;
+        }
+        p = o_in; mm = M[io]; vv = V[io];
+        adam_one(p, dop, mm, vv, st_o, af.c);
+        opac[i] = p; M[io] = mm; V[io] = vv;
+        float2 ps = s_in, ms = *reinterpret_cast<float2 *>(M + is), vs = *reinterpret_cast<float2 *>(V + is);
+        adam_one(ps.x, ds.x, ms.x, vs.x, st_s, af.c);
+        adam_one(ps.y, ds.y, ms.y, vs.y, st_s, af.c);
+        scales[i] = ps; *reinterpret_cast<float2 *>(M + is) = ms; *reinterpret_cast<float2 *>(V + is) = vs;
+        // (4N + 2i and 6N + 4i floats: 8- resp. 16-byte aligned whenever the bucket is 16-byte aligned and N is even;
+        //  the launcher falls back to the separate optimiser kernel otherwise)
+        float4 pq = q_in, mq = *reinterpret_cast<float4 *>(M + ir), vq = *reinterpret_cast<float4 *>(V + ir);
+        adam_one(pq.x, dq.x, mq.x, vq.x, st_r, af.c);
+        adam_one(pq.y, dq.y, mq.y, vq.y, st_r, af.c);
+        adam_one(pq.z, dq.z, mq.z, vq.z, st_r, af.c);
+        adam_one(pq.w, dq.w, mq.w, vq.w, st_r, af.c);
+        rots[i] = pq; *reinterpret_cast<float4 *>(M + ir) = mq; *reinterpret_cast<float4 *>(V + ir) = vq;
+    }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(DevCam cam, int N, const float *__restrict__ means,
@@ -407,14 +447,19 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
                           const float *scales, const float *rots, const float *opac, const int32_t *radii,
                           const float *grec, float *dmeans, float *dscales, float *drots, float *dopac,
-                          hipStream_t st)
+                          hipStream_t st, const AdamFuse *fuse)
 {
     const int nb = (N + 255) / 256;
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = nullptr;
+    AdamFuse af;
+    memset(&af, 0, sizeof(af));
+    if (fuse) af = *fuse;
     ScopedTimer tm(T_PREPROCESS_BWD, st);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
-                       (const float4 *)rots, opac, radii, (const float4 *)grec, dmeans, (float2 *)dscales,
+    // (parameters are only written when af.enabled, which the caller sets for its own mutable tensors)
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, af, N, const_cast<float *>(means),
+                       (float2 *)const_cast<float *>(scales), (float4 *)const_cast<float *>(rots),
+                       const_cast<float *>(opac), radii, (float4 *)const_cast<float *>(grec), dmeans, (float2 *)dscales,
                        (float4 *)drots, dopac);
     SLS_LAUNCH_CHECK("preprocess_bwd_kernel");
     return SLS_OK;

@@ -58,10 +58,15 @@ class MappingEngine:
         # temporal re-sort: the workspace keeps the depth order of the last iteration; it is repaired
         # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
         self.reuse_depth_order = True
+        # single GPU: Adam is applied inside the backward; the flat gradient bucket is only filled when asked
+        # for (the reference drops its gradients right after optimizer.step() as well)
+        self.keep_grads = False
+        self._ws_ready = False
         self._order_cam = None            # id() of the camera whose depth order the workspace holds
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
 
-    # views of the flat gradient bucket in the optimiser's group order
+    # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
+    # when keep_grads is set; keyframe-parallel mode always fills and all-reduces it)
     def grad_views(self):
         N = self.N
         g = self.grads
@@ -76,12 +81,16 @@ class MappingEngine:
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
             self._order_cam = None    # the depth order lived in the old workspace
+            self._ws_ready = False
         base = self.workspace.data_ptr()
         return (base + 255) & ~255, self.workspace.numel() - 256
 
     def _config(self, apply_adam, with_regulariser, reuse_order=False):
         c, cfg = _abi.SlsMappingConfig(), self.cfg
         c.reuse_depth_order = 1 if reuse_order else 0
+        c.keep_grads = 1 if self.keep_grads else 0
+        c.workspace_ready = 1 if self._ws_ready else 0
+        self._ws_ready = True
         c.lambda_alpha, c.lambda_normal = cfg.opt_lambda_alpha, cfg.opt_lambda_normal
         c.scaling_max = cfg.opt_scaling_max
         c.scaling_max_penalty = cfg.opt_scaling_max_penalty if with_regulariser else 0.0

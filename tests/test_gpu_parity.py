@@ -405,6 +405,7 @@ def test_mapping_engine_matches_unfused_step(device):
     b = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"] * 1.7, sc["opac"], device=str(device))
     a.training_setup(fused=False)
     eng = MappingEngine(b, cfg)
+    eng.keep_grads = True          # the test looks at the gradient bucket
     eng.capacity = 2048            # far too small: forces the overflow / retry path
     names = ("_xyz", "_scaling", "_rotation", "_opacity")
     init = {k: getattr(a, k).detach().clone() for k in names}
