@@ -16,3 +16,11 @@ eng = MappingEngine(model, MappingConfig())
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     st = eng.step(cam)
 print(st)
+# calibration kernel for tools/pmc_traffic.sh: one stand-alone fused Adam step over 10*N floats
+# (16 B read + 12 B written per element, known exactly)
+from splat_loam_amd.optim import FusedAdam
+p = torch.nn.Parameter(torch.zeros(10 * N, device="cuda:0"))
+p.grad = torch.ones_like(p)
+opt = FusedAdam([{"params": [p], "lr": 1e-3, "name": "calib"}], lr=1e-3, eps=1e-15)
+opt.step()
+torch.cuda.synchronize()
