@@ -172,6 +172,7 @@ int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_dept
  * update is skipped (the caller grows the capacity and repeats the iteration).
  * status_dev lives in DEVICE memory; read it after the stream has drained.
  * *allmap_out (optional) receives the address of allmap inside the workspace. */
+struct SlsMappingStatus;
 typedef struct SlsMappingConfig {
     float lambda_alpha, lambda_normal, scaling_max, scaling_max_penalty, depth_ratio;
     float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
@@ -185,6 +186,9 @@ typedef struct SlsMappingConfig {
     int32_t workspace_ready; /* 0 on the first call with a (new) workspace, 1 afterwards: the call keeps the
                               * accumulation buffers inside the workspace zeroed for its successor */
     double beta1, beta2, eps;
+    struct SlsMappingStatus *status_mirror; /* optional, HOST-visible (pinned, device-mapped) memory: the last
+                              * kernel of the iteration copies *status_dev there, so the caller can read the
+                              * status after an event/stream wait without enqueuing a device->host copy */
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */

@@ -261,6 +261,10 @@ struct AdamFuse {
     float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
     float *exp_avg, *exp_avg_sq;          // 10*N floats each
     const uint32_t *skip_flag;            // the iteration's overflow word: non-zero -> no update
+    // optional: the iteration's status block (8 words, complete before this last kernel starts) is
+    // copied to a host-visible mirror by thread 0, which saves the device->host copy kernel
+    const uint32_t *status_src;
+    uint32_t *status_mirror;
 };
 
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8

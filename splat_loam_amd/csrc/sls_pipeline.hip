@@ -270,6 +270,9 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     AdamFuse fuse;
     memset(&fuse, 0, sizeof(fuse));
     fuse.clear_grec = 1;
+    static_assert(sizeof(SlsMappingStatus) == 32, "the mirror copy moves 8 words");
+    fuse.status_src = (const uint32_t *)status_dev;
+    fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
     if (cfg->apply_adam && aligned) {
         fuse.enabled = 1;

@@ -294,6 +294,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float2 *__restrict__ dscales, float4 *__restrict__ drots, float *__restrict__ dopac)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && af.status_mirror) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);
+    }
     if (i >= N) return;
     float dm[3] = { 0, 0, 0 };
     float2 ds = make_float2(0, 0);

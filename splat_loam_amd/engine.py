@@ -62,6 +62,8 @@ class MappingEngine:
         # for (the reference drops its gradients right after optimizer.step() as well)
         self.keep_grads = False
         self._ws_ready = False
+        import os
+        self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
         self._order_cam = None            # id() of the camera whose depth order the workspace holds
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
 
@@ -108,7 +110,7 @@ class MappingEngine:
                 raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
         return ps
 
-    def _enqueue(self, camera, apply_adam, with_regulariser, status=None):
+    def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None):
         lib = _abi.lib()
         H, W = int(camera.image_height), int(camera.image_width)
         settings = GaussianRasterizationSettings(H, W, 1.0, camera.world_view_transform, camera.projection_matrix)
@@ -120,6 +122,7 @@ class MappingEngine:
         xyz, scaling, rotation, opacity = self._params()
         reuse = self.reuse_depth_order and apply_adam and self._order_cam == id(camera)
         cfg = self._config(apply_adam, with_regulariser, reuse)
+        cfg.status_mirror = mirror
         self._order_cam = id(camera)
         _abi.check(lib.sls_mapping_step(
             C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
@@ -193,9 +196,14 @@ class MappingEngine:
 
     def _step_lagged(self, camera):
         slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
-        self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot])
+        if self.status_mirror:
+            # the iteration's last kernel mirrors the status block into pinned host memory: no copy kernel
+            self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot],
+                          mirror=self._lag_host[slot].data_ptr())
+        else:
+            self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot])
+            self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
         self.t += 1
-        self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
         self._lag_ev[slot].record(torch.cuda.current_stream(self.dev))
         prev, self._lag_pending = self._lag_pending, (slot, camera)
         return None if prev is None else self._lag_collect(prev, redo_current=True)
