@@ -330,30 +330,60 @@ constexpr int kResortPer = kResortWindow / 256;   // items per thread at load/st
 constexpr uint32_t kResortFailed = 2u;            // bit in SlsMappingStatus.overflow
 
 // Stages of the bitonic network on s_a[0..kResortWindow), from width K0 up to the full window.
-// Wave w owns the pairs of the slice [w * W/4, (w+1) * W/4) whenever the partner distance j fits
-// in it (j <= W/8): those stages need no workgroup barrier (one wave, LDS in program order);
-// only the three stages with j >= W/4 exchange between slices.  Branch-free compare-exchange.
+//   * partner distances j >= 4 go through LDS; wave w owns the pairs of the slice
+//     [w * W/4, (w+1) * W/4) whenever j fits in it (j <= W/8): those stages need no workgroup
+//     barrier (one wave, LDS in program order), only the stages with j >= W/4 exchange between slices;
+//   * the last two stages of every width (j = 2, 1) run in registers on the 4 consecutive
+//     elements a thread owns (two 128-bit LDS accesses instead of two bank-conflicting stages).
+// Branch-free compare-exchange throughout.
+__device__ __forceinline__ void cx64(uint64_t &a, uint64_t &b, bool desc)
+{
+    const bool sw = (a > b) != desc;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
 template <int K0>
 __device__ __forceinline__ void bitonic_lds(uint64_t *s_a)
 {
+    static_assert(kResortWindow == 1024, "4 elements per thread, 256 threads");
     constexpr int kSlicePairs = kResortWindow / 8;      // pairs per wave = half its slice
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = K0; k <= kResortWindow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int j = k >> 1; j >= 4; j >>= 1) {
             const bool cross = j >= kResortWindow / 4;
             if (cross) __syncthreads();
+            constexpr int kQ = kSlicePairs / 64;
+            int ii[kQ];
+            uint64_t a[kQ], b[kQ];
 #pragma unroll
-            for (int q = 0; q < kSlicePairs / 64; ++q) {
+            for (int q = 0; q < kQ; ++q) {   // all loads first: one LDS round trip per stage
                 const int pidx = wave * kSlicePairs + q * 64 + lane;
-                const int i = 2 * pidx - (pidx & (j - 1)), l = i + j;
-                const bool desc = (i & k) != 0 && k != kResortWindow;
-                const uint64_t a = s_a[i], b = s_a[l];
-                const bool sw = (a > b) != desc;
-                s_a[i] = sw ? b : a;
-                s_a[l] = sw ? a : b;
+                ii[q] = 2 * pidx - (pidx & (j - 1));
+                a[q] = s_a[ii[q]];
+                b[q] = s_a[ii[q] + j];
+            }
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                cx64(a[q], b[q], (ii[q] & k) != 0 && k != kResortWindow);
+                s_a[ii[q]] = a[q];
+                s_a[ii[q] + j] = b[q];
             }
             if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
+        // j = 2, 1 on elements 4t .. 4t+3 (inside the thread's own wave slice)
+        ulonglong2 *v = reinterpret_cast<ulonglong2 *>(s_a) + 2 * threadIdx.x;
+        ulonglong2 p0 = v[0], p1 = v[1];
+        uint64_t e0 = p0.x, e1 = p0.y, e2 = p1.x, e3 = p1.y;
+        const bool desc = ((4 * (int)threadIdx.x) & k) != 0 && k != kResortWindow;
+        if (k >= 4) {
+            cx64(e0, e2, desc); cx64(e1, e3, desc);
+            cx64(e0, e1, desc); cx64(e2, e3, desc);
+        } else {   // k == 2: pairs (4t, 4t+1) ascending, (4t+2, 4t+3) descending
+            cx64(e0, e1, false); cx64(e2, e3, true);
+        }
+        v[0] = make_ulonglong2(e0, e1);
+        v[1] = make_ulonglong2(e2, e3);
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 }
@@ -362,7 +392,7 @@ __global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t 
                                                           const uint32_t *__restrict__ keys_by_surfel,
                                                           uint64_t *__restrict__ comp)
 {
-    __shared__ uint64_t s_a[kResortWindow];
+    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
     const int base = blockIdx.x * kResortWindow;
 #pragma unroll
     for (int q = 0; q < kResortPer; ++q) {
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t
                                                            uint32_t *__restrict__ block_sums)
 {
     static_assert(kResortWindow % 512 == 0, "a shifted window must cover whole 256-blocks");
-    __shared__ uint64_t s_a[kResortWindow];
+    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
     __shared__ uint32_t s_part[kResortPer][4];
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2;
 #pragma unroll
