@@ -326,7 +326,6 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
 //      iteration with the full radix sort (same protocol as a capacity overflow).
 // ---------------------------------------------------------------------------
 constexpr int kResortWindow = 1024;
-constexpr int kResortPer = kResortWindow / 256;   // items per thread at load/store
 constexpr uint32_t kResortFailed = 2u;            // bit in SlsMappingStatus.overflow
 
 // Stages of the bitonic network on s_a[0..kResortWindow), from width K0 up to the full window.
@@ -342,61 +341,49 @@ __device__ __forceinline__ void cx64(uint64_t &a, uint64_t &b, bool desc)
     const uint64_t lo = sw ? b : a, hi = sw ? a : b;
     a = lo; b = hi;
 }
+// The network is latency bound (a few LDS round trips per stage, 46 dependent stages), so a
+// window gets kResortThreads = 512 threads (two elements, one pair each): twice the waves per
+// SIMD of a 256-thread block hide each other's LDS latency.
+constexpr int kResortThreads = 512;
+constexpr int kResortE = kResortWindow / kResortThreads;   // consecutive elements a thread owns (2)
 template <int K0>
 __device__ __forceinline__ void bitonic_lds(uint64_t *s_a)
 {
-    static_assert(kResortWindow == 1024, "4 elements per thread, 256 threads");
-    constexpr int kSlicePairs = kResortWindow / 8;      // pairs per wave = half its slice
+    static_assert(kResortE == 2, "one pair per thread");
+    constexpr int kWaves = kResortThreads / 64, kSlice = kResortWindow / kWaves;   // elements per wave slice
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pidx = wave * (kSlice / 2) + lane;
     for (int k = K0; k <= kResortWindow; k <<= 1) {
-        for (int j = k >> 1; j >= 4; j >>= 1) {
-            const bool cross = j >= kResortWindow / 4;
+        for (int j = k >> 1; j >= 2; j >>= 1) {
+            const bool cross = j >= kSlice;
             if (cross) __syncthreads();
-            constexpr int kQ = kSlicePairs / 64;
-            int ii[kQ];
-            uint64_t a[kQ], b[kQ];
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) {   // all loads first: one LDS round trip per stage
-                const int pidx = wave * kSlicePairs + q * 64 + lane;
-                ii[q] = 2 * pidx - (pidx & (j - 1));
-                a[q] = s_a[ii[q]];
-                b[q] = s_a[ii[q] + j];
-            }
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) {
-                cx64(a[q], b[q], (ii[q] & k) != 0 && k != kResortWindow);
-                s_a[ii[q]] = a[q];
-                s_a[ii[q] + j] = b[q];
-            }
+            const int i = 2 * pidx - (pidx & (j - 1));
+            uint64_t a = s_a[i], b = s_a[i + j];
+            cx64(a, b, (i & k) != 0 && k != kResortWindow);
+            s_a[i] = a;
+            s_a[i + j] = b;
             if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
-        // j = 2, 1 on elements 4t .. 4t+3 (inside the thread's own wave slice)
-        ulonglong2 *v = reinterpret_cast<ulonglong2 *>(s_a) + 2 * threadIdx.x;
-        ulonglong2 p0 = v[0], p1 = v[1];
-        uint64_t e0 = p0.x, e1 = p0.y, e2 = p1.x, e3 = p1.y;
-        const bool desc = ((4 * (int)threadIdx.x) & k) != 0 && k != kResortWindow;
-        if (k >= 4) {
-            cx64(e0, e2, desc); cx64(e1, e3, desc);
-            cx64(e0, e1, desc); cx64(e2, e3, desc);
-        } else {   // k == 2: pairs (4t, 4t+1) ascending, (4t+2, 4t+3) descending
-            cx64(e0, e1, false); cx64(e2, e3, true);
-        }
+        // j = 1 on the two consecutive elements the thread owns (one 128-bit access each way)
+        ulonglong2 *v = reinterpret_cast<ulonglong2 *>(s_a) + threadIdx.x;
+        const ulonglong2 pv = v[0];
+        uint64_t e0 = pv.x, e1 = pv.y;
+        cx64(e0, e1, ((2 * (int)threadIdx.x) & k) != 0 && k != kResortWindow);
         v[0] = make_ulonglong2(e0, e1);
-        v[1] = make_ulonglong2(e2, e3);
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t *__restrict__ prev_order,
-                                                          const uint32_t *__restrict__ keys_by_surfel,
-                                                          uint64_t *__restrict__ comp)
+__global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, const uint32_t *__restrict__ prev_order,
+                                                                     const uint32_t *__restrict__ keys_by_surfel,
+                                                                     uint64_t *__restrict__ comp)
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
     const int base = blockIdx.x * kResortWindow;
 #pragma unroll
-    for (int q = 0; q < kResortPer; ++q) {
-        const int o = q * 256 + threadIdx.x, pos = base + o;
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
         uint64_t c = ~0ull;                        // padding behind the end sorts last
         if (pos < N) {
             const uint32_t g = min(prev_order[pos], (uint32_t)(N - 1));   // (memory-safe whatever the caller kept)
@@ -407,8 +394,8 @@ __global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t 
     __syncthreads();
     bitonic_lds<2>(s_a);
 #pragma unroll
-    for (int q = 0; q < kResortPer; ++q) {
-        const int o = q * 256 + threadIdx.x, pos = base + o;
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
         if (pos < N) comp[pos] = s_a[o];
     }
 }
@@ -416,18 +403,19 @@ __global__ __launch_bounds__(256) void resort_sort_kernel(int N, const uint32_t 
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
 // Also produces level 1 of the scan of tiles_touched (the sums of the four aligned 256-blocks a
 // window covers), which saves the gather_block_sums launch.
-__global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
-                                                           uint32_t *__restrict__ order, uint64_t *__restrict__ edges,
-                                                           const uint32_t *__restrict__ tiles,
-                                                           uint32_t *__restrict__ block_sums)
+__global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
+                                                                      uint32_t *__restrict__ order,
+                                                                      uint64_t *__restrict__ edges,
+                                                                      const uint32_t *__restrict__ tiles,
+                                                                      uint32_t *__restrict__ block_sums)
 {
-    static_assert(kResortWindow % 512 == 0, "a shifted window must cover whole 256-blocks");
+    static_assert(kResortWindow == 1024 && kResortThreads == 512, "two 256-blocks of positions per pass of the store loop");
     __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
-    __shared__ uint32_t s_part[kResortPer][4];
+    __shared__ uint32_t s_part[4][4];          // [256-block of the window][wave inside it]
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2;
 #pragma unroll
-    for (int q = 0; q < kResortPer; ++q) {
-        const int o = q * 256 + threadIdx.x;
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x;
         // the second half is loaded back to front: ascending + descending = bitonic
         const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
         const int pos = base + src;
@@ -436,8 +424,8 @@ __global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t
     __syncthreads();
     bitonic_lds<kResortWindow>(s_a);
 #pragma unroll
-    for (int q = 0; q < kResortPer; ++q) {
-        const int o = q * 256 + threadIdx.x, pos = base + o;
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
         uint32_t v = 0;
         if (pos >= 0 && pos < N) {
             const uint32_t g = (uint32_t)s_a[o];
@@ -446,10 +434,10 @@ __global__ __launch_bounds__(256) void resort_merge_kernel(int N, const uint64_t
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) s_part[q][threadIdx.x >> 6] = v;
+        if ((threadIdx.x & 63) == 0) s_part[o >> 8][(o >> 6) & 3] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kResortPer) {
+    if (threadIdx.x < 4) {
         const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
         if (base + (int)threadIdx.x * 256 >= 0 && blk * 256 < N)
             block_sums[blk] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
@@ -647,10 +635,10 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         const int nA = (N + kResortWindow - 1) / kResortWindow;
         const int nB = (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow;   // windows that hold a real element
         ScopedTimer tm(T_SORT_SCATTER, st);
-        hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(256), 0, st, N, (const uint32_t *)order,
+        hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
                            (const uint32_t *)keys, comp);
         SLS_LAUNCH_CHECK("resort_sort_kernel");
-        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(256), 0, st, N, (const uint64_t *)comp, order, edges,
+        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order, edges,
                            tiles, block_sums);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
         resort_windows = nB;
