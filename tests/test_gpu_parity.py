@@ -469,7 +469,8 @@ def test_mapping_engine_lagged_status_read(device):
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.02 * moved, k
 
 
-def test_mapping_engine_depth_order_repair(device):
+@pytest.mark.parametrize("N", [30000, 4999], ids=["even-n", "odd-n"])   # odd N: separate optimiser kernel, unaligned scratch views
+def test_mapping_engine_depth_order_repair(device, N):
     """reuse_depth_order: repairing the previous iteration's depth order (windowed re-sort +
     exactness check) gives the same iterations as sorting from scratch; when the surfels are
     moved so far that the repair cannot reach the exact order, the iteration is flagged,
@@ -478,7 +479,7 @@ def test_mapping_engine_depth_order_repair(device):
     from splat_loam_amd.engine import MappingEngine
     from splat_loam_amd.mapping import MappingConfig
     from splat_loam_amd.scene import Camera, SurfelModel
-    N, H, W = 30000, 32, 512
+    H, W = 32, 512
     sc = synth.make_scene(N, H, W, seed=16, range_lo=2.0, range_hi=25.0)
     depth, valid = synth.make_targets(H, W, sc)
     cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
