@@ -39,8 +39,11 @@ class MappingEngine:
         self.dev = p.device
         self.N = int(p.shape[0])
         n10 = 10 * self.N
-        # flat buckets, one extra word at the end of grads carries the overflow flag through the all-reduce
-        self.grads = torch.zeros((n10 + 1,), dtype=torch.float32, device=self.dev)
+        # flat buckets; two extra words at the end of grads carry the two "iteration void" flags
+        # (instance buffers too small, depth-order repair failed) through the all-reduce
+        self.grads = torch.zeros((n10 + 2,), dtype=torch.float32, device=self.dev)
+        self._flag_lut = torch.tensor([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]], device=self.dev)
+        self._flag_w = torch.tensor([1, 2], dtype=torch.int32, device=self.dev)
         self.exp_avg = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
         self.exp_avg_sq = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
         self.status = torch.zeros((8,), dtype=torch.int32, device=self.dev)
@@ -120,7 +123,7 @@ class MappingEngine:
             self.capacity = max(4 * self.N, 1 << 16)
         ws_ptr, ws_bytes = self._ensure_workspace(H, W, self.capacity)
         xyz, scaling, rotation, opacity = self._params()
-        reuse = self.reuse_depth_order and apply_adam and self._order_cam == id(camera)
+        reuse = self.reuse_depth_order and self._order_cam == id(camera)
         cfg = self._config(apply_adam, with_regulariser, reuse)
         cfg.status_mirror = mirror
         self._order_cam = id(camera)
@@ -165,14 +168,14 @@ class MappingEngine:
             else:
                 rank = dist.get_rank(group)
                 self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0))
-                # overflow word rides at the end of the gradient bucket: one collective
-                self.grads[-1:] = self.status[1:2].to(torch.float32)
+                # the two flag bits ride at the end of the gradient bucket: one collective
+                self.grads[-2:] = self._flag_lut[(self.status[1] & 3).long()]
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
-                self.flag.copy_((self.grads[-1:] > 0).to(torch.int32))
+                # any rank's flag voids the iteration everywhere: fold the reduced bits into the local
+                # status word on the device (it guards Adam), so the one status read below is the only sync
+                self.status[1:2] = ((self.grads[-2:] > 0).to(torch.int32) * self._flag_w).sum().reshape(1)
+                self.flag.copy_(self.status[1:2])
                 self._adam_guarded()
-                # any rank's overflow voids the iteration everywhere: fold it into the local status
-                # word on the device, so that the one status read below is the only sync
-                self.status[1:2].copy_(torch.maximum(self.status[1:2], self.flag))
             if not sync:
                 self.t += 1
                 return None
@@ -185,7 +188,7 @@ class MappingEngine:
             # room if the instance buffers were too small
             self._order_cam = None
             self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
-            if sharded or st["too_small"]:
+            if st["too_small"]:
                 need = st["R"]
                 if sharded:
                     t = torch.tensor([need], dtype=torch.int64, device=self.dev)
