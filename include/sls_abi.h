@@ -17,6 +17,8 @@
  *     scene/gaussian_model.py:77-81
  *   GaussianRasterizer.markVisible (lineage API, unused in tree) sls_mark_visible
  *   one iteration of Mapper.optimize  slam/mapper.py:150-204     sls_mapping_step
+ *   GSAligner.set_query/set_reference/align                      sls_aligner_normals/_align
+ *     slam/tracker.py:141-197 ("next" row 3)
  *   render() post-processing + depth_to_normal + mapper loss     sls_consumer_fwd_bwd
  *     gaussian_renderer/__init__.py:48-93,                       ("next" row 1)
  *     utils/graphic_utils.py:26-88, slam/mapper.py:158-187
@@ -208,6 +210,48 @@ int sls_mapping_step(const SlsCamera *cam, int N,
                      const SlsMappingConfig *cfg, uint64_t R_capacity,
                      void *workspace, size_t workspace_bytes,
                      SlsMappingStatus *status_dev, float **allmap_out, void *stream);
+
+/* ---- frame-to-keyframe registration on spherical range images -------
+ * The job of the reference's `gsaligner` extension (slam/tracker.py:141-197: set_query /
+ * set_reference / align(iguess) -> (T, fitness, _)).  That submodule is not vendored, so the
+ * algorithm is this repository's own: projective nearest-pixel association
+ * under the spherical model of `projmatrix`, point-to-plane + range-image residuals with Huber
+ * weights, Gauss-Newton on SE(3) (left perturbation), the 6x6 system solved on the device.
+ *   depth: H*W floats (0 / <= depth_min = invalid), points: H*W*3 floats in the frame's own
+ *   coordinates (utils/graphic_utils.py:26-66 with transform_in_world=False), normals: H*W*3.
+ *   T_host: row-major 4x4 ref_T_query initial guess (HOST); workspace: DEVICE scratch. */
+typedef struct SlsAlignerParams {
+    int32_t num_iterations;   /* Gauss-Newton iterations */
+    int32_t min_inliers;      /* fewer associated pixels: the pose is left as it is */
+    float max_distance;       /* association gate |T p - q| (m) */
+    float min_cos_angle;      /* gate on cos(angle between reference normal and viewing ray) */
+    float huber_delta;        /* point-to-plane residual (m) */
+    float range_weight;       /* weight of the range-image term (0: off) */
+    float range_huber;        /* (m) */
+    float depth_min, depth_max;
+    float damping;            /* added to the diagonal of the normal equations */
+} SlsAlignerParams;
+typedef struct SlsAlignerResult {
+    float pose[12];           /* row-major 3x4 [R|t] of ref_T_query */
+    float fitness;            /* associated / valid query pixels at the final pose */
+    float chi2;               /* weighted squared error at the final pose */
+    float last_step;          /* |xi| of the last update (-1: system was not positive definite) */
+    int32_t inliers, valid_query, iterations;
+} SlsAlignerResult;
+size_t sls_aligner_workspace_bytes(void);
+int sls_aligner_normals(const SlsCamera *cam, const float *depth, const float *points, float depth_min,
+                        float *normals, void *stream);
+/* one linearisation at T_host; sys_out (DEVICE, 32 doubles): H upper triangle (21) | b (6) |
+ * chi2 | inliers | valid query pixels | 0 0   (tests compare it with the checker) */
+int sls_aligner_linearize(const SlsCamera *cam, const SlsAlignerParams *prm, const float *ref_depth,
+                          const float *ref_points, const float *ref_normals, const float *query_depth,
+                          const float *query_points, const float *T_host, void *workspace, double *sys_out,
+                          void *stream);
+/* num_iterations iterations + one evaluation, enqueued without a host sync; result_dev: DEVICE */
+int sls_aligner_align(const SlsCamera *cam, const SlsAlignerParams *prm, const float *ref_depth,
+                      const float *ref_points, const float *ref_normals, const float *query_depth,
+                      const float *query_points, const float *T_host, void *workspace,
+                      SlsAlignerResult *result_dev, void *stream);
 
 /* ---- fused Adam over up to 8 parameter tensors in one launch ------------
  * torch.optim.Adam semantics (no weight decay, no amsgrad); step is 1-based

@@ -36,6 +36,17 @@ class SlsMappingConfig(C.Structure):
     ]
 
 
+class SlsAlignerParams(C.Structure):
+    _fields_ = [("num_iterations", C.c_int32), ("min_inliers", C.c_int32), ("max_distance", C.c_float),
+                ("min_cos_angle", C.c_float), ("huber_delta", C.c_float), ("range_weight", C.c_float),
+                ("range_huber", C.c_float), ("depth_min", C.c_float), ("depth_max", C.c_float), ("damping", C.c_float)]
+
+
+class SlsAlignerResult(C.Structure):
+    _fields_ = [("pose", C.c_float * 12), ("fitness", C.c_float), ("chi2", C.c_float), ("last_step", C.c_float),
+                ("inliers", C.c_int32), ("valid_query", C.c_int32), ("iterations", C.c_int32)]
+
+
 class SlsMappingStatus(C.Structure):
     _fields_ = [("R", C.c_uint32), ("overflow", C.c_uint32), ("loss_sums", C.c_float * 4),
                 ("loss_reg", C.c_float), ("pad", C.c_uint32)]
@@ -80,6 +91,10 @@ _PROTOS = {
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),
+    "sls_aligner_workspace_bytes": (C.c_size_t, []),
+    "sls_aligner_normals": (C.c_int, [C.POINTER(SlsCamera), _VP, _VP, C.c_float, _VP, _VP]),
+    "sls_aligner_linearize": (C.c_int, [C.POINTER(SlsCamera), C.POINTER(SlsAlignerParams)] + [_VP] * 8 + [_VP]),
+    "sls_aligner_align": (C.c_int, [C.POINTER(SlsCamera), C.POINTER(SlsAlignerParams)] + [_VP] * 8 + [_VP]),
     "sls_timing_slots": (C.c_int, []),
     "sls_timing_name": (C.c_char_p, [C.c_int]),
     "sls_timing_enable": (C.c_int, [C.c_int]),
