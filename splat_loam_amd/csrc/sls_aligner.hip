@@ -17,7 +17,7 @@
 //               added to the system with one f64 atomic per block and term;
 //   solve     : ONE thread: (H + damping I) xi = -b by Cholesky in double,
 //               T <- exp(xi) T, statistics of the iteration, accumulators cleared.
-// A whole align() is enqueued without a host sync; the caller reads the 64-byte result.
+// A whole align() is enqueued without a host sync; the caller reads the 72-byte result.
 // HBM/latency bound: ~30 B per query pixel per iteration, P <= 131k pixels.
 #include <cstring>
 #include "sls_common.hpp"

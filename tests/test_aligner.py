@@ -182,3 +182,17 @@ def test_gsaligner_rejects_cpu_tensors(device):
     al = GSAligner(**GSAlignerParams(image_height=8, image_width=64).__dict__)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         al.set_reference(torch.zeros(1, 8, 64), torch.zeros(512, 3), torch.eye(4))
+
+
+@pytest.mark.gpu
+def test_mapping_then_tracking_against_the_rendered_keyframe(device):
+    """End to end, every hot component in its reference role (tools/slam_demo.py): surfels from a
+    scan as densify() builds them (distCUDA2 scales) -> MappingEngine iterations -> render() of the
+    keyframe -> GSAligner registers the following scans against the RENDERED keyframe."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import slam_demo
+    out = slam_demo.run(H=32, W=512, n_frames=4, n_iter=40, verbose=False, dev=str(device))
+    assert out["N"] > 5000 and out["losses"][-1] < 0.8 * out["losses"][0]
+    assert out["depth_err"] < 0.30                                  # rendered keyframe vs the scan it was built from (m)
+    for (dt, da), fit in zip(out["errs"], out["fits"]):
+        assert dt < 0.08 and da < math.radians(0.4) and fit > 0.6, (out["errs"], out["fits"])
