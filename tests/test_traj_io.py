@@ -1,0 +1,71 @@
+"""Result files in the reference's formats: odom.txt (TUM / KITTI), graph.yaml."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from splat_loam_amd import traj_io  # noqa: E402
+
+
+def _poses(n=7, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        T = np.eye(4)
+        T[:3, :3] = traj_io.rotation_of_wxyz(q) + 1e-7 * rng.normal(size=(3, 3))     # slightly off orthonormal
+        T[:3, 3] = rng.uniform(-50, 50, 3)
+        out.append(T)
+    return out
+
+
+def test_tum_round_trip_and_line_format(tmp_path):
+    poses, ts = _poses(), [1700000000.0 + 0.1 * k for k in range(7)]
+    f = tmp_path / "res" / "odom.txt"
+    traj_io.write_tum(f, poses, ts)
+    lines = open(f).read().splitlines()
+    assert lines[0] == "#timestamp tx ty tz qx qy qz qw" and len(lines) == 8
+    first = lines[1].split()
+    assert len(first) == 8 and first[0] == f"{ts[0]:.6f}" and first[1] == f"{poses[0][0, 3]:.4f}"
+    ts2, poses2 = traj_io.read_tum(f)
+    assert np.allclose(ts2, ts)
+    for a, b in zip(poses, poses2):
+        assert np.abs(a[:3, 3] - b[:3, 3]).max() <= 5e-5 and np.abs(a[:3, :3] - b[:3, :3]).max() <= 1e-6
+        assert abs(np.linalg.det(b[:3, :3]) - 1.0) < 1e-12
+
+
+def test_kitti_round_trip(tmp_path):
+    poses = _poses(5, seed=3)
+    f = tmp_path / "odom.txt"
+    traj_io.write_kitti(f, poses)
+    lines = open(f).read().splitlines()
+    assert len(lines) == 5 and all(len(l.split()) == 12 for l in lines)
+    for a, b in zip(poses, traj_io.read_kitti(f)):
+        assert np.abs(a - b).max() <= 1e-6 and np.array_equal(b[3], [0, 0, 0, 1])
+
+
+def test_quaternion_conversion_covers_all_branches():
+    for q in ([1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [0.1, 0.9, -0.3, 0.2], [0.1, 0.2, 0.9, -0.3],
+              [0.05, -0.2, 0.1, 0.95]):
+        q = np.array(q, float); q /= np.linalg.norm(q)
+        if q[0] < 0:
+            q = -q
+        q2 = traj_io.quaternion_wxyz(traj_io.rotation_of_wxyz(q))
+        assert np.abs(np.abs(q2 @ q) - 1.0) < 1e-12
+
+
+def test_graph_yaml_schema(tmp_path):
+    poses = _poses(3, seed=5)
+    proj = np.eye(4); K = np.array([[-163.0, 0, 512.0], [0, -136.8, 4.8], [0, 0, 1]]); proj[:3, :3] = K.T
+    models = [{"id": 0, "world_T_model": poses[0], "filename": "models/0000.ply", "frame_ids": [0, 1]}]
+    frames = [{"id": k, "timestamp": 0.1 * k, "model_T_frame": poses[1 + k], "projmatrix": proj, "model_id": 0} for k in range(2)]
+    f = tmp_path / "graph.yaml"
+    traj_io.write_graph(f, models, frames)
+    g = traj_io.read_graph(f)
+    assert set(g) == {"models", "frames"} and list(g["models"][0]) == ["id", "world_T_model", "filename", "frame_ids"]
+    assert list(g["frames"][0]) == ["id", "timestamp", "model_T_frame", "projmatrix", "model_id"]
+    assert np.allclose(g["models"][0]["world_T_model"], poses[0][:3].reshape(-1))
+    assert g["frames"][1]["projmatrix"] == [-163.0, -136.8, 512.0, 4.8] and g["models"][0]["frame_ids"] == [0, 1]
