@@ -133,12 +133,11 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
     }
     const float pc = (float)px, pr = (float)py;
     const float mscale = cam.far_c / (cam.far_c - cam.near_c);
-    const float k1 = slot >= 1 ? 1.0f : 0.0f, k2 = slot >= 2 ? 1.0f : 0.0f, k3 = slot >= 3 ? 1.0f : 0.0f;
     const uint32_t below = (1u << slot) - 1u, upto = (2u << slot) - 1u;   // quad bits of the earlier slots (and self)
 
-    // replicated over the quad: Tr, M1, M2, done.  Per-lane partial sums: D, N*, dist.
+    // replicated over the quad: Tr, done.  Per-lane partial sums: D, N*, M1, M2.
     float Tr = 1.0f, M1 = 0.0f, M2 = 0.0f;
-    float D = 0.0f, N0 = 0.0f, N1 = 0.0f, N2 = 0.0f, dist = 0.0f, med = 0.0f;
+    float D = 0.0f, N0 = 0.0f, N1 = 0.0f, N2 = 0.0f, med = 0.0f;
     uint32_t medc = 0, last = 0, cons = 0;
     bool done = !inside;
     bool wave_done = __all(done);
@@ -206,13 +205,11 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
             const float dep = upd ? e.depth : 1.0f;
             const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
             const float mw = m * w, mmw = m * mw;
-            float e1, t1, e2, t2;
-            quad_excl_total(mw, k1, k2, k3, e1, t1);
-            quad_excl_total(mmw, k1, k2, k3, e2, t2);
-            const float A = 1.0f - E;
-            dist += (m * m * A + (M2 + e2) - 2.0f * m * (M1 + e1)) * w;
-            M1 += t1;
-            M2 += t2;
+            // Distortion: sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) over the exclusive prefixes is the
+            // pairwise form sum_{j<i} w_i w_j (m_i - m_j)^2 = A * M2 - M1^2 of the TOTALS (A = sum w = 1 - T):
+            // only the two moments are accumulated (per lane), no prefix over the slots, no running term.
+            M1 += mw;
+            M2 += mmw;
             D += dep * w;
             N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
             const bool is_med = upd && (E > 0.5f);
@@ -234,7 +231,9 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
     }
 
     // combine the four slots of a pixel
-    D = quad_sum(D); N0 = quad_sum(N0); N1 = quad_sum(N1); N2 = quad_sum(N2); dist = quad_sum(dist);
+    D = quad_sum(D); N0 = quad_sum(N0); N1 = quad_sum(N1); N2 = quad_sum(N2);
+    M1 = quad_sum(M1); M2 = quad_sum(M2);
+    const float dist = (1.0f - Tr) * M2 - M1 * M1;
     last = quad_max(last);
     const uint32_t medc_q = quad_max(medc);
     med = quad_sum((medc == medc_q && medc != 0u) ? med : 0.0f);
