@@ -35,7 +35,7 @@ int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       uint64_t *block_masks = nullptr);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
-                      const uint64_t *block_masks = nullptr);
+                      const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -260,7 +260,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
-                           w.grec, st, w.block_masks);
+                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f);   // the consumer's dL/d(median, distortion) are 0 then
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;

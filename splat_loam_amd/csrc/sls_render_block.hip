@@ -271,7 +271,9 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
 // prefix.  The 16 gradient fields are reduced over the 16 pixels of a slot with
 // block_reduce16 and flushed with one 64-lane global float atomic per step.
 // ---------------------------------------------------------------------------
-template <int BW, int BH>
+// LEAN: the caller guarantees dL/d(median) = dL/d(distortion) = 0 (the mapper's loss at
+// depth_ratio = 0, gaussian_renderer/__init__.py:79-86): their terms are compiled out.
+template <int BW, int BH, bool LEAN>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
@@ -319,8 +321,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         dN0 = dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix];
         dN1 = dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix];
         dN2 = dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix];
-        dMed = dL_dallmap[SLS_CH_MEDIAN * P + pix];
-        dDist = dL_dallmap[SLS_CH_DIST * P + pix];
+        if (!LEAN) {
+            dMed = dL_dallmap[SLS_CH_MEDIAN * P + pix];
+            dDist = dL_dallmap[SLS_CH_DIST * P + pix];
+        }
     }
     const float Af = 1.0f - Tf;
     uint32_t wmax = last;
@@ -384,17 +388,24 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 Tr = dppq<0xFF>(Ti);
                 const float w = act ? e.alpha * Ti : 0.0f;
                 const float dep = act ? e.depth : 1.0f;
-                const float rdep = __builtin_amdgcn_rcpf(dep);
-                const float m = mscale * (1.0f - cam.near_c * rdep);
-                const float dm_dd = mscale * cam.near_c * rdep * rdep;
-                const float gk = dD * dep + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA +
-                                 dDist * (M2 + m * m * Af - 2.0f * m * M1);
+                float gdist = 0.0f, ddist = 0.0f;     // distortion terms of g_k and of dL/ddepth
+                if (!LEAN) {
+                    const float rdep = __builtin_amdgcn_rcpf(dep);
+                    const float m = mscale * (1.0f - cam.near_c * rdep);
+                    const float dm_dd = mscale * cam.near_c * rdep * rdep;
+                    gdist = dDist * (M2 + m * m * Af - 2.0f * m * M1);
+                    ddist = dDist * 2.0f * (m * Af - M1) * dm_dd;
+                }
+                const float gk = dD * dep + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA + gdist;
                 float Se, St;
                 quad_excl_total(w * gk, k1, k2, k3, Se, St);
                 const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
                 S += St;
-                float dL_ddepth = w * dD + dDist * 2.0f * w * (m * Af - M1) * dm_dd;
-                dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
+                float dL_ddepth = w * dD;
+                if (!LEAN) {
+                    dL_ddepth += w * ddist;
+                    dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
+                }
                 const bool unclamped = e.og < SLS_ALPHA_MAX;
                 const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
                 const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
@@ -446,21 +457,19 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
-                            const uint64_t *block_masks, int shape, hipStream_t st)
+                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
-    if (shape == 1)
-        hipLaunchKernelGGL((render_bwd_block_kernel<8, 2>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
-                           (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
-                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,
-                           g_dbg_bwd_cycles);
-    else
-        hipLaunchKernelGGL((render_bwd_block_kernel<4, 4>), grid, block, 0, st, cam, (const uint2 *)ranges, vals,
-                           (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,
-                           (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,
-                           g_dbg_bwd_cycles);
+#define SLS_BWD_BLOCK(BW_, BH_, LEAN_)                                                                              \
+    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_>), grid, block, 0, st, cam, (const uint2 *)ranges,   \
+                       vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
+                       (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
+                       g_dbg_bwd_cycles)
+    if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true); else SLS_BWD_BLOCK(4, 4, true); }
+    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false); else SLS_BWD_BLOCK(4, 4, false); }
+#undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");
     return SLS_OK;
 }
