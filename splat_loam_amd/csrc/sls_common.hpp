@@ -263,8 +263,9 @@ struct AdamFuse {
     const uint32_t *skip_flag;            // the iteration's overflow word: non-zero -> no update
     // optional: the iteration's status block (8 words, complete before this last kernel starts) is
     // copied to a host-visible mirror by thread 0, which saves the device->host copy kernel
-    const uint32_t *status_src;
+    uint32_t *status_src;
     uint32_t *status_mirror;
+    float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
 };
 
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8

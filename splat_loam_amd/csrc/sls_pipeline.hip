@@ -13,7 +13,7 @@ namespace sls {
 int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
-                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st);
+                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
@@ -53,7 +53,7 @@ struct MapWs {
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
-    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks;
+    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum;
     size_t total;
 };
 
@@ -90,10 +90,11 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.consumer_scratch_bytes = consumer_scratch_bytes(H, W);
     w.consumer_scratch = take(w.consumer_scratch_bytes);
     w.block_masks = (uint64_t *)take(block_mask_bytes(cap, (int)T));
-    // zeroed together, with one memset per iteration: [tile_consumed | grec]
+    // zeroed together on the first use of a workspace: [reg_accum | tile_consumed | grec]
+    w.reg_accum = (float *)take(4);
     w.tile_consumed = (uint32_t *)take(T * 4);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
-    w.zero_bytes = (size_t)((char *)w.grec - (char *)w.tile_consumed) + n * SLS_GREC_STRIDE * 4;
+    w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
     w.total = off;
     return w;
 }
@@ -226,20 +227,20 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const DevCam dc = make_devcam(*cam);
     const uint32_t cap = (uint32_t)R_capacity;
     if (allmap_out) *allmap_out = w.allmap;
-    SLS_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(SlsMappingStatus), st));
+    // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
     if (!cfg->workspace_ready) {
         // first use of this workspace: the gradient records must start from zero; afterwards the backward
         // of the projection leaves them zeroed behind itself (no 64*N-byte memset per iteration)
         ScopedTimer tm(T_GREC_MEMSET, st);
-        SLS_HIP_CHECK(hipMemsetAsync(w.tile_consumed, 0, w.zero_bytes, st));
+        SLS_HIP_CHECK(hipMemsetAsync(w.reg_accum, 0, w.zero_bytes, st));
     }
 
     // ---- forward ---------------------------------------------------------------
     uint32_t *okeys, *ovals, *n_dev;
     depth_order_key_buffers(N, w.order_scratch, w.order, &okeys, &ovals, &n_dev);
-    int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, &status_dev->loss_reg, N, xyz,
+    int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   okeys, ovals, n_dev, st);
+                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev);
     if (rc) return rc;
     rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow);
@@ -271,7 +272,8 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     memset(&fuse, 0, sizeof(fuse));
     fuse.clear_grec = 1;
     static_assert(sizeof(SlsMappingStatus) == 32, "the mirror copy moves 8 words");
-    fuse.status_src = (const uint32_t *)status_dev;
+    fuse.status_src = (uint32_t *)status_dev;
+    fuse.reg_accum = w.reg_accum;
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
     if (cfg->apply_adam && aligned) {

@@ -119,6 +119,8 @@ struct RegArgs {
     int raw;            // 1: scales/rots/opac are raw (pre-activation) parameters
     float smax, pen;    // slam/mapper.py:190-195 scale regulariser (pen == 0: off)
     float *reg_out;     // device scalar accumulating pen * sum relu(max_axis_scale - smax)
+    uint32_t *status_clear;   // optional: 8 status words of the iteration, zeroed by thread 0 of the FIRST kernel
+                              // (nothing else touches them before this kernel has finished)
 };
 
 __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q, float &o)
@@ -145,6 +147,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     uint32_t my_tiles = 0;
     float my_reg = 0.0f;
     if (i == 0 && n_dev) *n_dev = (uint32_t)N;
+    if (i == 0 && ra.status_clear) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ra.status_clear[k] = 0u;
+    }
     float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
     if (i < N) {
         int r_out = 0;
@@ -294,9 +300,15 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float2 *__restrict__ dscales, float4 *__restrict__ drots, float *__restrict__ dopac)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && af.status_mirror) {
+    if (i == 0) {
+        if (af.reg_accum) {   // the regulariser was summed in the workspace: publish it, leave zero for the next iteration
+            reinterpret_cast<float *>(af.status_src)[6] = *af.reg_accum;
+            *af.reg_accum = 0.0f;
+        }
+        if (af.status_mirror) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);
+            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);
+        }
     }
     if (i >= N) return;
     float dm[3] = { 0, 0, 0 };
@@ -435,11 +447,11 @@ __global__ __launch_bounds__(256) void mark_visible_kernel(DevCam cam, int N, co
 int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, float *reg_out, int N,
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
-                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st)
+                          uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear)
 {
     const int nb = (N + 255) / 256;
     RegArgs ra;
-    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out;
+    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out; ra.status_clear = status_clear;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
                        (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, order_keys,
@@ -455,7 +467,7 @@ int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int
 {
     const int nb = (N + 255) / 256;
     RegArgs ra;
-    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = nullptr;
+    ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = nullptr; ra.status_clear = nullptr;
     AdamFuse af;
     memset(&af, 0, sizeof(af));
     if (fuse) af = *fuse;
