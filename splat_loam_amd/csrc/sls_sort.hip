@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
                                                            const uint32_t *__restrict__ count_ptr, uint32_t cap,
                                                            int shift, const uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ totals, int nchunks_cap,
-                                                           uint2 *__restrict__ ranges_out, int nranges)
+                                                           uint2 *__restrict__ ranges_out, int nranges,
+                                                           uint32_t packed_val_mask)
 {
     constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread
     __shared__ uint32_t s_cursor[kSortWavesPerBlock][BINS];
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
         const uint32_t idx = base + (uint32_t)r * 64;
         const bool valid = idx < R;
         k[r] = valid ? keys_in[idx] : (KeyT)0;
-        v[r] = valid ? vals_in[idx] : 0u;
+        // packed mode (vals_in == null): the value is the low part of the key
+        v[r] = valid ? (vals_in ? vals_in[idx] : ((uint32_t)k[r] & packed_val_mask)) : 0u;
     }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     __builtin_amdgcn_wave_barrier();
@@ -228,7 +230,7 @@ int sort_passes(int nbits)
 template <typename KeyT, int BITS>
 static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout, const uint32_t *count_ptr,
                       uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int nblocks,
-                      uint2 *ranges_out, int nranges, hipStream_t st)
+                      uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st)
 {
     {
         ScopedTimer tm(T_SORT_HIST, st);
@@ -245,7 +247,7 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
         ScopedTimer tm(T_SORT_SCATTER, st);
         hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, vin, kout, vout,
                            count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks, ranges_out,
-                           nranges);
+                           nranges, packed_val_mask);
     }
     SLS_LAUNCH_CHECK("sort_scatter_kernel");
     return SLS_OK;
@@ -263,7 +265,8 @@ template <typename KeyT>
 static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32_t *vals_tmp,
                               const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
                               size_t scratch_bytes, int *result_in_tmp, hipStream_t st,
-                              uint2 *ranges_out = nullptr, int nranges = 0, bool drop_sorted_keys = false)
+                              uint2 *ranges_out = nullptr, int nranges = 0, bool drop_sorted_keys = false,
+                              int base_shift = 0)
 {
     *result_in_tmp = 0;
     if (cap == 0 || nbits <= 0) return SLS_OK;
@@ -284,12 +287,14 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
     KeyT *kb[2] = { keys, keys_tmp };
     uint32_t *vb[2] = { vals, vals_tmp };
     for (int p = 0; p < npasses; ++p) {
-        const int shift = bits * p;
+        const int shift = base_shift + bits * p;
         const int src = p & 1, dst = src ^ 1;
+        // packed single-pass sort (vals == null): the value travels in the key's low base_shift bits
+        const uint32_t packed_val_mask = (vals == nullptr && base_shift > 0) ? ((1u << base_shift) - 1u) : 0u;
         int rc;
         KeyT *kout = (drop_sorted_keys && p + 1 == npasses) ? nullptr : kb[dst];
 #define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kout, vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
-                                        nblocks, ranges_out, nranges, st)
+                                        nblocks, ranges_out, nranges, packed_val_mask, st)
         switch (bits) {
         case 8: rc = SLS_PASS(8); break;
         case 9: rc = SLS_PASS(9); break;
@@ -519,8 +524,9 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
                                                          const uint32_t *__restrict__ tiles,
                                                          const uint32_t *__restrict__ offsets, uint32_t cap,
                                                          uint32_t *__restrict__ tkeys, uint32_t *__restrict__ vals,
-                                                         uint32_t *__restrict__ overflow)
+                                                         uint32_t *__restrict__ overflow, int pack_shift)
 {
+    // pack_shift > 0 (vals == null): one word per instance, (tile << pack_shift) | surfel
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const uint32_t g = order[i];
@@ -541,8 +547,9 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
             int tx = rc.x + k;
             if (tx >= GX) tx -= GX;
             if (off < cap) {
-                tkeys[off] = row + (uint32_t)tx;
-                vals[off] = g;
+                const uint32_t tile = row + (uint32_t)tx;
+                if (vals) { tkeys[off] = tile; vals[off] = g; }
+                else tkeys[off] = (tile << pack_shift) | g;
             }
             ++off;
         }
@@ -689,16 +696,27 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     // one pass over the tile ids (T <= 2048): the sort's digit bases are the ranges
     const bool fused_ranges = sort_passes(tile_bits) == 1 && keys64_out == nullptr;
     if (!fused_ranges) SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
+    // ... and if tile id and surfel index fit one word together, an instance IS one word:
+    // half the traffic in emit, histogram and scatter
+    const int idx_bits = bits_for((uint32_t)(N - 1)) > 0 ? bits_for((uint32_t)(N - 1)) : 1;
+    const bool packed = fused_ranges && tile_bits + idx_bits <= 32;
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
-                           (const int4 *)rect, tiles, offsets, cap, tkeys, vals, overflow);
+                           (const int4 *)rect, tiles, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow,
+                           packed ? idx_bits : 0);
     }
     SLS_LAUNCH_CHECK("emit_tiles_kernel");
     int which = 0;
-    int rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
+    int rc;
+    if (packed) {
+        rc = radix_sort_pairs_t<uint32_t>(tkeys, nullptr, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
+                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits);
+    } else {
+        rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
                                           scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T,
                                           fused_ranges);   // nobody reads the sorted tile ids then
+    }
     if (rc) return rc;
     *sorted_in_tmp = which;
     if (!fused_ranges) {
