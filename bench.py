@@ -313,7 +313,7 @@ def main():
                                    {True: "sync", False: "async", "lagged": "lagged-1"}[status_read])
                    if engine is not None else "torch",
                    "depth_order": ("repaired from the previous iteration, verified exact"
-                                   if (engine is not None and engine.reuse_depth_order and world == 1)
+                                   if (engine is not None and engine.reuse_depth_order)
                                    else "sorted from scratch")},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,
     }
