@@ -32,6 +32,7 @@ class SlsMappingConfig(C.Structure):
         ("lr_xyz", C.c_float), ("lr_opacity", C.c_float), ("lr_scaling", C.c_float), ("lr_rotation", C.c_float),
         ("apply_adam", C.c_int32), ("reuse_depth_order", C.c_int32), ("keep_grads", C.c_int32), ("workspace_ready", C.c_int32),
         ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+        ("depth_order", C.c_void_p),
         ("status_mirror", C.c_void_p),
     ]
 

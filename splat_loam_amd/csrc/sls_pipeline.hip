@@ -237,16 +237,19 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
 
     // ---- forward ---------------------------------------------------------------
     uint32_t *okeys, *ovals, *n_dev;
-    depth_order_key_buffers(N, w.order_scratch, w.order, &okeys, &ovals, &n_dev);
+    // the depth order lives in the workspace, or in a caller-owned buffer (one per keyframe, so that every
+    // keyframe of a window can repair ITS order when the mapper samples keyframes at random)
+    uint32_t *order = cfg->depth_order ? cfg->depth_order : w.order;
+    depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
                                    okeys, ovals, n_dev, st, (uint32_t *)status_dev);
     if (rc) return rc;
-    rc = launch_depth_order_scan(N, w.depth, w.tiles, w.order, w.offsets, &status_dev->R, w.order_scratch,
+    rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow);
     if (rc) return rc;
     int in_tmp = 0;
-    rc = launch_bin_sort(dc, N, &status_dev->R, cap, w.order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,
+    rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,
                          w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
                          &status_dev->overflow, st);
     if (rc) return rc;

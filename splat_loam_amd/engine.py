@@ -67,8 +67,14 @@ class MappingEngine:
         self._ws_ready = False
         import os
         self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
-        self._order_cam = None            # id() of the camera whose depth order the workspace holds
+        # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
+        # id(camera) -> [order tensor, iteration it was last written]; an order older than max_order_age
+        # iterations is not worth repairing (the surfels moved too far) and is rebuilt from scratch
+        self._orders = {}
+        self.max_order_age = 4
+        self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
+        self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
     # when keep_grads is set; keyframe-parallel mode always fills and all-reduces it)
@@ -85,7 +91,6 @@ class MappingEngine:
             nbytes = int(lib.sls_mapping_workspace_bytes(self.N, H, W, self.capacity))
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
-            self._order_cam = None    # the depth order lived in the old workspace
             self._ws_ready = False
         base = self.workspace.data_ptr()
         return (base + 255) & ~255, self.workspace.numel() - 256
@@ -105,6 +110,11 @@ class MappingEngine:
         c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
         return c
 
+    def _forget_order(self, camera):
+        ent = self._orders.get(id(camera))
+        if ent is not None:
+            ent[1] = None
+
     def _params(self):
         m = self.model
         ps = (m._xyz, m._scaling, m._rotation, m._opacity)
@@ -123,10 +133,18 @@ class MappingEngine:
             self.capacity = max(4 * self.N, 1 << 16)
         ws_ptr, ws_bytes = self._ensure_workspace(H, W, self.capacity)
         xyz, scaling, rotation, opacity = self._params()
-        reuse = self.reuse_depth_order and self._order_cam == id(camera)
+        ent = self._orders.get(id(camera))
+        if ent is None:
+            if len(self._orders) >= self.max_cached_orders:
+                self._orders.pop(next(iter(self._orders)))
+            ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None]
+            self._orders[id(camera)] = ent
+        reuse = self.reuse_depth_order and ent[1] is not None and self._enq - ent[1] <= self.max_order_age
+        self._enq += 1
+        ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
+        cfg.depth_order = ent[0].data_ptr()
         cfg.status_mirror = mirror
-        self._order_cam = id(camera)
         _abi.check(lib.sls_mapping_step(
             C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
             self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
@@ -186,7 +204,7 @@ class MappingEngine:
                 return st
             # repeat the iteration (parameters were not touched): with the full sort, and with more
             # room if the instance buffers were too small
-            self._order_cam = None
+            self._forget_order(camera)
             self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
             if st["too_small"]:
                 need = st["R"]
@@ -225,7 +243,9 @@ class MappingEngine:
         cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
         cur_void = cur_st is not None and cur_st["overflow"]
         self.t -= 2 if cur_void else 1
-        self._order_cam = None                      # repeat with the full sort
+        self._forget_order(pcam)                    # repeat with the full sort
+        if cur_void:
+            self._forget_order(cur[1])
         self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
         if st["too_small"] or (cur_void and cur_st["too_small"]):
             need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)

@@ -509,6 +509,14 @@ def test_mapping_engine_depth_order_repair(device, N):
                     m._xyz.mul_(f)
     assert rep.stats["repeated_resort"] == 1 and full.stats["repeated_resort"] == 0
     assert rep.t == full.t == 8 and len(losses[0]) == len(losses[1]) == 8
+    # keyframes sampled in turn (slam/mapper.py:152-156 samples at random): every keyframe keeps its own order
+    cam2 = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(3)[2], data_device=str(device))
+    for it in range(6):
+        c = cam if it % 2 == 0 else cam2
+        losses[0].append(full.step(c)["loss"])
+        losses[1].append(rep.step(c)["loss"])
+    assert rep.stats["repeated_resort"] == 1, "orders two iterations old are still repairable"
+    assert len(rep._orders) == 2
     for a, b in zip(*losses):
         assert abs(a - b) <= 1e-5 * abs(a), losses
     # (float atomics order the gradient sums differently from run to run and Adam amplifies that where
