@@ -24,12 +24,19 @@ size_t sort_scratch_bytes(uint64_t cap);
 size_t order_scratch_bytes(int N);
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr);
+                            hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr,
+                            struct ScanHandoff *handoff = nullptr);
+struct ScanHandoff {
+    const uint32_t *block_sums;
+    int resort_windows;
+    const uint64_t *resort_edges;
+};
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
                     const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
-                    uint32_t *overflow, hipStream_t st);
+                    uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff = nullptr,
+                    uint32_t *total_out = nullptr);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
                       uint64_t *block_masks = nullptr);
@@ -245,13 +252,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
                                    okeys, ovals, n_dev, st, (uint32_t *)status_dev);
     if (rc) return rc;
+    ScanHandoff handoff = { nullptr, 0, nullptr };   // the emission finishes the scan of tiles_touched
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
-                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow);
+                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff);
     if (rc) return rc;
     int in_tmp = 0;
     rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, w.depth, w.offsets, w.tkeys, w.vals,
                          w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
-                         &status_dev->overflow, st);
+                         &status_dev->overflow, st, &handoff, &status_dev->R);
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,

@@ -39,6 +39,15 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *count_ptr, uint32
     return c < cap ? c : cap;
 }
 
+// What the depth-order stage hands to an emission that finishes the scan of tiles_touched itself
+// (block_sums null: the emission reads precomputed offsets)
+struct ScanHandoff {
+    const uint32_t *block_sums;     // sums of tiles_touched over 256-blocks of depth-order positions
+    int resort_windows;             // > 0: the order was repaired, check these window edges (resort_verify)
+    const uint64_t *resort_edges;
+};
+__device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restrict__ edges, uint32_t *__restrict__ flag);
+
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
@@ -524,15 +533,43 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
                                                          const uint32_t *__restrict__ tiles,
                                                          const uint32_t *__restrict__ offsets, uint32_t cap,
                                                          uint32_t *__restrict__ tkeys, uint32_t *__restrict__ vals,
-                                                         uint32_t *__restrict__ overflow, int pack_shift)
+                                                         uint32_t *__restrict__ overflow, int pack_shift,
+                                                         ScanHandoff fused, uint32_t *__restrict__ total_out,
+                                                         uint32_t *__restrict__ fail_flag)
 {
     // pack_shift > 0 (vals == null): one word per instance, (tile << pack_shift) | surfel
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t g = order[i];
-    const uint32_t t = tiles[g];
-    if (!t) return;
-    const uint32_t end = offsets[i];
+    const uint32_t g = (i < N) ? order[i] : 0u;
+    const uint32_t t = (i < N) ? tiles[g] : 0u;
+    uint32_t end;
+    if (fused.block_sums) {
+        // level 2 of the scan of tiles_touched done here (no scan launch, no offsets array): prefix of the
+        // preceding 256-blocks' sums + inclusive scan inside the block; the last block publishes R
+        __shared__ uint32_t s_wave[4];
+        __shared__ uint32_t s_pre[4];
+        if (fused.resort_windows > 0 && blockIdx.x == 0) resort_verify(fused.resort_windows, fused.resort_edges, fail_flag);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t pre = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += fused.block_sums[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+        uint32_t incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        if (lane == 0) s_pre[wave] = pre;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+        end = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3] + wave_prefix + incl;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = end;
+    } else {
+        end = (i < N) ? offsets[i] : 0u;
+    }
+    if (i >= N || !t) return;
     uint32_t off = end - t;
     if (end > cap) {
         // The buffers are too small: flag it (the caller repeats the iteration with more room) but
@@ -613,7 +650,7 @@ void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **k
 // reported in *fail_flag (see above).
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st, int reuse_order, uint32_t *fail_flag)
+                            hipStream_t st, int reuse_order, uint32_t *fail_flag, ScanHandoff *handoff)
 {
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
@@ -660,11 +697,23 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
             return SLS_E_ARG;
         }
     }
+    if (handoff && resort_windows > 0) {   // the emission finishes the scan and checks the repaired order
+        handoff->block_sums = block_sums;
+        handoff->resort_windows = resort_windows;
+        handoff->resort_edges = resort_edges;
+        return SLS_OK;
+    }
     ScopedTimer tm(T_SCAN, st);
     if (resort_windows == 0) {   // (the merge kernel of the repair already summed the blocks)
         hipLaunchKernelGGL(gather_block_sums_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
                            block_sums);
         SLS_LAUNCH_CHECK("gather_block_sums_kernel");
+    }
+    if (handoff) {
+        handoff->block_sums = block_sums;
+        handoff->resort_windows = 0;
+        handoff->resort_edges = nullptr;
+        return SLS_OK;
     }
     hipLaunchKernelGGL(gather_scan_final_kernel, dim3(nb), dim3(256), 0, st, N, (const uint32_t *)order, tiles,
                        (const uint32_t *)block_sums, offsets, total_out, resort_windows, resort_edges, fail_flag);
@@ -680,7 +729,7 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     const int32_t *rect, const uint32_t *tiles, const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
-                    uint32_t *overflow, hipStream_t st)
+                    uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff, uint32_t *total_out)
 {
     const int T = cam.GX * cam.GY;
     *sorted_in_tmp = 0;
@@ -704,7 +753,8 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
                            (const int4 *)rect, tiles, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow,
-                           packed ? idx_bits : 0);
+                           packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,
+                           overflow);
     }
     SLS_LAUNCH_CHECK("emit_tiles_kernel");
     int which = 0;
