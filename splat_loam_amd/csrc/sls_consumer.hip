@@ -31,6 +31,7 @@ struct ConsumerArgs {
     const float2 *col_h, *row_h;   // half-pixel ray tables
     float4 *du, *dv, *ns;          // scratch: dL/du, dL/dv, (n_surf, dot)
     float *sums;                   // [geom, normal, alpha, total]
+    float *partials;               // scratch: 3 floats per block of kernel B (no same-address atomics)
     float *dL_dallmap;
 };
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a)
     __syncthreads();
     if (threadIdx.x < 3) {
         const float v = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
-        if (v != 0.0f) atomicAdd(&a.sums[threadIdx.x], v);
+        a.partials[(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
     }
 }
 
@@ -120,8 +121,25 @@ __global__ __launch_bounds__(256) void consumer_c_kernel(ConsumerArgs a)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        a.sums[3] = a.sums[0] * a.inv_P + a.lambda_n * a.inv_nv * a.sums[1] + a.lambda_a * a.inv_nv * a.sums[2];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {   // the per-block partial sums of kernel B -> the three sums + the total
+        __shared__ float s_red[3][4];
+        const int nb = gridDim.x * gridDim.y;
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        for (int b = threadIdx.x; b < nb; b += 256) { t0 += a.partials[3 * b]; t1 += a.partials[3 * b + 1]; t2 += a.partials[3 * b + 2]; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = t0; s_red[1][threadIdx.x >> 6] = t1; s_red[2][threadIdx.x >> 6] = t2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float g = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+            const float n = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            const float al = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+            a.sums[0] = g; a.sums[1] = n; a.sums[2] = al;
+            a.sums[3] = g * a.inv_P + a.lambda_n * a.inv_nv * n + a.lambda_a * a.inv_nv * al;
+        }
+    }
     if (c >= a.W || r >= a.H) return;
     const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
     const bool valid = a.valid[pix] == 1;
@@ -162,7 +180,11 @@ __global__ __launch_bounds__(256) void consumer_c_kernel(ConsumerArgs a)
     a.dL_dallmap[SLS_CH_DIST * P + pix] = 0.0f;
 }
 
-size_t consumer_scratch_bytes(int H, int W) { return sizeof(float4) * 3 * (size_t)H * (size_t)W; }
+size_t consumer_scratch_bytes(int H, int W)
+{
+    const size_t nblocks = (size_t)((W + 63) / 64) * (size_t)((H + 3) / 4);
+    return sizeof(float4) * 3 * (size_t)H * (size_t)W + sizeof(float) * 3 * nblocks;
+}
 
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
@@ -183,10 +205,11 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
     a.du = (float4 *)scratch;
     a.dv = a.du + (size_t)H * W;
     a.ns = a.dv + (size_t)H * W;
+    a.partials = (float *)(a.ns + (size_t)H * W);
     a.sums = sums;
     a.dL_dallmap = dL_dallmap;
     ScopedTimer tm(T_CONSUMER, st);
-    if (!sums_zeroed) SLS_HIP_CHECK(hipMemsetAsync(sums, 0, 4 * sizeof(float), st));
+    (void)sums_zeroed;   // (the sums are written, not accumulated)
     const dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(consumer_b_kernel, grid, dim3(256), 0, st, a);
     SLS_LAUNCH_CHECK("consumer_b_kernel");
