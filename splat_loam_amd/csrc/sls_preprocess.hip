@@ -212,25 +212,28 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 float ex = -1.0e30f, ey = -1.0e30f;
                 const float lo = 255.0f * o;
                 if (lo > 1.0f) {
-                    const float rho_max = 2.0f * logf(lo) * 1.001f + 1.0e-3f;
+                    // (hardware-approximate rcp / sqrt / log here: these extents only have to be
+                    //  conservative, the margins below swallow an ulp; nothing exact depends on them)
+                    const float rho_max = 2.0f * __logf(lo) * 1.001f + 1.0e-3f;
                     float th2, daz2;
-                    ball_extent(sqrtf(rho_max) * smax, g.rho, g.rxy, th2, daz2);
-                    const float r2 = sqrtf(0.5f * rho_max);
+                    const float kk = __builtin_amdgcn_sqrtf(rho_max), rad = kk * smax;
+                    ball_extent(rad, g.rho, g.rxy, th2, daz2);
+                    const float r2 = __builtin_amdgcn_sqrtf(0.5f * rho_max);
                     // Tighter bound for the 3D branch: the hit point is p + u su Tu + v sv Tv with
                     // u^2+v^2 <= rho_max, an ellipse; its (az, el) extent to first order, plus a bound
                     // on the second-order remainder of atan2 (|Hessian| <= 1/r^2 on the segment).
                     // min(ball bound, ellipse bound) is still conservative.
-                    const float kk = sqrtf(rho_max), rad = kk * smax;
                     if (g.rxy > 2.0f * rad && g.rxy > 0.5f * g.rho) {
-                        const float au = (g.p[0] * g.Tu[1] - g.p[1] * g.Tu[0]) / g.rxy2;
-                        const float av = (g.p[0] * g.Tv[1] - g.p[1] * g.Tv[0]) / g.rxy2;
-                        const float rat_xy = rad / (g.rxy - rad);
-                        const float az_ell = kk * sqrtf(g.su * g.su * au * au + g.sv * g.sv * av * av) + 0.75f * rat_xy * rat_xy;
-                        const float zr = g.p[2] / (g.rxy * g.rho2);
-                        const float eu = -zr * (g.p[0] * g.Tu[0] + g.p[1] * g.Tu[1]) + g.rxy / g.rho2 * g.Tu[2];
-                        const float ev = -zr * (g.p[0] * g.Tv[0] + g.p[1] * g.Tv[1]) + g.rxy / g.rho2 * g.Tv[2];
-                        const float rat = rad / (g.rho - rad);
-                        const float el_ell = kk * sqrtf(g.su * g.su * eu * eu + g.sv * g.sv * ev * ev) + 1.5f * rat * rat;
+                        const float irxy2 = __builtin_amdgcn_rcpf(g.rxy2), irho2 = __builtin_amdgcn_rcpf(g.rho2);
+                        const float au = (g.p[0] * g.Tu[1] - g.p[1] * g.Tu[0]) * irxy2;
+                        const float av = (g.p[0] * g.Tv[1] - g.p[1] * g.Tv[0]) * irxy2;
+                        const float rat_xy = rad * __builtin_amdgcn_rcpf(g.rxy - rad);
+                        const float az_ell = kk * __builtin_amdgcn_sqrtf(g.su * g.su * au * au + g.sv * g.sv * av * av) + 0.75f * rat_xy * rat_xy;
+                        const float zr = g.p[2] * __builtin_amdgcn_rcpf(g.rxy) * irho2;
+                        const float eu = -zr * (g.p[0] * g.Tu[0] + g.p[1] * g.Tu[1]) + g.rxy * irho2 * g.Tu[2];
+                        const float ev = -zr * (g.p[0] * g.Tv[0] + g.p[1] * g.Tv[1]) + g.rxy * irho2 * g.Tv[2];
+                        const float rat = rad * __builtin_amdgcn_rcpf(g.rho - rad);
+                        const float el_ell = kk * __builtin_amdgcn_sqrtf(g.su * g.su * eu * eu + g.sv * g.sv * ev * ev) + 1.5f * rat * rat;
                         daz2 = fminf(daz2, az_ell * 1.02f);
                         th2 = fminf(th2, el_ell * 1.02f);
                     }
