@@ -193,6 +193,10 @@ typedef struct SlsMappingConfig {
     struct SlsMappingStatus *status_mirror; /* optional, HOST-visible (pinned, device-mapped) memory: the last
                               * kernel of the iteration copies *status_dev there, so the caller can read the
                               * status after an event/stream wait without enqueuing a device->host copy */
+    float *void_flags_out;   /* optional DEVICE pointer to 2 floats (keyframe-parallel mode: the two words after the
+                              * gradient bucket): [0] = 1.0 if bit 0 of status.overflow is set, [1] = 1.0 if any
+                              * other bit is, else 0.0 — summed over ranks by the gradient all-reduce and then
+                              * handed to sls_adam_step_reduced */
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
@@ -273,6 +277,13 @@ int sls_adam_step(const SlsAdamGroup *groups_host, int ngroups, double beta1, do
  * overflow word of SlsMappingStatus, possibly OR-reduced over ranks). */
 int sls_adam_step_guarded(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
                           double eps, int64_t step, const uint32_t *skip_flag_dev, void *stream);
+/* Keyframe-parallel form: void_flags_dev points at the two floats SlsMappingConfig.void_flags_out
+ * produced, AFTER the SUM all-reduce.  The update is skipped if either is > 0 (some rank voided the
+ * iteration), and the reduced bits (bit 0 / bit 1) are stored to *status_overflow_dev (may be null)
+ * so that the caller's status read sees the group's verdict. */
+int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
+                          double eps, int64_t step, const float *void_flags_dev,
+                          uint32_t *status_overflow_dev, void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------
  * out[i] = mean of squared distances from point i to its 3 nearest other

@@ -34,6 +34,7 @@ class SlsMappingConfig(C.Structure):
         ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
         ("depth_order", C.c_void_p),
         ("status_mirror", C.c_void_p),
+        ("void_flags_out", C.c_void_p),
     ]
 
 
@@ -89,6 +90,8 @@ _PROTOS = {
     "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
     "sls_adam_step_guarded": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP]),
+    "sls_adam_step_reduced": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_int64, _VP, _VP, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),

@@ -80,9 +80,19 @@ struct AdamArgs {
     AdamCoef c;
 };
 
+// void_flags (keyframe-parallel mode): two floats that rode the gradient all-reduce, > 0 if ANY rank
+// voided the iteration (instance buffers too small / another reason); the reduced bits are also
+// written to *status_word so that the caller's one status read sees them.
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units,
-                                                   const uint32_t *__restrict__ skip_flag)
+                                                   const uint32_t *__restrict__ skip_flag,
+                                                   const float *__restrict__ void_flags,
+                                                   uint32_t *__restrict__ status_word)
 {
+    if (void_flags) {
+        const uint32_t bits = (void_flags[0] > 0.0f ? 1u : 0u) | (void_flags[1] > 0.0f ? 2u : 0u);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && status_word) *status_word = bits;
+        if (bits) return;
+    }
     if (skip_flag && *skip_flag) return;   // e.g. the instance buffers overflowed: gradients are incomplete
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * 256) {
         int gi = 0;
@@ -221,7 +231,7 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 
 namespace sls {
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
-                const uint32_t *skip_flag, hipStream_t stream)
+                const uint32_t *skip_flag, hipStream_t stream, const float *void_flags, uint32_t *status_word)
 {
     SLS_REQUIRE(groups && ngroups > 0 && ngroups <= kMaxAdamGroups, "1..8 groups");
     SLS_REQUIRE(step >= 1, "step is 1-based");
@@ -244,7 +254,8 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond
     {
         ScopedTimer tm(T_ADAM, (hipStream_t)stream);
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units, skip_flag);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units, skip_flag,
+                           void_flags, status_word);
     }
     SLS_LAUNCH_CHECK("adam_kernel");
     return SLS_OK;
@@ -256,13 +267,21 @@ extern "C" {
 int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                   void *stream)
 {
-    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream);
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream, nullptr, nullptr);
 }
 
 int sls_adam_step_guarded(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps,
                           int64_t step, const uint32_t *skip_flag_dev, void *stream)
 {
-    return launch_adam(groups, ngroups, beta1, beta2, eps, step, skip_flag_dev, (hipStream_t)stream);
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, skip_flag_dev, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int sls_adam_step_reduced(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps,
+                          int64_t step, const float *void_flags_dev, uint32_t *status_overflow_dev, void *stream)
+{
+    SLS_REQUIRE(void_flags_dev, "null pointer");
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream, void_flags_dev,
+                       status_overflow_dev);
 }
 
 size_t sls_consumer_scratch_bytes(int H, int W) { return (H > 0 && W > 0) ? consumer_scratch_bytes(H, W) : 0; }

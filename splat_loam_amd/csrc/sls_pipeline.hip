@@ -50,7 +50,8 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed = false);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
-                const uint32_t *skip_flag, hipStream_t stream);
+                const uint32_t *skip_flag, hipStream_t stream, const float *void_flags = nullptr,
+                uint32_t *status_word = nullptr);
 
 // ---------------------------------------------------------------------------
 // workspace of sls_mapping_step: one caller-owned buffer, carved here
@@ -286,6 +287,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.status_src = (uint32_t *)status_dev;
     fuse.reg_accum = w.reg_accum;
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
+    fuse.void_flags = cfg->void_flags_out;
     const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
     if (cfg->apply_adam && aligned) {
         fuse.enabled = 1;

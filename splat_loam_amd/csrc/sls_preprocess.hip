@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             reinterpret_cast<float *>(af.status_src)[6] = *af.reg_accum;
             *af.reg_accum = 0.0f;
         }
+        if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM all-reduce
+            const uint32_t bits = af.status_src[1];
+            af.void_flags[0] = (bits & 1u) ? 1.0f : 0.0f;
+            af.void_flags[1] = (bits & ~1u) ? 1.0f : 0.0f;
+        }
         if (af.status_mirror) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);

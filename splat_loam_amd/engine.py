@@ -42,12 +42,9 @@ class MappingEngine:
         # flat buckets; two extra words at the end of grads carry the two "iteration void" flags
         # (instance buffers too small, depth-order repair failed) through the all-reduce
         self.grads = torch.zeros((n10 + 2,), dtype=torch.float32, device=self.dev)
-        self._flag_lut = torch.tensor([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]], device=self.dev)
-        self._flag_w = torch.tensor([1, 2], dtype=torch.int32, device=self.dev)
         self.exp_avg = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
         self.exp_avg_sq = torch.zeros((n10,), dtype=torch.float32, device=self.dev)
         self.status = torch.zeros((8,), dtype=torch.int32, device=self.dev)
-        self.flag = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         self.t = 0
         self.capacity = 0
         self.workspace = None
@@ -145,6 +142,8 @@ class MappingEngine:
         cfg = self._config(apply_adam, with_regulariser, reuse)
         cfg.depth_order = ent[0].data_ptr()
         cfg.status_mirror = mirror
+        # keyframe-parallel mode: the void bits leave the step as two floats behind the gradient bucket
+        cfg.void_flags_out = None if apply_adam else self.grads.data_ptr() + 4 * 10 * self.N
         _abi.check(lib.sls_mapping_step(
             C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
             self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
@@ -186,14 +185,12 @@ class MappingEngine:
             else:
                 rank = dist.get_rank(group)
                 self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0))
-                # the two flag bits ride at the end of the gradient bucket: one collective
-                self.grads[-2:] = self._flag_lut[(self.status[1] & 3).long()]
+                # the step left its two void flags behind the gradients (cfg.void_flags_out): one collective,
+                # no torch glue kernels
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
-                # any rank's flag voids the iteration everywhere: fold the reduced bits into the local
-                # status word on the device (it guards Adam), so the one status read below is the only sync
-                self.status[1:2] = ((self.grads[-2:] > 0).to(torch.int32) * self._flag_w).sum().reshape(1)
-                self.flag.copy_(self.status[1:2])
-                self._adam_guarded()
+                # any rank's flag voids the iteration everywhere: Adam reads the reduced flags and stores the
+                # group's verdict into the local status word, so the one status read below is the only sync
+                self._adam_reduced()
             if not sync:
                 self.t += 1
                 return None
@@ -265,7 +262,7 @@ class MappingEngine:
         prev, self._lag_pending = self._lag_pending, None
         return self._lag_collect(prev, redo_current=False)
 
-    def _adam_guarded(self):
+    def _adam_reduced(self):
         lib = _abi.lib()
         N = self.N
         xyz, scaling, rotation, opacity = self._params()
@@ -279,9 +276,10 @@ class MappingEngine:
             arr[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * off
             arr[k].numel = n
             arr[k].lr = lr
-        _abi.check(lib.sls_adam_step_guarded(arr, 4, self.betas[0], self.betas[1], self.eps, self.t + 1,
-                                             self.flag.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream),
-                   "sls_adam_step_guarded")
+        _abi.check(lib.sls_adam_step_reduced(arr, 4, self.betas[0], self.betas[1], self.eps, self.t + 1,
+                                             self.grads.data_ptr() + 4 * 10 * N, self.status.data_ptr() + 4,
+                                             torch.cuda.current_stream(self.dev).cuda_stream),
+                   "sls_adam_step_reduced")
 
     def allmap(self, H, W) -> torch.Tensor:
         """Copy of the last iteration's allmap (7,H,W) out of the workspace."""
