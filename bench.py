@@ -117,7 +117,7 @@ def main():
                          "the HIP rasterizer + HIP loss consumer; unfused: torch render()/loss glue (same maths)")
     ap.add_argument("--status-read", choices=("lagged", "sync", "async"), default="lagged",
                     help="engine mode, how the per-iteration status (loss terms, R, overflow) reaches the host.  The "
-                         "reference reads its loss once per iteration (slam/mapper.py:206-209).  lagged (default, 1 GPU): "
+                         "reference reads its loss once per iteration (slam/mapper.py:206-209).  lagged (default): "
                          "every iteration's status is read, but after the NEXT iteration has been enqueued, so the GPU "
                          "queue never drains; sync: read before enqueuing the next one; async: never read")
     ap.add_argument("--async-steps", action="store_true", help="alias of --status-read async")
@@ -309,8 +309,7 @@ def main():
                                   "unfused": " (torch loss glue)"}[args.mode],
                    "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff,
                    "parallelism": f"keyframe-dp{world}",
-                   "status_read": ("sync" if (world > 1 and status_read == "lagged") else
-                                   {True: "sync", False: "async", "lagged": "lagged-1"}[status_read])
+                   "status_read": {True: "sync", False: "async", "lagged": "lagged-1"}[status_read]
                    if engine is not None else "torch",
                    "depth_order": ("repaired from the previous iteration, verified exact"
                                    if (engine is not None and engine.reuse_depth_order)

@@ -279,11 +279,13 @@ int sls_adam_step_guarded(const SlsAdamGroup *groups_host, int ngroups, double b
                           double eps, int64_t step, const uint32_t *skip_flag_dev, void *stream);
 /* Keyframe-parallel form: void_flags_dev points at the two floats SlsMappingConfig.void_flags_out
  * produced, AFTER the SUM all-reduce.  The update is skipped if either is > 0 (some rank voided the
- * iteration), and the reduced bits (bit 0 / bit 1) are stored to *status_overflow_dev (may be null)
- * so that the caller's status read sees the group's verdict. */
+ * iteration), and the reduced bits (bit 0 / bit 1) are stored to status_dev->overflow (status_dev may be
+ * null) so that the caller's status read sees the group's verdict; with status_mirror (HOST-visible, as in
+ * SlsMappingConfig) the status block is also copied there by this, the iteration's last, kernel. */
 int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double beta1, double beta2,
                           double eps, int64_t step, const float *void_flags_dev,
-                          uint32_t *status_overflow_dev, void *stream);
+                          struct SlsMappingStatus *status_dev, struct SlsMappingStatus *status_mirror,
+                          void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------
  * out[i] = mean of squared distances from point i to its 3 nearest other

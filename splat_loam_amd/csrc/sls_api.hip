@@ -86,11 +86,18 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_units,
                                                    const uint32_t *__restrict__ skip_flag,
                                                    const float *__restrict__ void_flags,
-                                                   uint32_t *__restrict__ status_word)
+                                                   uint32_t *status_block, uint32_t *status_mirror)
 {
     if (void_flags) {
         const uint32_t bits = (void_flags[0] > 0.0f ? 1u : 0u) | (void_flags[1] > 0.0f ? 2u : 0u);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && status_word) *status_word = bits;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && status_block) {
+            status_block[1] = bits;                       // SlsMappingStatus.overflow: the group's verdict
+            if (status_mirror) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    __builtin_nontemporal_store(k == 1 ? bits : status_block[k], status_mirror + k);
+            }
+        }
         if (bits) return;
     }
     if (skip_flag && *skip_flag) return;   // e.g. the instance buffers overflowed: gradients are incomplete
@@ -231,7 +238,8 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 
 namespace sls {
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
-                const uint32_t *skip_flag, hipStream_t stream, const float *void_flags, uint32_t *status_word)
+                const uint32_t *skip_flag, hipStream_t stream, const float *void_flags, uint32_t *status_block,
+                uint32_t *status_mirror)
 {
     SLS_REQUIRE(groups && ngroups > 0 && ngroups <= kMaxAdamGroups, "1..8 groups");
     SLS_REQUIRE(step >= 1, "step is 1-based");
@@ -255,7 +263,7 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
     {
         ScopedTimer tm(T_ADAM, (hipStream_t)stream);
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, units, skip_flag,
-                           void_flags, status_word);
+                           void_flags, status_block, status_mirror);
     }
     SLS_LAUNCH_CHECK("adam_kernel");
     return SLS_OK;
@@ -267,21 +275,24 @@ extern "C" {
 int sls_adam_step(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                   void *stream)
 {
-    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream, nullptr, nullptr);
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 int sls_adam_step_guarded(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps,
                           int64_t step, const uint32_t *skip_flag_dev, void *stream)
 {
-    return launch_adam(groups, ngroups, beta1, beta2, eps, step, skip_flag_dev, (hipStream_t)stream, nullptr, nullptr);
+    return launch_adam(groups, ngroups, beta1, beta2, eps, step, skip_flag_dev, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 int sls_adam_step_reduced(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps,
-                          int64_t step, const float *void_flags_dev, uint32_t *status_overflow_dev, void *stream)
+                          int64_t step, const float *void_flags_dev, SlsMappingStatus *status_dev,
+                          SlsMappingStatus *status_mirror, void *stream)
 {
     SLS_REQUIRE(void_flags_dev, "null pointer");
+    SLS_REQUIRE(!status_mirror || status_dev, "status_mirror needs status_dev");
+    static_assert(sizeof(SlsMappingStatus) == 32, "the mirror copy moves 8 words");
     return launch_adam(groups, ngroups, beta1, beta2, eps, step, nullptr, (hipStream_t)stream, void_flags_dev,
-                       status_overflow_dev);
+                       (uint32_t *)status_dev, (uint32_t *)status_mirror);
 }
 
 size_t sls_consumer_scratch_bytes(int H, int W) { return (H > 0 && W > 0) ? consumer_scratch_bytes(H, W) : 0; }

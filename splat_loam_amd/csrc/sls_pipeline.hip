@@ -51,7 +51,7 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     hipStream_t st, bool sums_zeroed = false);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                 const uint32_t *skip_flag, hipStream_t stream, const float *void_flags = nullptr,
-                uint32_t *status_word = nullptr);
+                uint32_t *status_block = nullptr, uint32_t *status_mirror = nullptr);
 
 // ---------------------------------------------------------------------------
 // workspace of sls_mapping_step: one caller-owned buffer, carved here

@@ -54,6 +54,7 @@ class MappingEngine:
         self._lag_dev = torch.zeros((2, 8), dtype=torch.int32, device=self.dev)
         self._lag_host = torch.zeros((2, 8), dtype=torch.int32).pin_memory()
         self._lag_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self._group = None
         self._lag_pending = None          # (slot, camera) of the iteration whose status was not read yet
         # temporal re-sort: the workspace keeps the depth order of the last iteration; it is repaired
         # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
@@ -170,12 +171,13 @@ class MappingEngine:
         """One mapping iteration on `camera`.  Returns the status dict (sync=True)
         or None (sync=False: fire-and-forget; overflow is then detected at the
         next synchronous step, the skipped Adam update keeps the model intact).
-        sync="lagged" (single GPU): the iteration is enqueued BEFORE the status of
+        sync="lagged": the iteration is enqueued BEFORE the status of
         the previous one is read, so the GPU queue never runs dry while the host
         waits for a loss value; returns the PREVIOUS iteration's status (None on
         the first call) — finish with flush()."""
         sharded = dist.is_initialized() and dist.get_world_size(group) > 1
-        if sync == "lagged" and not sharded:
+        self._group = group
+        if sync == "lagged":
             return self._step_lagged(camera)
         if self._lag_pending is not None:
             self.flush()
@@ -190,7 +192,7 @@ class MappingEngine:
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
                 # any rank's flag voids the iteration everywhere: Adam reads the reduced flags and stores the
                 # group's verdict into the local status word, so the one status read below is the only sync
-                self._adam_reduced()
+                self._adam_reduced(self.status, None)
             if not sync:
                 self.t += 1
                 return None
@@ -214,7 +216,17 @@ class MappingEngine:
 
     def _step_lagged(self, camera):
         slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
-        if self.status_mirror:
+        group = self._group
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            # keyframe-parallel: the group's verdict is known on the device only (the void flags ride the
+            # gradient all-reduce and guard Adam), so the host can lag here exactly as on one GPU
+            self._enqueue(camera, apply_adam=False, with_regulariser=(dist.get_rank(group) == 0),
+                          status=self._lag_dev[slot])
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+            self._adam_reduced(self._lag_dev[slot], self._lag_host[slot].data_ptr() if self.status_mirror else None)
+            if not self.status_mirror:
+                self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
+        elif self.status_mirror:
             # the iteration's last kernel mirrors the status block into pinned host memory: no copy kernel
             self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot],
                           mirror=self._lag_host[slot].data_ptr())
@@ -248,7 +260,7 @@ class MappingEngine:
             need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
             self.capacity = int(need * self.capacity_factor) + 1024
             self.workspace = None
-        st = self.step(pcam, sync=True)
+        st = self.step(pcam, group=self._group, sync=True)
         if cur_void and redo_current:
             self._step_lagged(cur[1])
         elif cur_st is not None and not cur_void:
@@ -262,7 +274,7 @@ class MappingEngine:
         prev, self._lag_pending = self._lag_pending, None
         return self._lag_collect(prev, redo_current=False)
 
-    def _adam_reduced(self):
+    def _adam_reduced(self, status, mirror):
         lib = _abi.lib()
         N = self.N
         xyz, scaling, rotation, opacity = self._params()
@@ -277,7 +289,7 @@ class MappingEngine:
             arr[k].numel = n
             arr[k].lr = lr
         _abi.check(lib.sls_adam_step_reduced(arr, 4, self.betas[0], self.betas[1], self.eps, self.t + 1,
-                                             self.grads.data_ptr() + 4 * 10 * N, self.status.data_ptr() + 4,
+                                             self.grads.data_ptr() + 4 * 10 * N, status.data_ptr(), mirror,
                                              torch.cuda.current_stream(self.dev).cuda_stream),
                    "sls_adam_step_reduced")
 

@@ -547,7 +547,7 @@ def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, 
         lib.sls_debug_variant(3, 3)
 
 
-def _engine_rank(rank, world, port, out_dir):
+def _engine_rank(rank, world, port, out_dir, mode="sync"):
     import os
     import torch.distributed as dist
     from splat_loam_amd import synth
@@ -564,12 +564,43 @@ def _engine_rank(rank, world, port, out_dir):
     eng = MappingEngine(model, MappingConfig())
     if rank == 1:
         eng.capacity = 1024           # one rank overflows: BOTH must skip Adam and repeat
+    if mode == "lagged":
+        # the status of iteration k is read after k+1 was enqueued; the verdict of the GROUP guards Adam on
+        # the device, so both ranks void / repeat the same iterations without an extra collective
+        seen = [eng.step(cam, sync="lagged") for _ in range(4)]
+        assert seen[0] is None
+        st = eng.flush()
+        assert eng.stats["repeated_too_small"] >= 1 and not st["overflow"]
+        ref = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+        eng2 = MappingEngine(ref, MappingConfig())
+        for _ in range(4):
+            eng2.step(cam)
+        moved = (ref._xyz.detach() - torch.tensor(sc["means"], device="cuda:0")).abs().max().item()
+        assert moved > 0
+        assert (ref._xyz.detach() - model._xyz.detach()).abs().max().item() <= 0.02 * moved
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
+                 rot=model._rotation.detach().cpu().numpy(), g=eng.grads.cpu().numpy(), t=eng.t)
+        dist.destroy_process_group()
+        return
     st = eng.step(cam)
     g1 = eng.grads[:-2].cpu().numpy()
     st = eng.step(cam)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
              rot=model._rotation.detach().cpu().numpy(), g=eng.grads.cpu().numpy(), g1=g1, R=st["R"], t=eng.t)
     dist.destroy_process_group()
+
+
+def test_engine_keyframe_parallel_lagged_two_ranks(device, tmp_path):
+    """Keyframe-parallel engine, lagged status read (2 ranks, gloo, one GPU): an overflow on one rank voids
+    the iteration on both, both repeat it, replicas stay bit-identical and agree with the synchronous mode."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_engine_rank, args=(2, port, str(tmp_path), "lagged"), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert int(r0["t"]) == int(r1["t"]) == 4
+    for k in ("xyz", "rot", "g"):
+        assert np.array_equal(r0[k], r1[k]), f"replicas diverged: {k}"
 
 
 def test_engine_keyframe_parallel_two_ranks(device, tmp_path):
