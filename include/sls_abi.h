@@ -259,6 +259,26 @@ int sls_aligner_align(const SlsCamera *cam, const SlsAlignerParams *prm, const f
                       const float *query_points, const float *T_host, void *workspace,
                       SlsAlignerResult *result_dev, void *stream);
 
+/* ---- spherical projector (scene/preprocessing.py:42-64, the job of `pyprojections`) ----------
+ * A LiDAR scan (n,3) f32 -> the images a keyframe is built from.  Convention (pinned by
+ * utils/graphic_utils.py:41-59): pixel (c, r) holds the directions with floor(fx*az + cx + 1) = c,
+ * floor(fy*el + cy + 1) = r; a 360-degree image wraps in azimuth; the nearest return wins a pixel.
+ * scratch: sls_projector_scratch_bytes(H, W), 8-byte aligned, initialised ONCE by sls_projector_prepare;
+ * every later call leaves it ready for the next scan.  Nothing synchronises with the host. */
+size_t sls_projector_scratch_bytes(int H, int W);
+int sls_projector_prepare(int H, int W, void *scratch, size_t scratch_bytes, void *stream);
+/* pyp.calculate_spherical_intrinsics (scene/preprocessing.py:42-44): intrinsics_out = 12 DEVICE floats:
+ * K row-major (9), vfov, hfov, 1.0 if the cloud had any point off the origin. */
+int sls_projector_intrinsics(int n, const float *cloud, int H, int W, float full_azimuth_threshold_deg,
+                             float *intrinsics_out, void *scratch, size_t scratch_bytes, void *stream);
+/* pyp.Camera(...).project + the image gathering of scene/preprocessing.py:45-64.  K_dev: 9 DEVICE floats.
+ * lut (H*W int32, -1 = empty; may be null), range_image (H*W; 0 where empty), normals_image (H*W*3,
+ * -p/|p| , scene/preprocessing.py:112; may be null), valid (H*W bytes).  Points with range outside
+ * (depth_min, depth_max] are dropped. */
+int sls_projector_project(int n, const float *cloud, const float *K_dev, int H, int W, float depth_min,
+                          float depth_max, int32_t *lut, float *range_image, float *normals_image,
+                          uint8_t *valid, void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- fused Adam over up to 8 parameter tensors in one launch ------------
  * torch.optim.Adam semantics (no weight decay, no amsgrad); step is 1-based
  * and shared by all groups. */

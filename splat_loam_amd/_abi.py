@@ -92,6 +92,11 @@ _PROTOS = {
                                         C.c_int64, _VP, _VP]),
     "sls_adam_step_reduced": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP, _VP, _VP]),
+    "sls_projector_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sls_projector_prepare": (C.c_int, [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
+    "sls_projector_intrinsics": (C.c_int, [C.c_int, _VP, C.c_int, C.c_int, C.c_float, _VP, _VP, C.c_size_t, _VP]),
+    "sls_projector_project": (C.c_int, [C.c_int, _VP, _VP, C.c_int, C.c_int, C.c_float, C.c_float, _VP, _VP, _VP, _VP,
+                                        _VP, C.c_size_t, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),

@@ -86,3 +86,77 @@ def scan_to_images(cloud: np.ndarray, H: int, W: int, depth_min: float = 0.5, de
     normals_image[invalid] = 0.0
     return dict(K=K, vfov=vfov, hfov=hfov, range_image=range_image, normals_image=normals_image,
                 valid=~invalid, lut=lut)
+
+
+class DeviceProjector:
+    """The same projection on the MI355X (csrc/sls_projector.hip through the C ABI): the scan never
+    leaves the device, K is computed and consumed there, no host synchronisation.  One instance per
+    image size; images are freshly allocated per scan (they become the keyframe's targets).
+
+        proj = DeviceProjector(H, W, depth_min, depth_max)
+        out = proj.scan_to_images(cloud_cuda)     # dict like scan_to_images(), device tensors; K (3,3) on device
+    """
+
+    def __init__(self, H: int, W: int, depth_min: float = 0.5, depth_max: float = 100.0,
+                 full_azimuth_threshold_deg: float = 300.0, device="cuda:0"):
+        import torch
+        from . import _abi
+        self.H, self.W = int(H), int(W)
+        self.depth_min, self.depth_max = float(depth_min), float(depth_max)
+        self.thr = float(full_azimuth_threshold_deg)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("DeviceProjector runs on the GPU only (no CPU fallback); use scan_to_images() on the host")
+        lib = _abi.lib()
+        self._bytes = int(lib.sls_projector_scratch_bytes(self.H, self.W))
+        self._scratch = torch.empty((self._bytes + 7) // 8, dtype=torch.int64, device=self.dev)
+        _abi.check(lib.sls_projector_prepare(self.H, self.W, self._scratch.data_ptr(), self._bytes, self._stream()),
+                   "sls_projector_prepare")
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _cloud(self, cloud):
+        import torch
+        if not (isinstance(cloud, torch.Tensor) and cloud.is_cuda):
+            raise RuntimeError("cloud must be a CUDA tensor (no CPU fallback)")
+        if cloud.dtype != torch.float32 or cloud.dim() != 2 or cloud.shape[1] != 3:
+            raise RuntimeError("cloud must be (N,3) float32")
+        return cloud.contiguous()
+
+    def intrinsics(self, cloud):
+        """12 device floats: K row-major, vfov, hfov, any-point flag (calculate_spherical_intrinsics)."""
+        import torch
+        from . import _abi
+        cloud = self._cloud(cloud)
+        out = torch.empty(12, dtype=torch.float32, device=self.dev)
+        _abi.check(_abi.lib().sls_projector_intrinsics(cloud.shape[0], cloud.data_ptr(), self.H, self.W, self.thr,
+                                                       out.data_ptr(), self._scratch.data_ptr(), self._bytes,
+                                                       self._stream()), "sls_projector_intrinsics")
+        return out
+
+    def project(self, cloud, K):
+        """(lut int32 (H,W), range_image (H,W), normals_image (H,W,3), valid bool (H,W)) for K: 9+ device floats."""
+        import torch
+        from . import _abi
+        cloud = self._cloud(cloud)
+        if not (isinstance(K, torch.Tensor) and K.is_cuda and K.dtype == torch.float32 and K.numel() >= 9):
+            raise RuntimeError("K must be a CUDA float32 tensor with the 9 row-major entries first")
+        K = K.contiguous()
+        H, W = self.H, self.W
+        lut = torch.empty((H, W), dtype=torch.int32, device=self.dev)
+        rng = torch.empty((H, W), dtype=torch.float32, device=self.dev)
+        nrm = torch.empty((H, W, 3), dtype=torch.float32, device=self.dev)
+        valid = torch.empty((H, W), dtype=torch.uint8, device=self.dev)
+        _abi.check(_abi.lib().sls_projector_project(cloud.shape[0], cloud.data_ptr(), K.data_ptr(), H, W, self.depth_min,
+                                                    self.depth_max, lut.data_ptr(), rng.data_ptr(), nrm.data_ptr(),
+                                                    valid.data_ptr(), self._scratch.data_ptr(), self._bytes,
+                                                    self._stream()), "sls_projector_project")
+        return lut, rng, nrm, valid.view(torch.bool)
+
+    def scan_to_images(self, cloud):
+        intr = self.intrinsics(cloud)
+        lut, rng, nrm, valid = self.project(cloud, intr)
+        return dict(K=intr[:9].view(3, 3), vfov=intr[9], hfov=intr[10], range_image=rng, normals_image=nrm,
+                    valid=valid, lut=lut)

@@ -25,21 +25,28 @@ class Camera:
                  data_device="cuda"):
         dev = torch.device(data_device)
         self.data_device = dev
-        image_depth = np.asarray(image_depth, dtype=np.float32)
-        self.image_depth = torch.from_numpy(image_depth).to(dev)
-        self.image_height, self.image_width = int(image_depth.shape[1]), int(image_depth.shape[2])
+
+        def put(a, dtype=None):
+            # NumPy (the reference's scene/cameras.py:26-39) or tensors already on the device
+            # (projector.DeviceProjector): the latter are taken as they are, no host round trip
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dtype if dtype is not None else a.dtype).contiguous()
+            return torch.from_numpy(np.asarray(a, dtype=dtype and {torch.float32: np.float32}[dtype])).to(dev)
+
+        self.image_depth = put(image_depth, torch.float32)
+        self.image_height, self.image_width = int(self.image_depth.shape[1]), int(self.image_depth.shape[2])
         if image_normal is None:
             image_normal = np.zeros((3, self.image_height, self.image_width), np.float32)
         if image_valid is None:
             image_valid = np.ones((1, self.image_height, self.image_width), np.uint8)
-        self.image_normal = torch.from_numpy(np.asarray(image_normal, dtype=np.float32)).to(dev)
-        self.image_valid = torch.from_numpy(np.asarray(image_valid)).to(dev)
+        self.image_normal = put(image_normal, torch.float32)
+        self.image_valid = put(image_valid)
         if world_T_lidar is None:
             world_T_lidar = np.eye(4)
         view = np.linalg.inv(np.asarray(world_T_lidar, dtype=np.float64)).astype(np.float32)
         self.world_view_transform = torch.tensor(view).transpose(0, 1).contiguous().to(dev)
         self.projection_matrix = torch.eye(4, dtype=torch.float32, device=dev)
-        self.projection_matrix[:3, :3] = torch.from_numpy(np.asarray(K, dtype=np.float32)).to(dev).transpose(0, 1)
+        self.projection_matrix[:3, :3] = put(K, torch.float32).reshape(3, 3).transpose(0, 1)
 
 
 class SurfelModel:
