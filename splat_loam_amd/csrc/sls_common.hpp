@@ -265,6 +265,7 @@ struct AdamFuse {
     // copied to a host-visible mirror by thread 0, which saves the device->host copy kernel
     uint32_t *status_src;
     uint32_t *status_mirror;
+    uint8_t *touched;       // optional: per surfel, set by the backward tile kernel if its gradient record was written
     float *void_flags;      // optional: 2 floats, the void bits for the keyframe-parallel all-reduce
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
 };

@@ -42,7 +42,9 @@ int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       uint64_t *block_masks = nullptr);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
-                      const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false);
+                      const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
+                      uint8_t *touched = nullptr);
+extern int g_bwd_variant;
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -61,7 +63,7 @@ struct MapWs {
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
-    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum;
+    float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum; uint8_t *touched;
     size_t total;
 };
 
@@ -98,9 +100,10 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.consumer_scratch_bytes = consumer_scratch_bytes(H, W);
     w.consumer_scratch = take(w.consumer_scratch_bytes);
     w.block_masks = (uint64_t *)take(block_mask_bytes(cap, (int)T));
-    // zeroed together on the first use of a workspace: [reg_accum | tile_consumed | grec]
+    // zeroed together on the first use of a workspace: [reg_accum | tile_consumed | touched | grec]
     w.reg_accum = (float *)take(4);
     w.tile_consumed = (uint32_t *)take(T * 4);
+    w.touched = (uint8_t *)take(n);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
     w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
     w.total = off;
@@ -272,8 +275,9 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                          w.consumer_scratch, w.consumer_scratch_bytes, st, true);   // sums zeroed with the status
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
+    uint8_t *touched = g_bwd_variant >= 2 ? w.touched : nullptr;   // (the block kernels mark the surfels they reach)
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
-                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f);   // the consumer's dL/d(median, distortion) are 0 then
+                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched);   // the consumer's dL/d(median, distortion) are 0 then
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
@@ -286,6 +290,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     static_assert(sizeof(SlsMappingStatus) == 32, "the mirror copy moves 8 words");
     fuse.status_src = (uint32_t *)status_dev;
     fuse.reg_accum = w.reg_accum;
+    fuse.touched = touched;
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     fuse.void_flags = cfg->void_flags_out;
     const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);

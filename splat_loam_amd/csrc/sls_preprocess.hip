@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float o = o_in;
     activate(ra, s, q, o);
     const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
-    if (radii[i] > 0) {
+    // (an unmarked surfel's record is all zeros and so is its gradient: nothing to read, nothing to clear)
+    const bool marked = !af.touched || af.touched[i] != 0;
+    if (marked && af.touched) af.touched[i] = 0;
+    if (radii[i] > 0 && marked) {
         SurfelGeom g;
         surfel_geom(cam, m, s, q, g);
         const float4 g0 = grec[(size_t)i * 4 + 0], g1 = grec[(size_t)i * 4 + 1];

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
-    uint32_t *__restrict__ dbg_cycles)
+    uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles)
 {
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         float Tr = Tf, S = 0.0f;   // replicated over the quad
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
-            s_gidx[lane] = next_idx;
+            const uint32_t my_idx = next_idx;
+            s_gidx[lane] = my_idx;
             if (r > 0) {
                 SLS_WSTAGE_LOAD_REC()
                 next_idx = vals[range.x + (uint32_t)((r - 1) * 64 + lane)];
@@ -364,6 +365,9 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             if (mask == 0) continue;
             const bool pass = (mask >> lane) & 1ull;
             const int npass = __builtin_popcountll(mask);
+            // only surfels marked here can have a non-zero gradient record: preprocess_bwd reads (and clears)
+            // the records of the others not at all.  One byte store per round; same value from every block.
+            if (touched && pass) touched[my_idx] = 1;
             // survivors in DESCENDING list order
             if (pass) s_list[npass - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
             __builtin_amdgcn_wave_barrier();
@@ -457,7 +461,7 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
-                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean)
+                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -466,7 +470,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_>), grid, block, 0, st, cam, (const uint2 *)ranges,   \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       g_dbg_bwd_cycles)
+                       touched, g_dbg_bwd_cycles)
     if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true); else SLS_BWD_BLOCK(4, 4, true); }
     else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false); else SLS_BWD_BLOCK(4, 4, false); }
 #undef SLS_BWD_BLOCK
