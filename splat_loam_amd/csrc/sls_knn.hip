@@ -3,14 +3,14 @@
 // other points (slam/mapper.py:113-115, scene/gaussian_model.py:77-81).
 //
 // Exact 3-NN, built for LiDAR-like (very non-uniform) clouds:
-//   1. bounding cube, 30-bit Morton code per point;
+//   1. bounding cube, 30-bit Hilbert-curve index per point;
 //   2. wave64 LSD radix sort of (code, index) — the sorter of sls_sort.hip;
-//   3. points gathered in Morton order (float4: xyz + original index) and
+//   3. points gathered in curve order (float4: xyz + original index) and
 //      axis-aligned boxes over runs of 256 consecutive points;
-//   4. one thread per point (neighbouring lanes = neighbouring points): scan
-//      the own box first for a tight bound, then walk all boxes with a
-//      wave-uniform box index (box bounds come through the scalar cache) and
-//      scan only boxes whose distance lower bound beats the current third-best.
+//   4. one wave per 64 consecutive points, one lane per point: the own box first for a
+//      tight bound, then boxes / their 32-point sub-boxes whose gap to the wave's points
+//      beats the wave's worst third-best are listed (64 tests per step), and each listed
+//      sub-box is staged through LDS if it can still improve some lane's own bound.
 // Squared distances use the fixed expression fma(dz,dz,fma(dy,dy,dx*dx)), so
 // the result is reproducible bit for bit by a CPU brute force.
 #include <float.h>
@@ -25,6 +25,7 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
                          int *result_in_tmp, hipStream_t st);
 
 constexpr int kKnnBox = 256;
+constexpr int kKnnSub = 32;    // points per sub-box (8 per box)
 
 __device__ __forceinline__ uint32_t f2ord(float f)
 {   // monotone float -> uint mapping
@@ -63,13 +64,20 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(int M, const float *__res
             mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
         }
     }
+    // block combine in LDS, then 6 global atomics per block (same-address global atomics serialise)
+    __shared__ uint32_t s_box[6];
+    if (threadIdx.x < 6) s_box[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[k], f2ord(mn[k]));
-            atomicMax(&bbox[3 + k], f2ord(mx[k]));
+            atomicMin(&s_box[k], f2ord(mn[k]));
+            atomicMax(&s_box[3 + k], f2ord(mx[k]));
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], s_box[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bbox[threadIdx.x], s_box[threadIdx.x]);
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
@@ -94,13 +102,32 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(int M, const float *__r
     const uint32_t qx = (uint32_t)fminf(fmaxf((xyz[3 * i] - mnx) * s, 0.0f), 1023.0f);
     const uint32_t qy = (uint32_t)fminf(fmaxf((xyz[3 * i + 1] - mny) * s, 0.0f), 1023.0f);
     const uint32_t qz = (uint32_t)fminf(fmaxf((xyz[3 * i + 2] - mnz) * s, 0.0f), 1023.0f);
-    keys[i] = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+    // Hilbert index of the cell (Skilling's axes-to-transpose form, 10 bits per axis): unlike the Morton
+    // order it has no jumps, so runs of consecutive points (the boxes below) stay compact in space.
+    uint32_t X[3] = { qx, qy, qz };
+#pragma unroll
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (X[a] & Q) X[0] ^= P;
+            else { const uint32_t t = (X[0] ^ X[a]) & P; X[0] ^= t; X[a] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    uint32_t t = 0;
+#pragma unroll
+    for (uint32_t Q = 512u; Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    keys[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
     vals[i] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void knn_gather_boxes_kernel(int M, const float *__restrict__ xyz,
                                                                const uint32_t *__restrict__ sorted_idx,
-                                                               float4 *__restrict__ pts, float4 *__restrict__ boxes)
+                                                               float4 *__restrict__ pts, float4 *__restrict__ boxes,
+                                                               float4 *__restrict__ subboxes)
 {
     // one block per box of kKnnBox == blockDim.x points
     __shared__ float s_mn[4][3], s_mx[4][3];
@@ -115,10 +142,20 @@ __global__ __launch_bounds__(256) void knn_gather_boxes_kernel(int M, const floa
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = 16; off > 0; off >>= 1) {
             mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
             mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
         }
+    }
+    if ((threadIdx.x & (kKnnSub - 1)) == 0) {   // tight boxes over runs of 32 points (empty run: min > max)
+        const size_t sb = (size_t)blockIdx.x * (kKnnBox / kKnnSub) + threadIdx.x / kKnnSub;
+        subboxes[2 * sb] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        subboxes[2 * sb + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = fminf(mn[k], __shfl_xor(mn[k], 32, 64));
+        mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], 32, 64));
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
@@ -133,44 +170,188 @@ __global__ __launch_bounds__(256) void knn_gather_boxes_kernel(int M, const floa
 }
 
 __device__ __forceinline__ void best3_update(float d2, float &b0, float &b1, float &b2)
+{   // insertion into the sorted triple b0 <= b1 <= b2, branch-free (nested ifs end up as an indexed
+    // stack array here: scratch traffic in the innermost loop)
+    const float u0 = fmaxf(b0, d2);
+    b0 = fminf(b0, d2);
+    const float u1 = fmaxf(b1, u0);
+    b1 = fminf(b1, u0);
+    b2 = fminf(b2, u1);
+}
+
+// One WAVE per 64 curve-consecutive query points (lane = point), no block barriers: every wave runs
+// its own search at its own pace and 8 of them share a SIMD.
+//   a. the 8 runs of 32 points of the own box (256 points): a tight third-best b2 per lane;
+//   b. boxes (256 points) are tested 64 at a time, lane = box: gap between the box and the bounding
+//      box of each group of 8 consecutive query points against that group's worst b2 (isolated
+//      points and sparse stretches of the curve must not widen everybody's search); for the survivors the
+//      8 sub-boxes (32 points, much tighter: even a Hilbert run of 256 is loose) are tested the same
+//      way, 8 boxes per step; surviving sub-boxes go to a wave-private LDS list.  Chunks of 64 boxes
+//      are visited outwards from the own box, so b2 shrinks early;
+//   c. every listed sub-box is re-tested per lane against the lane's own b2 (point-to-box gap);
+//      if any lane can still improve, its 32 points go through LDS (broadcast reads) to all lanes.
+// All bounds are conservative (relative slack 1e-5), so the result is the exact 3-NN.
+template <bool SELF>
+__device__ __forceinline__ void knn_scan32(const float4 *s_run, const float4 me, int self, float &b0, float &b1, float &b2)
 {
-    if (d2 < b2) {
-        if (d2 < b1) {
-            b2 = b1;
-            if (d2 < b0) { b1 = b0; b0 = d2; } else b1 = d2;
-        } else b2 = d2;
+#pragma unroll 8
+    for (int k = 0; k < kKnnSub; ++k) {
+        const float4 p = s_run[k];
+        const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        best3_update((SELF && k == self) ? FLT_MAX : d2, b0, b1, b2);
     }
 }
 
-__global__ __launch_bounds__(256) void knn_query_kernel(int M, int nboxes, const float4 *__restrict__ pts,
-                                                        const float4 *__restrict__ boxes, float *__restrict__ out)
+__device__ __forceinline__ float box_gap2(const float4 amn, const float4 amx, const float4 bmn, const float4 bmx)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const bool live = j < M;
-    const float4 me = live ? pts[j] : make_float4(0, 0, 0, 0);
+    const float gx = fmaxf(fmaxf(bmn.x - amx.x, amn.x - bmx.x), 0.0f);
+    const float gy = fmaxf(fmaxf(bmn.y - amx.y, amn.y - bmx.y), 0.0f);
+    const float gz = fmaxf(fmaxf(bmn.z - amx.z, amn.z - bmx.z), 0.0f);
+    return fmaf(gz, gz, fmaf(gy, gy, gx * gx));
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void knn_query_kernel(int M, int nboxes, const float4 *__restrict__ pts,
+                                                       const float4 *__restrict__ boxes,
+                                                       const float4 *__restrict__ subboxes, float *__restrict__ out)
+{
+    constexpr int kSubs = kKnnBox / kKnnSub;            // 8 sub-boxes per box
+    __shared__ float4 s_run[kKnnSub];                   // wave-private: the workgroup IS one wave
+    __shared__ uint32_t s_box[64];
+    __shared__ uint32_t s_sub[64 * kSubs];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x * 64 + lane;
+    const bool live = q < M;
+    const float4 me = pts[live ? q : M - 1];
+    const int own_box = (blockIdx.x * 64) / kKnnBox, own_sub0 = (blockIdx.x * 64) / kKnnSub;   // my runs: own_sub0, +1
+    const int nsub = (M + kKnnSub - 1) / kKnnSub;
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
-    const int own = j / kKnnBox;
-    if (live) {
-        const int lo = own * kKnnBox, hi = min(lo + kKnnBox, M);
-        for (int k = lo; k < hi; ++k) {
-            if (k == j) continue;
-            const float4 p = pts[k];
-            const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
-            best3_update(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), b0, b1, b2);
+
+    auto stage = [&](int sb) {      // 32 points of run sb -> LDS (far-away sentinels beyond M)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kKnnSub) {
+            const int k = sb * kKnnSub + lane;
+            s_run[lane] = k < M ? pts[k] : make_float4(1.0e30f, 1.0e30f, 1.0e30f, 0.0f);
         }
+        __syncthreads();
+    };
+
+    // a. own box: my two runs first, then the other six
+    for (int t = 0; t < kSubs; ++t) {
+        const int sb = own_box * kSubs + ((t + (own_sub0 % kSubs)) % kSubs);
+        if (sb >= nsub) continue;
+        stage(sb);
+        const int self = (live && (q / kKnnSub) == sb) ? (q % kKnnSub) : -1;
+        knn_scan32<true>(s_run, me, self, b0, b1, b2);
     }
-    for (int b = 0; b < nboxes; ++b) {   // wave-uniform walk over all boxes
-        const float4 mn = boxes[2 * b], mx = boxes[2 * b + 1];
-        const float ex = fmaxf(fmaxf(mn.x - me.x, me.x - mx.x), 0.0f);
-        const float ey = fmaxf(fmaxf(mn.y - me.y, me.y - mx.y), 0.0f);
-        const float ez = fmaxf(fmaxf(mn.z - me.z, me.z - mx.z), 0.0f);
-        const float lb = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        if (live && b != own && lb * 0.99999f <= b2) {
-            const int lo = b * kKnnBox, hi = min(lo + kKnnBox, M);
-            for (int k = lo; k < hi; ++k) {
-                const float4 p = pts[k];
-                const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
-                best3_update(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), b0, b1, b2);
+
+    // bounding box of the wave's own points
+    float4 wmn = subboxes[2 * (size_t)own_sub0], wmx = subboxes[2 * (size_t)own_sub0 + 1];
+    if (own_sub0 + 1 < nsub) {
+        const float4 mn1 = subboxes[2 * (size_t)(own_sub0 + 1)], mx1 = subboxes[2 * (size_t)(own_sub0 + 1) + 1];
+        wmn = make_float4(fminf(wmn.x, mn1.x), fminf(wmn.y, mn1.y), fminf(wmn.z, mn1.z), 0.0f);
+        wmx = make_float4(fmaxf(wmx.x, mx1.x), fmaxf(wmx.y, mx1.y), fmaxf(wmx.z, mx1.z), 0.0f);
+    }
+
+    // bounding boxes of the 8 groups of 8 consecutive points (dead lanes: empty)
+    auto rl = [](float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); };
+    float4 gmn = live ? me : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.0f);
+    float4 gmx = live ? me : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.0f);
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        gmn.x = fminf(gmn.x, __shfl_xor(gmn.x, off, 64)); gmn.y = fminf(gmn.y, __shfl_xor(gmn.y, off, 64));
+        gmn.z = fminf(gmn.z, __shfl_xor(gmn.z, off, 64));
+        gmx.x = fmaxf(gmx.x, __shfl_xor(gmx.x, off, 64)); gmx.y = fmaxf(gmx.y, __shfl_xor(gmx.y, off, 64));
+        gmx.z = fmaxf(gmx.z, __shfl_xor(gmx.z, off, 64));
+    }
+    const int nchunks = (nboxes + 63) / 64, c0 = own_box / 64;
+    for (int it = 0; it < nchunks; ++it) {
+        // chunks outwards from the own one: c0, c0+1, c0-1, c0+2, ... (those inside [0, nchunks))
+        int chunk;
+        {
+            const int near = min(c0, nchunks - 1 - c0);            // both sides available for 2*near steps
+            if (it <= 2 * near) chunk = c0 + ((it & 1) ? (it + 1) / 2 : -(it / 2));
+            else chunk = (c0 < nchunks - 1 - c0) ? it : nchunks - 1 - it;
+        }
+        // Which boxes can reach the wave?  One bound for all 64 points would be ruined by a single isolated
+        // point (its b2 can be 1000 x the others') or by a sparse stretch of the curve (a bounding box that
+        // swallows the dense regions in between), so the wave is split into 8 groups of 8 consecutive points:
+        // a box is a candidate if its gap to a group's bounding box beats that group's worst b2.
+        float gB = live ? b2 : 0.0f;
+        gB = fmaxf(gB, __shfl_xor(gB, 1, 64)); gB = fmaxf(gB, __shfl_xor(gB, 2, 64)); gB = fmaxf(gB, __shfl_xor(gB, 4, 64));
+        const float B2 = wave_max(gB);
+        auto reaches = [&](const float4 bmn, const float4 bmx) -> bool {
+            if (!(box_gap2(wmn, wmx, bmn, bmx) * 0.99999f <= B2)) return false;
+            bool r = false;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 mn = make_float4(rl(gmn.x, 8 * g), rl(gmn.y, 8 * g), rl(gmn.z, 8 * g), 0.0f);
+                const float4 mx = make_float4(rl(gmx.x, 8 * g), rl(gmx.y, 8 * g), rl(gmx.z, 8 * g), 0.0f);
+                r = r || (box_gap2(mn, mx, bmn, bmx) * 0.99999f <= rl(gB, 8 * g));
+            }
+            return r;
+        };
+        const int b = chunk * 64 + lane;
+        bool c = false;
+        if (b < nboxes && b != own_box) c = reaches(boxes[2 * b], boxes[2 * b + 1]);
+        const uint64_t cm = __ballot(c);
+        const int nb = __builtin_popcountll(cm);
+        if (nb == 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (c) s_box[__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))] = (uint32_t)b;
+        __syncthreads();
+        // their sub-boxes, 8 boxes per step: lane = (box slot, sub-box)
+        int ns = 0;
+        for (int g = 0; g < nb; g += 8) {
+            const int slot = g + (lane >> 3);
+            bool cs = false;
+            uint32_t sb = 0;
+            if (slot < nb) {
+                sb = s_box[slot] * kSubs + (uint32_t)(lane & 7);
+                if ((int)sb < nsub) cs = reaches(subboxes[2 * (size_t)sb], subboxes[2 * (size_t)sb + 1]);
+            }
+            const uint64_t sm = __ballot(cs);
+            if (cs) s_sub[ns + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u))] = sb;
+            ns += __builtin_popcountll(sm);
+        }
+        __syncthreads();
+        // c. 64 listed sub-boxes at a time: lane k holds the bounds of candidate k (one parallel load), the
+        //    wave walks them with v_readlane broadcasts — no memory latency per candidate.  The points of the
+        //    next candidate that passes are fetched while the current one is scanned.
+        for (int base = 0; base < ns; base += 64) {
+            const int nk = min(64, ns - base);
+            const uint32_t sbl = s_sub[base + min(lane, nk - 1)];
+            const float4 mnl = subboxes[2 * (size_t)sbl], mxl = subboxes[2 * (size_t)sbl + 1];
+            auto wanted = [&](int k) -> bool {      // can candidate k still improve some lane?
+                const float4 mn = make_float4(rl(mnl.x, k), rl(mnl.y, k), rl(mnl.z, k), 0.0f);
+                const float4 mx = make_float4(rl(mxl.x, k), rl(mxl.y, k), rl(mxl.z, k), 0.0f);
+                return __ballot(live && box_gap2(me, me, mn, mx) * 0.99999f <= b2) != 0;
+            };
+            auto fetch = [&](int k) -> float4 {     // lanes 0..31: the points of candidate k (sentinels beyond M)
+                const int i = __builtin_amdgcn_readlane((int)sbl, k) * kKnnSub + (lane & (kKnnSub - 1));
+                return i < M ? pts[i] : make_float4(1.0e30f, 1.0e30f, 1.0e30f, 0.0f);
+            };
+            int k = 0;
+            while (k < nk && !wanted(k)) ++k;
+            float4 pre = make_float4(0, 0, 0, 0);
+            if (k < nk) pre = fetch(k);
+            while (k < nk) {
+                int kn = k + 1;
+                while (kn < nk && !wanted(kn)) ++kn;       // (tested with the bounds before this scan: conservative)
+                const float4 cur = pre;
+                if (kn < nk) pre = fetch(kn);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < kKnnSub) s_run[lane] = cur;
+                __syncthreads();
+                knn_scan32<false>(s_run, me, -1, b0, b1, b2);    // (a lane that did not need it cannot be changed by it)
+                k = kn;
             }
         }
     }
@@ -182,7 +363,7 @@ struct KnnScratch {
     uint32_t *bbox;
     uint32_t *keys, *keys_tmp;
     uint32_t *vals, *vals_tmp;
-    float4 *pts, *boxes;
+    float4 *pts, *boxes, *subboxes;
     void *sort;
     size_t sort_bytes, total;
 };
@@ -201,6 +382,7 @@ static KnnScratch knn_layout(int M, void *base)
     s.vals_tmp = (uint32_t *)(p + off); off += al(sizeof(uint32_t) * (size_t)M);
     s.pts = (float4 *)(p + off); off += al(sizeof(float4) * (size_t)M);
     s.boxes = (float4 *)(p + off); off += al(sizeof(float4) * 2 * (size_t)nboxes);
+    s.subboxes = (float4 *)(p + off); off += al(sizeof(float4) * 2 * (size_t)nboxes * (kKnnBox / kKnnSub));
     s.sort = (void *)(p + off);
     s.sort_bytes = sort_scratch_bytes((uint64_t)M);
     off += al(s.sort_bytes);
@@ -225,7 +407,7 @@ int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratc
     ScopedTimer tm(T_KNN, st);
     hipLaunchKernelGGL(knn_init_bbox_kernel, dim3(1), dim3(64), 0, st, s.bbox, (uint32_t)M);
     SLS_LAUNCH_CHECK("knn_init_bbox_kernel");
-    hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st, M, xyz, s.bbox);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, M, xyz, s.bbox);
     SLS_LAUNCH_CHECK("knn_bbox_kernel");
     hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, st, M, xyz, s.bbox, s.keys, s.vals);
     SLS_LAUNCH_CHECK("knn_morton_kernel");
@@ -235,9 +417,10 @@ int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratc
     if (rc) return rc;
     const int nboxes = (M + kKnnBox - 1) / kKnnBox;
     hipLaunchKernelGGL(knn_gather_boxes_kernel, dim3(nboxes), dim3(kKnnBox), 0, st, M, xyz,
-                       which ? s.vals_tmp : s.vals, s.pts, s.boxes);
+                       which ? s.vals_tmp : s.vals, s.pts, s.boxes, s.subboxes);
     SLS_LAUNCH_CHECK("knn_gather_boxes_kernel");
-    hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, st, M, nboxes, s.pts, s.boxes, out);
+    static_assert(kKnnBox == 256 && kKnnSub == 32, "the query kernel's lane mappings are written for 8 runs of 32");
+    hipLaunchKernelGGL(knn_query_kernel, dim3((M + 63) / 64), dim3(64), 0, st, M, nboxes, s.pts, s.boxes, s.subboxes, out);
     SLS_LAUNCH_CHECK("knn_query_kernel");
     return SLS_OK;
 }
