@@ -27,7 +27,15 @@
 
 namespace sls {
 
-constexpr int kSortRounds = 16;
+// (build-time knobs for A/B runs; measured on the bench scene: 8 rounds per wave = twice the waves does not
+//  speed the scatter up and costs the row scan 4 us; 4 waves per block = the old stray-word table access)
+#ifndef SLS_SORT_ROUNDS
+#define SLS_SORT_ROUNDS 16
+#endif
+#ifndef SLS_SORT_WAVES
+#define SLS_SORT_WAVES 16
+#endif
+constexpr int kSortRounds = SLS_SORT_ROUNDS;
 constexpr int kSortWaveItems = kWave * kSortRounds;  // 1024 items per wave
 constexpr int kSortWavesPerBlock = 4;
 constexpr int kSortMaxBins = 2048;   // 11-bit digits at most
@@ -51,38 +59,45 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
+// A block is WAVES chunks: the count table cnt[digit][chunk] is written (and read back by the scatter)
+// in runs of WAVES consecutive chunks per digit — 64 contiguous bytes with 16 waves — instead of one
+// stray word per (digit, wave).  The LDS rows are padded by one word so that the transposed access
+// (lanes = consecutive waves of one digit) spreads over the banks.
+template <int BITS> struct SortBlock { static constexpr int kWaves = BITS <= 9 ? SLS_SORT_WAVES : (BITS == 10 ? (SLS_SORT_WAVES < 8 ? SLS_SORT_WAVES : 8) : 4); };
+
 template <typename KeyT, int BITS>
-__global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *__restrict__ keys,
-                                                        const uint32_t *__restrict__ count_ptr, uint32_t cap,
-                                                        int shift, uint32_t *__restrict__ cnt, int nchunks_cap)
+__global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_hist_kernel(
+    const KeyT *__restrict__ keys, const uint32_t *__restrict__ count_ptr, uint32_t cap, int shift,
+    uint32_t *__restrict__ cnt, int nchunks_cap)
 {
-    constexpr int BINS = 1 << BITS;
-    __shared__ uint32_t s_hist[kSortWavesPerBlock][BINS];
+    constexpr int BINS = 1 << BITS, WAVES = SortBlock<BITS>::kWaves, STR = BINS + 1;
+    __shared__ uint32_t s_hist[WAVES * STR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
+    const int chunk0 = blockIdx.x * WAVES, chunk = chunk0 + wave;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
+    if (chunk0 >= nchunks) return;             // whole block beyond the data
 #pragma unroll
-    for (int k = 0; k < BINS / 64; ++k) s_hist[wave][lane + 64 * k] = 0;
-    if (chunk >= nchunks) return;
-    const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
-    KeyT k[kSortRounds];
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const uint32_t idx = base + (uint32_t)r * 64;
-        k[r] = (idx < R) ? keys[idx] : (KeyT)0;
-    }
+    for (int k = 0; k < BINS / 64; ++k) s_hist[wave * STR + lane + 64 * k] = 0;
     __builtin_amdgcn_wave_barrier();
+    if (chunk < nchunks) {
+        const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
+        KeyT k[kSortRounds];
 #pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const uint32_t idx = base + (uint32_t)r * 64;
-        if (idx < R) atomicAdd(&s_hist[wave][(uint32_t)(k[r] >> shift) & (uint32_t)(BINS - 1)], 1u);
+        for (int r = 0; r < kSortRounds; ++r) {
+            const uint32_t idx = base + (uint32_t)r * 64;
+            k[r] = (idx < R) ? keys[idx] : (KeyT)0;
+        }
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) {
+            const uint32_t idx = base + (uint32_t)r * 64;
+            if (idx < R) atomicAdd(&s_hist[wave * STR + ((uint32_t)(k[r] >> shift) & (uint32_t)(BINS - 1))], 1u);
+        }
     }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < BINS / 64; ++q) {
-        const int d = lane + 64 * q;
-        cnt[(size_t)d * nchunks_cap + chunk] = s_hist[wave][d];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BINS * WAVES; idx += 64 * WAVES) {
+        const int d = idx / WAVES, w = idx % WAVES;
+        if (chunk0 + w < nchunks_cap) cnt[(size_t)d * nchunks_cap + chunk0 + w] = s_hist[w * STR + d];
     }
 }
 
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict_
 
 // step 3: stable scatter
 template <typename KeyT, int BITS>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restrict__ keys_in,
+__global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_kernel(const KeyT *__restrict__ keys_in,
                                                            const uint32_t *__restrict__ vals_in,
                                                            KeyT *__restrict__ keys_out,
                                                            uint32_t *__restrict__ vals_out,
@@ -133,49 +148,57 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
                                                            uint2 *__restrict__ ranges_out, int nranges,
                                                            uint32_t packed_val_mask)
 {
-    constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread
-    __shared__ uint32_t s_cursor[kSortWavesPerBlock][BINS];
+    constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread (of the first 256)
+    constexpr int WAVES = SortBlock<BITS>::kWaves, STR = BINS + 1;
+    __shared__ uint32_t s_cursor[WAVES * STR];
     __shared__ uint32_t s_digit_base[BINS];
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
-    if ((int)(blockIdx.x * kSortWavesPerBlock) >= nchunks) return;   // whole block beyond the data
-    {   // exclusive scan of the BINS digit totals (PER consecutive ones per thread)
+    const int chunk0 = blockIdx.x * WAVES;
+    if (chunk0 >= nchunks) return;   // whole block beyond the data
+    {   // exclusive scan of the BINS digit totals (PER consecutive ones per thread, first 256 threads)
+        const bool scanner = threadIdx.x < 256;
         uint32_t loc[PER];
         uint32_t v = 0;
+        if (scanner) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { loc[k] = v; v += totals[threadIdx.x * PER + k]; }
+            for (int k = 0; k < PER; ++k) { loc[k] = v; v += totals[threadIdx.x * PER + k]; }
+        }
         uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
-        if (lane == 63) s_wave[wave] = incl;
+        if (scanner && lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+        if (scanner) {
+            uint32_t wave_prefix = 0;
+            for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) s_digit_base[threadIdx.x * PER + k] = wave_prefix + incl - v + loc[k];
-        // single-pass sort by tile id: the digit bases ARE the tile ranges (A5)
-        if (ranges_out && blockIdx.x == 0) {
+            for (int k = 0; k < PER; ++k) s_digit_base[threadIdx.x * PER + k] = wave_prefix + incl - v + loc[k];
+            // single-pass sort by tile id: the digit bases ARE the tile ranges (A5)
+            if (ranges_out && blockIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int d = threadIdx.x * PER + k;
-                const uint32_t b0 = wave_prefix + incl - v + loc[k], c = totals[d];
-                if (d < nranges) ranges_out[d] = c ? make_uint2(b0, b0 + c) : make_uint2(0u, 0u);
+                for (int k = 0; k < PER; ++k) {
+                    const int d = threadIdx.x * PER + k;
+                    const uint32_t b0 = wave_prefix + incl - v + loc[k], c = totals[d];
+                    if (d < nranges) ranges_out[d] = c ? make_uint2(b0, b0 + c) : make_uint2(0u, 0u);
+                }
             }
         }
         __syncthreads();
     }
-    const int chunk = blockIdx.x * kSortWavesPerBlock + wave;
-    if (chunk >= nchunks) return;
-#pragma unroll
-    for (int q = 0; q < BINS / 64; ++q) {
-        const int d = lane + 64 * q;
-        s_cursor[wave][d] = s_digit_base[d] + cnt[(size_t)d * nchunks_cap + chunk];
+    // cursors of the block's WAVES chunks: runs of WAVES consecutive counts per digit (see sort_hist_kernel)
+    for (int idx = threadIdx.x; idx < BINS * WAVES; idx += 64 * WAVES) {
+        const int d = idx / WAVES, w = idx % WAVES;
+        if (chunk0 + w < nchunks_cap) s_cursor[w * STR + d] = s_digit_base[d] + cnt[(size_t)d * nchunks_cap + chunk0 + w];
     }
+    __syncthreads();
+    const int chunk = chunk0 + wave;
+    if (chunk >= nchunks) return;
     const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
     KeyT k[kSortRounds];
     uint32_t v[kSortRounds];
@@ -204,12 +227,12 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const KeyT *__restric
         const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
         const uint32_t count = (uint32_t)__popcll(peers);
         uint32_t pos = 0;
-        if (valid) pos = s_cursor[wave][digit] + rank;
+        if (valid) pos = s_cursor[wave * STR + digit] + rank;
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             if (keys_out) keys_out[pos] = k[r];     // (a caller that only wants the permutation passes null in the last pass)
             vals_out[pos] = v[r];
-            if (rank == count - 1) s_cursor[wave][digit] = pos + 1;
+            if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -238,13 +261,14 @@ int sort_passes(int nbits)
 
 template <typename KeyT, int BITS>
 static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout, const uint32_t *count_ptr,
-                      uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int nblocks,
+                      uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int /*unused*/,
                       uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st)
 {
+    const int nblocks = (nchunks + SortBlock<BITS>::kWaves - 1) / SortBlock<BITS>::kWaves;
     {
         ScopedTimer tm(T_SORT_HIST, st);
-        hipLaunchKernelGGL((sort_hist_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, count_ptr, cap, shift,
-                           cnt, nchunks);
+        hipLaunchKernelGGL((sort_hist_kernel<KeyT, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st, kin,
+                           count_ptr, cap, shift, cnt, nchunks);
     }
     SLS_LAUNCH_CHECK("sort_hist_kernel");
     {
@@ -254,7 +278,7 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
     SLS_LAUNCH_CHECK("sort_rowscan_kernel");
     {
         ScopedTimer tm(T_SORT_SCATTER, st);
-        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(256), 0, st, kin, vin, kout, vout,
+        hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st, kin, vin, kout, vout,
                            count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks, ranges_out,
                            nranges, packed_val_mask);
     }
