@@ -84,10 +84,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_hist_kernel
         const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
         KeyT k[kSortRounds];
 #pragma unroll
-        for (int r = 0; r < kSortRounds; ++r) {
-            const uint32_t idx = base + (uint32_t)r * 64;
-            k[r] = (idx < R) ? keys[idx] : (KeyT)0;
-        }
+        for (int r = 0; r < kSortRounds; ++r) k[r] = keys[min(base + (uint32_t)r * 64, R - 1u)];   // (chunk < nchunks: R >= 1)
 #pragma unroll
         for (int r = 0; r < kSortRounds; ++r) {
             const uint32_t idx = base + (uint32_t)r * 64;
@@ -154,18 +151,44 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
     __shared__ uint32_t s_digit_base[BINS];
     __shared__ uint32_t s_wave[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk0 = blockIdx.x * WAVES, chunk = chunk0 + wave;
+    // Everything the block needs from memory is requested up front — its items, its rows of the count
+    // table, the digit totals, the item count — so the waits below overlap into ONE round trip (with one
+    // wave per SIMD nothing else would hide them).  Loads are guarded by the buffers' capacity, validity
+    // (idx < R) is applied afterwards.
+    const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
+    KeyT k[kSortRounds];
+    uint32_t v[kSortRounds];
+    // (clamped addresses instead of predicated loads: a conditional load per round compiles into a branch
+    //  and a full wait per round — sixteen serialised round trips)
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) k[r] = keys_in[min(base + (uint32_t)r * 64, cap - 1u)];
+    if (vals_in) {
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) v[r] = vals_in[min(base + (uint32_t)r * 64, cap - 1u)];
+    } else {   // packed mode: the value is the low part of the key
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
+    }
+    constexpr int CPT = BINS / 64;             // count-table entries per thread: BINS * WAVES / (64 * WAVES)
+    uint32_t my_cnt[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = threadIdx.x + q * 64 * WAVES, d = idx / WAVES, w = idx % WAVES;
+        my_cnt[q] = (chunk0 + w < nchunks_cap) ? cnt[(size_t)d * nchunks_cap + chunk0 + w] : 0u;
+    }
+    const bool scanner = threadIdx.x < 256;
+    uint32_t tot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tot[q] = scanner ? totals[threadIdx.x * PER + q] : 0u;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
-    const int chunk0 = blockIdx.x * WAVES;
     if (chunk0 >= nchunks) return;   // whole block beyond the data
     {   // exclusive scan of the BINS digit totals (PER consecutive ones per thread, first 256 threads)
-        const bool scanner = threadIdx.x < 256;
         uint32_t loc[PER];
         uint32_t v = 0;
-        if (scanner) {
 #pragma unroll
-            for (int k = 0; k < PER; ++k) { loc[k] = v; v += totals[threadIdx.x * PER + k]; }
-        }
+        for (int k = 0; k < PER; ++k) { loc[k] = v; v += tot[k]; }
         uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
                     const int d = threadIdx.x * PER + k;
-                    const uint32_t b0 = wave_prefix + incl - v + loc[k], c = totals[d];
+                    const uint32_t b0 = wave_prefix + incl - v + loc[k], c = tot[k];
                     if (d < nranges) ranges_out[d] = c ? make_uint2(b0, b0 + c) : make_uint2(0u, 0u);
                 }
             }
@@ -192,24 +215,13 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
         __syncthreads();
     }
     // cursors of the block's WAVES chunks: runs of WAVES consecutive counts per digit (see sort_hist_kernel)
-    for (int idx = threadIdx.x; idx < BINS * WAVES; idx += 64 * WAVES) {
-        const int d = idx / WAVES, w = idx % WAVES;
-        if (chunk0 + w < nchunks_cap) s_cursor[w * STR + d] = s_digit_base[d] + cnt[(size_t)d * nchunks_cap + chunk0 + w];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = threadIdx.x + q * 64 * WAVES, d = idx / WAVES, w = idx % WAVES;
+        s_cursor[w * STR + d] = s_digit_base[d] + my_cnt[q];
     }
     __syncthreads();
-    const int chunk = chunk0 + wave;
     if (chunk >= nchunks) return;
-    const uint32_t base = (uint32_t)chunk * kSortWaveItems + lane;
-    KeyT k[kSortRounds];
-    uint32_t v[kSortRounds];
-#pragma unroll
-    for (int r = 0; r < kSortRounds; ++r) {
-        const uint32_t idx = base + (uint32_t)r * 64;
-        const bool valid = idx < R;
-        k[r] = valid ? keys_in[idx] : (KeyT)0;
-        // packed mode (vals_in == null): the value is the low part of the key
-        v[r] = valid ? (vals_in ? vals_in[idx] : ((uint32_t)k[r] & packed_val_mask)) : 0u;
-    }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
