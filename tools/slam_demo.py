@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Mapping + tracking on a synthetic sequence, every hot component in its reference role:
-scan -> range image (room ray caster) -> surfels initialised as Mapper.densify does
+scan (room ray caster) -> point cloud -> range image on the device (projector.DeviceProjector, the job of
+scene/preprocessing.py:42-64) -> surfels initialised as Mapper.densify does
 (slam/mapper.py:100-135: one surfel per sampled pixel, scale from distCUDA2, normal-aligned,
 opacity 0.9) -> MappingEngine iterations on the keyframe -> for the following scans:
 render the keyframe from the model (render()), register the scan against it
@@ -18,6 +19,7 @@ from simple_knn._C import distCUDA2
 from splat_loam_amd import synth
 from splat_loam_amd.engine import MappingEngine
 from splat_loam_amd.mapping import MappingConfig
+from splat_loam_amd.projector import DeviceProjector
 from splat_loam_amd.renderer import depth_to_points, render
 from splat_loam_amd.scene import Camera, SurfelModel
 
@@ -72,10 +74,20 @@ def run(H=64, W=1024, n_frames=6, n_iter=60, verbose=True, dev="cuda:0"):
     depth_err = float(np.abs(rd - d0)[(d0 > 0.5) & (rd > 0.5)].mean())
     kf_T_frame = torch.eye(4, device=dev)
     errs, fits, t_track = [], [], 0.0
+    proj = DeviceProjector(H, W, 0.5, 100.0, device=dev)
+    Kd = torch.tensor(K.reshape(-1), dtype=torch.float32, device=dev)
     for k in range(1, n_frames):
         dk, pk = scans[k]
+        # the scan arrives as an unordered point cloud; the projector turns it into the query images on the device
+        cloud = pk[dk > 0.5].astype(np.float32)
+        cloud = torch.tensor(cloud[np.random.default_rng(k).permutation(len(cloud))], device=dev)
+        lut, q_depth, _, q_valid = proj.project(cloud, Kd)
+        q_points = cloud[lut.reshape(-1).clamp_min(0).long()] * q_valid.reshape(-1, 1)
+        if k == 1:
+            assert float((q_depth.cpu() - torch.tensor(dk)).abs().max()) < 1e-4, "projector disagrees with the ray caster"
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
-        al.set_query(torch.tensor(dk, device=dev)[None], torch.tensor(pk.reshape(-1, 3), device=dev), cam0.projection_matrix)
+        al.set_query(q_depth[None], q_points, cam0.projection_matrix)
         kf_T_frame, fitness, info = al.align(kf_T_frame)
         torch.cuda.synchronize(); t_track += time.perf_counter() - t1
         gt = np.linalg.inv(poses[0]) @ poses[k]
