@@ -229,13 +229,27 @@ def test_cpu_tensors_are_refused():
 def test_knn_bitexact(device, oracle32):
     from splat_loam_amd.knn import distCUDA2
     from splat_loam_amd import synth
-    for M, seed in ((1, 0), (3, 1), (4, 2), (257, 3), (6000, 4)):
+    # sizes around the kernel's granularities: 32-point runs, 64-point waves, 256-point boxes, 64-box chunks
+    for M, seed in ((1, 0), (3, 1), (4, 2), (31, 5), (63, 6), (64, 7), (65, 8), (255, 9), (256, 10), (257, 3), (513, 11),
+                    (6000, 4), (20000, 12)):
         pts = synth.make_scene(M, 64, 1024, seed=seed)["means"]
         got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
         ref = oracle32.knn_dist2(pts)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"M={M}"
     # duplicates and collinear points
     pts = np.repeat(np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [5, 0, 0]], np.float32), 3, axis=0)
+    got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), oracle32.knn_dist2(pts).view(np.uint32))
+    # a LiDAR-like cloud: two walls, a dense cluster, isolated far returns and 300 copies of one point
+    # (very different local densities in one wave, zero distances, bounds that must stay conservative)
+    rng = np.random.default_rng(21)
+    wall1 = np.stack([rng.uniform(-20, 20, 6000), np.full(6000, 8.0), rng.uniform(-2, 3, 6000)], 1)
+    wall2 = np.stack([np.full(4000, -15.0), rng.uniform(-30, 30, 4000), rng.uniform(-2, 6, 4000)], 1)
+    cluster = rng.normal(0, 0.02, (3000, 3)) + np.array([3.0, -2.0, 0.5])
+    far = rng.uniform(-150, 150, (40, 3))
+    same = np.tile(np.array([[1.25, 2.5, -0.75]]), (300, 1))
+    pts = np.concatenate([wall1, wall2, cluster, far, same]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
     got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), oracle32.knn_dist2(pts).view(np.uint32))
 
