@@ -322,36 +322,34 @@ __global__ __launch_bounds__(64) void knn_query_kernel(int M, int nboxes, const 
             ns += __builtin_popcountll(sm);
         }
         __syncthreads();
-        // c. 64 listed sub-boxes at a time: lane k holds the bounds of candidate k (one parallel load), the
-        //    wave walks them with v_readlane broadcasts — no memory latency per candidate.  The points of the
-        //    next candidate that passes are fetched while the current one is scanned.
+        // c. 64 listed sub-boxes at a time, lane = candidate: the exact test — can it improve ANY of the 64
+        //    query points? — runs for all 64 candidates at once (the queries are broadcast with v_readlane);
+        //    the survivors are scanned one after the other, the next one's points are fetched meanwhile.
         for (int base = 0; base < ns; base += 64) {
             const int nk = min(64, ns - base);
             const uint32_t sbl = s_sub[base + min(lane, nk - 1)];
             const float4 mnl = subboxes[2 * (size_t)sbl], mxl = subboxes[2 * (size_t)sbl + 1];
-            auto wanted = [&](int k) -> bool {      // can candidate k still improve some lane?
-                const float4 mn = make_float4(rl(mnl.x, k), rl(mnl.y, k), rl(mnl.z, k), 0.0f);
-                const float4 mx = make_float4(rl(mxl.x, k), rl(mxl.y, k), rl(mxl.z, k), 0.0f);
-                return __ballot(live && box_gap2(me, me, mn, mx) * 0.99999f <= b2) != 0;
-            };
+            const float qb2 = live ? b2 : -1.0f;
+            bool need = false;
+            for (int qi = 0; qi < 64; ++qi) {
+                const float4 qp = make_float4(rl(me.x, qi), rl(me.y, qi), rl(me.z, qi), 0.0f);
+                need = need || (box_gap2(qp, qp, mnl, mxl) * 0.99999f <= rl(qb2, qi));
+            }
+            uint64_t todo = __ballot(need && lane < nk);
             auto fetch = [&](int k) -> float4 {     // lanes 0..31: the points of candidate k (sentinels beyond M)
                 const int i = __builtin_amdgcn_readlane((int)sbl, k) * kKnnSub + (lane & (kKnnSub - 1));
                 return i < M ? pts[i] : make_float4(1.0e30f, 1.0e30f, 1.0e30f, 0.0f);
             };
-            int k = 0;
-            while (k < nk && !wanted(k)) ++k;
             float4 pre = make_float4(0, 0, 0, 0);
-            if (k < nk) pre = fetch(k);
-            while (k < nk) {
-                int kn = k + 1;
-                while (kn < nk && !wanted(kn)) ++kn;       // (tested with the bounds before this scan: conservative)
+            if (todo) pre = fetch(__builtin_ctzll(todo));
+            while (todo) {
+                todo &= todo - 1;
                 const float4 cur = pre;
-                if (kn < nk) pre = fetch(kn);
+                if (todo) pre = fetch(__builtin_ctzll(todo));
                 __builtin_amdgcn_wave_barrier();
                 if (lane < kKnnSub) s_run[lane] = cur;
                 __syncthreads();
                 knn_scan32<false>(s_run, me, -1, b0, b1, b2);    // (a lane that did not need it cannot be changed by it)
-                k = kn;
             }
         }
     }
