@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 
 __global__ __launch_bounds__(256) void knn_morton_kernel(int M, const float *__restrict__ xyz,
                                                          const uint32_t *__restrict__ bbox,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, int key_bits)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void knn_morton_kernel(int M, const float *__r
     for (uint32_t Q = 512u; Q > 1u; Q >>= 1)
         if (X[2] & Q) t ^= Q - 1u;
     X[0] ^= t; X[1] ^= t; X[2] ^= t;
-    keys[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+    // small clouds are sorted on the top 21 bits only (two 11-bit radix passes instead of three 10-bit ones;
+    // points of one 2^-7 cell stay in input order): measured faster up to ~200 k points, slower beyond
+    keys[i] = ((spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2])) >> (30 - key_bits);
     vals[i] = (uint32_t)i;
 }
 
@@ -402,15 +404,16 @@ int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratc
         return SLS_E_ARG;
     }
     const int nb = (M + 255) / 256;
+    const int key_bits = M <= 200000 ? 21 : 30;
     ScopedTimer tm(T_KNN, st);
     hipLaunchKernelGGL(knn_init_bbox_kernel, dim3(1), dim3(64), 0, st, s.bbox, (uint32_t)M);
     SLS_LAUNCH_CHECK("knn_init_bbox_kernel");
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 256 ? nb : 256), dim3(256), 0, st, M, xyz, s.bbox);
     SLS_LAUNCH_CHECK("knn_bbox_kernel");
-    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, st, M, xyz, s.bbox, s.keys, s.vals);
+    hipLaunchKernelGGL(knn_morton_kernel, dim3(nb), dim3(256), 0, st, M, xyz, s.bbox, s.keys, s.vals, key_bits);
     SLS_LAUNCH_CHECK("knn_morton_kernel");
     int which = 0;
-    int rc = radix_sort_pairs_u32(s.keys, s.vals, s.keys_tmp, s.vals_tmp, s.bbox + 6, (uint32_t)M, 30, s.sort,
+    int rc = radix_sort_pairs_u32(s.keys, s.vals, s.keys_tmp, s.vals_tmp, s.bbox + 6, (uint32_t)M, key_bits, s.sort,
                                   s.sort_bytes, &which, st);
     if (rc) return rc;
     const int nboxes = (M + kKnnBox - 1) / kKnnBox;
