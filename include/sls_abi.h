@@ -179,7 +179,9 @@ typedef struct SlsMappingConfig {
     float lambda_alpha, lambda_normal, scaling_max, scaling_max_penalty, depth_ratio;
     float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
     int32_t apply_adam;   /* 0: gradients only (all-reduce them, then sls_adam_step) */
-    int32_t reuse_depth_order; /* 1: the workspace still holds the depth order of the previous iteration on the
+    int32_t reuse_depth_order; /* 0: sort from scratch.  2 (up to 4): as 1 with that many repair rounds, each of which
+                                * lets a surfel travel one more window of 1024 positions (+16 us per extra round).
+                                * 1: the workspace still holds the depth order of the previous iteration on the
                                 * SAME keyframe and surfel set: repair it (windowed re-sort + verification)
                                 * instead of sorting from scratch.  If the repair does not reach the exact
                                 * order, bit 1 of status.overflow is set, Adam is skipped, repeat with 0. */

@@ -450,6 +450,37 @@ __global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, cons
     }
 }
 
+// Second repair round, first half (reuse_depth_order = 2): after one round the array is sorted inside every
+// SHIFTED window, so an aligned window is again two sorted halves — merged here (10 stages instead of the 55
+// of a sort); followed by resort_merge_kernel once more.  Every round lets a surfel travel another window.
+__global__ __launch_bounds__(kResortThreads) void resort_merge_aligned_kernel(int N, const uint32_t *__restrict__ order,
+                                                                              const uint32_t *__restrict__ keys_by_surfel,
+                                                                              uint64_t *__restrict__ comp)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
+    const int base = blockIdx.x * kResortWindow;
+#pragma unroll
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x;
+        // the second half is loaded back to front: ascending + descending = bitonic
+        const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
+        const int pos = base + src;
+        uint64_t c = ~0ull;                        // padding behind the end sorts last
+        if (pos < N) {
+            const uint32_t g = order[pos];
+            c = ((uint64_t)keys_by_surfel[g] << 32) | g;
+        }
+        s_a[o] = c;
+    }
+    __syncthreads();
+    bitonic_lds<kResortWindow>(s_a);
+#pragma unroll
+    for (int q = 0; q < kResortE; ++q) {
+        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
+        if (pos < N) comp[pos] = s_a[o];
+    }
+}
+
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
 // Also produces level 1 of the scan of tiles_touched (the sums of the four aligned 256-blocks a
 // window covers), which saves the gather_block_sums launch.
@@ -721,6 +752,14 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order, edges,
                            tiles, block_sums);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
+        for (int round = 1; round < reuse_order; ++round) {   // (reuse_order = 2: one more round, twice the reach)
+            hipLaunchKernelGGL(resort_merge_aligned_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
+                               (const uint32_t *)keys, comp);
+            SLS_LAUNCH_CHECK("resort_merge_aligned_kernel");
+            hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order,
+                               edges, tiles, block_sums);
+            SLS_LAUNCH_CHECK("resort_merge_kernel");
+        }
         resort_windows = nB;
         resort_edges = edges;
     } else {

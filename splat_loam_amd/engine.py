@@ -55,10 +55,14 @@ class MappingEngine:
         self._lag_host = torch.zeros((2, 8), dtype=torch.int32).pin_memory()
         self._lag_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self._group = None
+        self._lag_ready = []              # statuses of finished iterations not handed out yet (lagged mode)
+        self.flushed = []
         self._lag_pending = None          # (slot, camera) of the iteration whose status was not read yet
         # temporal re-sort: the workspace keeps the depth order of the last iteration; it is repaired
         # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
         self.reuse_depth_order = True
+        self.repair_span = 256            # iterations an extra repair round stays on after a repair that did not reach
+        self._repair_rounds, self._repair_until = 1, 0
         # single GPU: Adam is applied inside the backward; the flat gradient bucket is only filled when asked
         # for (the reference drops its gradients right after optimizer.step() as well)
         self.keep_grads = False
@@ -95,7 +99,7 @@ class MappingEngine:
 
     def _config(self, apply_adam, with_regulariser, reuse_order=False):
         c, cfg = _abi.SlsMappingConfig(), self.cfg
-        c.reuse_depth_order = 1 if reuse_order else 0
+        c.reuse_depth_order = int(reuse_order)      # 0: from scratch, 1 / 2: repair with that many rounds
         c.keep_grads = 1 if self.keep_grads else 0
         c.workspace_ready = 1 if self._ws_ready else 0
         self._ws_ready = True
@@ -108,10 +112,13 @@ class MappingEngine:
         c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
         return c
 
-    def _forget_order(self, camera):
+    def _forget_order(self, camera, failed_repair=False):
         ent = self._orders.get(id(camera))
         if ent is not None:
             ent[1] = None
+        if failed_repair:
+            self._repair_rounds = min(self._repair_rounds + 1, 3)
+            self._repair_until = self._enq + self.repair_span
 
     def _params(self):
         m = self.model
@@ -138,6 +145,12 @@ class MappingEngine:
             ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None]
             self._orders[id(camera)] = ent
         reuse = self.reuse_depth_order and ent[1] is not None and self._enq - ent[1] <= self.max_order_age
+        # after a failed repair the following iterations repair with one more round (one more window of reach,
+        # +16 us); every `repair_span` iterations without a failure the number of rounds steps down again
+        if self._repair_rounds > 1 and self._enq >= self._repair_until:
+            self._repair_rounds -= 1
+            self._repair_until = self._enq + self.repair_span
+        reuse = self._repair_rounds if reuse else 0
         self._enq += 1
         ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
@@ -203,7 +216,7 @@ class MappingEngine:
                 return st
             # repeat the iteration (parameters were not touched): with the full sort, and with more
             # room if the instance buffers were too small
-            self._forget_order(camera)
+            self._forget_order(camera, failed_repair=st["resort_failed"])
             self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
             if st["too_small"]:
                 need = st["R"]
@@ -236,7 +249,11 @@ class MappingEngine:
         self.t += 1
         self._lag_ev[slot].record(torch.cuda.current_stream(self.dev))
         prev, self._lag_pending = self._lag_pending, (slot, camera)
-        return None if prev is None else self._lag_collect(prev, redo_current=True)
+        if prev is not None:
+            self._lag_collect(prev, redo_current=True)
+        # every iteration's status is handed out exactly once, oldest first (a repeated iteration makes two
+        # of them available at once: the next call returns the second)
+        return self._lag_ready.pop(0) if self._lag_ready else None
 
     def _lag_collect(self, prev, redo_current):
         pslot, pcam = prev
@@ -244,6 +261,7 @@ class MappingEngine:
         st = self._parse_status(self._lag_host[pslot].clone())
         if not st["overflow"]:
             self.last = st
+            self._lag_ready.append(st)
             return st
         # The instance buffers were too small: that iteration skipped its Adam update on the
         # device, and so did the one enqueued after it (same capacity).  Drain, grow, redo.
@@ -252,27 +270,39 @@ class MappingEngine:
         cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
         cur_void = cur_st is not None and cur_st["overflow"]
         self.t -= 2 if cur_void else 1
-        self._forget_order(pcam)                    # repeat with the full sort
+        self._forget_order(pcam, failed_repair=st["resort_failed"])     # repeat with the full sort
         if cur_void:
-            self._forget_order(cur[1])
+            self._forget_order(cur[1], failed_repair=cur_st["resort_failed"])
         self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
         if st["too_small"] or (cur_void and cur_st["too_small"]):
             need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
             self.capacity = int(need * self.capacity_factor) + 1024
             self.workspace = None
+        if cur_st is not None and not cur_void:
+            self._lag_ready.append(cur_st)   # (another keyframe that fitted: it did run, nothing to repeat)
         st = self.step(pcam, group=self._group, sync=True)
-        if cur_void and redo_current:
-            self._step_lagged(cur[1])
-        elif cur_st is not None and not cur_void:
-            self.last = cur_st          # (another keyframe that fitted: it did run, nothing to repeat)
+        self._lag_ready.append(st)
+        if cur_void:
+            if redo_current:
+                # (not through _step_lagged: its return value would take a status off the queue)
+                self._redo_pending(cur[1])
+            else:
+                self._lag_ready.append(self.step(cur[1], group=self._group, sync=True))
         return st
 
+    def _redo_pending(self, camera):
+        ready, self._lag_ready = self._lag_ready, []
+        self._step_lagged(camera)                    # enqueues it again; nothing older is pending
+        self._lag_ready = ready + self._lag_ready
+
     def flush(self):
-        """Status of the last lagged iteration (None if nothing is pending)."""
-        if self._lag_pending is None:
-            return None
-        prev, self._lag_pending = self._lag_pending, None
-        return self._lag_collect(prev, redo_current=False)
+        """Drains the lagged pipeline: returns the status of the LAST iteration (None if there was none);
+        `self.flushed` lists every status that had not been handed out yet, oldest first."""
+        if self._lag_pending is not None:
+            prev, self._lag_pending = self._lag_pending, None
+            self._lag_collect(prev, redo_current=False)
+        self.flushed, self._lag_ready = self._lag_ready, []
+        return self.flushed[-1] if self.flushed else None
 
     def _adam_reduced(self, status, mirror):
         lib = _abi.lib()

@@ -541,6 +541,56 @@ def test_mapping_engine_depth_order_repair(device, N):
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.02 * moved, k
 
 
+def test_depth_order_repair_rounds(device):
+    """A surfel that has to travel more than half a window (512 positions) defeats one repair round — the
+    iteration is voided and repeated — but not two; the engine switches to two rounds after such a failure."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 30000, 32, 512
+    sc = synth.make_scene(N, H, W, seed=16, range_lo=2.0, range_hi=25.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, None, data_device=str(device))
+    # a radial perturbation that moves the worst surfel 600..1400 positions in the depth order
+    rng = np.random.default_rng(3)
+    r0 = np.linalg.norm(sc["means"], axis=1)
+    noise = rng.uniform(-1.0, 1.0, N)
+    rank0 = np.argsort(np.argsort(r0, kind="stable"), kind="stable")
+    amp = None
+    for a in np.geomspace(1e-4, 0.2, 60):
+        disp = np.abs(np.argsort(np.argsort(r0 * (1 + a * noise), kind="stable"), kind="stable") - rank0).max()
+        if 600 <= disp <= 1400:
+            amp = a
+            break
+    assert amp is not None
+    f = torch.tensor(1 + amp * noise, dtype=torch.float32, device=device)[:, None]
+    engines = []
+    for rounds in (0, 1, 2):
+        m = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+        e = MappingEngine(m, MappingConfig())
+        e.reuse_depth_order = rounds > 0
+        e._repair_rounds, e._repair_until = max(rounds, 1), 10 ** 9
+        engines.append((e, m))
+    losses = []
+    for e, m in engines:
+        ls = [e.step(cam)["loss"], e.step(cam)["loss"]]
+        with torch.no_grad():
+            m._xyz.mul_(f)
+        ls += [e.step(cam)["loss"], e.step(cam)["loss"]]
+        losses.append(ls)
+    assert engines[0][0].stats["repeated_resort"] == 0
+    assert engines[1][0].stats["repeated_resort"] == 1, "one round cannot reach: void + repeat with the full sort"
+    assert engines[1][0]._repair_rounds == 2, "and the engine repairs with two rounds from then on"
+    assert engines[2][0].stats["repeated_resort"] == 0, "two rounds reach"
+    for ls in losses[1:]:
+        for a, b in zip(losses[0], ls):
+            assert abs(a - b) <= 1e-5 * abs(a), losses
+    o0 = engines[0][0]._orders[id(cam)][0].cpu().numpy()
+    for e, _ in engines[1:]:          # the exact (key, index) order, bit for bit
+        assert np.array_equal(e._orders[id(cam)][0].cpu().numpy(), o0)
+
+
 @pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (3, 3)],
                          ids=["workgroup-per-tile", "wave-per-subtile", "block4x4-fwd", "block4x4-bwd", "block4x4", "block8x2"])
 def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
