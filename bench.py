@@ -312,8 +312,9 @@ def main():
                    "status_read": {True: "sync", False: "async", "lagged": "lagged-1"}[status_read]
                    if engine is not None else "torch",
                    "depth_order": ("repaired from the previous iteration, verified exact"
-                                   if (engine is not None and engine.reuse_depth_order)
-                                   else "sorted from scratch")},
+                                   if (engine is not None and engine.reuse_depth_order and status_read is not False)
+                                   else "sorted from scratch"),
+                   "repeated_iterations": dict(engine.stats) if engine is not None else None},
         "roofline": roofline, "cpu_baseline": cpu, "kernels": breakdown,
     }
     print(json.dumps(out))

@@ -128,7 +128,7 @@ class MappingEngine:
                 raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
         return ps
 
-    def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None):
+    def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None, allow_reuse=True):
         lib = _abi.lib()
         H, W = int(camera.image_height), int(camera.image_width)
         settings = GaussianRasterizationSettings(H, W, 1.0, camera.world_view_transform, camera.projection_matrix)
@@ -144,7 +144,8 @@ class MappingEngine:
                 self._orders.pop(next(iter(self._orders)))
             ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None]
             self._orders[id(camera)] = ent
-        reuse = self.reuse_depth_order and ent[1] is not None and self._enq - ent[1] <= self.max_order_age
+        reuse = (allow_reuse and self.reuse_depth_order and ent[1] is not None
+                 and self._enq - ent[1] <= self.max_order_age)
         # after a failed repair the following iterations repair with one more round (one more window of reach,
         # +16 us); every `repair_span` iterations without a failure the number of rounds steps down again
         if self._repair_rounds > 1 and self._enq >= self._repair_until:
@@ -194,12 +195,15 @@ class MappingEngine:
             return self._step_lagged(camera)
         if self._lag_pending is not None:
             self.flush()
+        # Fire-and-forget iterations sort from scratch: nobody would notice a repair that did not reach, and every
+        # later repair of that keyframe would start from the broken order and void its iteration as well.
+        reuse_ok = sync is not False
         while True:
             if not sharded:
-                self._enqueue(camera, apply_adam=True, with_regulariser=True)
+                self._enqueue(camera, apply_adam=True, with_regulariser=True, allow_reuse=reuse_ok)
             else:
                 rank = dist.get_rank(group)
-                self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0))
+                self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0), allow_reuse=reuse_ok)
                 # the step left its two void flags behind the gradients (cfg.void_flags_out): one collective,
                 # no torch glue kernels
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
