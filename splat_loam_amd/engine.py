@@ -327,6 +327,43 @@ class MappingEngine:
                                              torch.cuda.current_stream(self.dev).cuda_stream),
                    "sls_adam_step_reduced")
 
+    @torch.no_grad()
+    def remap(self, keep=None, appended: int = 0):
+        """The model's surfel set changed — call this AFTER replacing the model's parameter tensors, as
+        Mapper.densify / the opacity pruning do through cat_tensors_to_optimizer / _prune_optimizer
+        (scene/gaussian_model.py:223-316).  `keep`: bool (N_old,), the survivors in their old order (None: all);
+        `appended`: number of new surfels that follow them.  The Adam moments of the survivors are kept, the new
+        surfels start from zero moments and the step count goes on, exactly as the reference's optimizer state."""
+        if self._lag_pending is not None or self._lag_ready:
+            self.flush()
+        n_old = self.N
+        if keep is None:
+            keep = torch.ones((n_old,), dtype=torch.bool, device=self.dev)
+        keep = keep.to(self.dev).reshape(-1)
+        if keep.dtype != torch.bool or keep.numel() != n_old or appended < 0:
+            raise ValueError("keep must be a bool mask over the engine's current surfels, appended >= 0")
+        n_keep = int(keep.sum().item())
+        n_new = n_keep + int(appended)
+        if int(self.model._xyz.shape[0]) != n_new:
+            raise RuntimeError(f"the model holds {int(self.model._xyz.shape[0])} surfels, keep/appended describe {n_new}")
+
+        def carry(buf):
+            out = torch.zeros((10 * n_new,), dtype=torch.float32, device=self.dev)
+            src_off = dst_off = 0
+            for width in (3, 1, 2, 4):              # bucket layout [xyz 3N | opacity N | scaling 2N | rotation 4N]
+                src = buf[src_off:src_off + width * n_old].view(n_old, width)
+                out[dst_off:dst_off + width * n_keep].view(n_keep, width).copy_(src[keep])
+                src_off += width * n_old
+                dst_off += width * n_new
+            return out
+
+        self.exp_avg, self.exp_avg_sq = carry(self.exp_avg), carry(self.exp_avg_sq)
+        self.N = n_new
+        self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)
+        self.workspace = None                        # sized by N: rebuilt at the next step
+        self._orders.clear()                         # surfel indices changed: every kept depth order is void
+        self._params()
+
     def allmap(self, H, W) -> torch.Tensor:
         """Copy of the last iteration's allmap (7,H,W) out of the workspace."""
         off = int(self.allmap_ptr.value) - self.workspace.data_ptr()

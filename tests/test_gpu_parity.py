@@ -541,6 +541,62 @@ def test_mapping_engine_depth_order_repair(device, N):
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.02 * moved, k
 
 
+def test_mapping_engine_remap_after_prune_and_densify(device):
+    """Between keyframes the reference prunes and densifies (scene/gaussian_model.py:223-316): the engine carries
+    the Adam moments of the surviving surfels over, starts the new ones at zero and keeps counting steps —
+    checked against torch.optim.Adam over the torch pipeline going through the same surgery."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig, optimize_step
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 6000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=41, range_lo=2.0, range_hi=15.0)
+    extra = synth.make_scene(500, H, W, seed=42, range_lo=2.0, range_hi=15.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, None, data_device=str(device))
+    cfg = MappingConfig()
+    a = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+    b = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+    eng = MappingEngine(a, cfg)
+    b.training_setup(fused=False)                       # torch.optim.Adam, one group per tensor
+    for _ in range(3):
+        eng.step(cam)
+        optimize_step(b, cam, cfg)
+    keep = torch.rand(N, generator=torch.Generator().manual_seed(1)) > 0.3
+    new = SurfelModel.from_activated(extra["means"], extra["scales"], extra["rots"], extra["opac"], device=str(device))
+
+    def surgery(m, opt):
+        for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            old = getattr(m, name)
+            p = torch.nn.Parameter(torch.cat([old.detach()[keep.to(device)], getattr(new, name).detach()]).contiguous())
+            if opt is not None:                         # what cat_tensors_to_optimizer / _prune_optimizer do
+                grp = next(g for g in opt.param_groups if g["params"][0] is old)
+                st = opt.state.pop(old)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    st[k] = torch.cat([st[k][keep.to(device)], torch.zeros_like(getattr(new, name))])
+                grp["params"][0] = p
+                opt.state[p] = st
+            setattr(m, name, p)
+
+    moments_before = eng.exp_avg[:3 * N].view(N, 3)[keep.to(device)].clone()
+    surgery(a, None)
+    eng.remap(keep, appended=500)
+    surgery(b, b.optimizer)
+    n2 = int(keep.sum()) + 500
+    assert eng.N == n2 and torch.equal(eng.exp_avg[:3 * n2].view(n2, 3)[:n2 - 500], moments_before)
+    assert float(eng.exp_avg[:3 * n2].view(n2, 3)[n2 - 500:].abs().max()) == 0.0
+    start = a._xyz.detach().clone()
+    for _ in range(3):
+        st = eng.step(cam)
+        optimize_step(b, cam, cfg)
+    assert eng.t == 6 and np.isfinite(st["loss"])
+    moved = float((a._xyz.detach() - start).abs().max())
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        assert float((getattr(a, name).detach() - getattr(b, name).detach()).abs().max()) <= 0.05 * moved + 1e-6, name
+    with pytest.raises(RuntimeError):
+        eng.remap(None, appended=7)                     # the model was not resized accordingly
+
+
 def test_depth_order_repair_rounds(device):
     """A surfel that has to travel more than half a window (512 positions) defeats one repair round — the
     iteration is voided and repeated — but not two; the engine switches to two rounds after such a failure."""
