@@ -196,3 +196,20 @@ def test_mapping_then_tracking_against_the_rendered_keyframe(device):
     assert out["depth_err"] < 0.30                                  # rendered keyframe vs the scan it was built from (m)
     for (dt, da), fit in zip(out["errs"], out["fits"]):
         assert dt < 0.08 and da < math.radians(0.4) and fit > 0.6, (out["errs"], out["fits"])
+
+
+@pytest.mark.gpu
+def test_sequence_tracking_densify_optimize_prune(device):
+    """The reference's per-frame loop on a synthetic sequence with every component of this
+    repository in its role (tools/slam_demo.py::run_sequence): DeviceProjector -> GSAligner against the rendered
+    keyframe -> keyframes at the ESTIMATED poses: densify (distCUDA2 scales), MappingEngine.remap, iterations over
+    geometrically sampled keyframes, opacity pruning, remap.  No ground truth enters after frame 0: the pose error
+    must not accumulate."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import slam_demo
+    out = slam_demo.run_sequence(H=32, W=512, n_frames=9, kf_every=4, n_iter=40, verbose=False, dev=str(device))
+    assert [k for k, *_ in out["log"]] == [0, 4, 8]
+    assert all(n_new > 0 for _, n_new, _, _ in out["log"]) and out["N"] > 5000
+    errs = out["errs"]
+    assert max(e[0] for e in errs) < 0.10 and max(e[1] for e in errs) < math.radians(0.5), errs
+    assert errs[-1][0] < errs[1][0] + 0.03, "drift"

@@ -101,6 +101,117 @@ def run(H=64, W=1024, n_frames=6, n_iter=60, verbose=True, dev="cuda:0"):
     return dict(losses=losses, errs=errs, fits=fits, depth_err=depth_err, N=eng.N)
 
 
+def _new_surfels(points_world, normals_world, existing_xyz, smax, dev):
+    """Parameters of densified surfels (slam/mapper.py:100-135): scale from distCUDA2 over new + existing
+    centres, normal-aligned rotation, opacity 0.9."""
+    n = normals_world / np.linalg.norm(normals_world, axis=1, keepdims=True)
+    helper = np.where(np.abs(n[:, 2:3]) < 0.9, np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
+    t0 = np.cross(n, helper); t0 /= np.linalg.norm(t0, axis=1, keepdims=True)
+    rots = synth._quat_from_R(np.stack([t0, np.cross(n, t0), n], 2))
+    xyz = torch.tensor(points_world, dtype=torch.float32, device=dev)
+    full = xyz if existing_xyz is None else torch.cat([xyz, existing_xyz.detach()])
+    d2 = torch.clamp(distCUDA2(full), 1e-7, smax ** 2)[:xyz.shape[0]]
+    return SurfelModel.from_activated(xyz, torch.sqrt(d2)[:, None].repeat(1, 2), torch.tensor(rots, dtype=torch.float32),
+                                      torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
+
+
+def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0"):
+    """Odometry + mapping over a sequence, the reference's per-frame loop with this repository's
+    components: every scan is registered against the latest keyframe as the MODEL renders it (tracker); every
+    `kf_every`-th frame becomes a keyframe at its ESTIMATED pose: densify where the model is transparent
+    (Mapper.densify), engine.remap, `n_iter` iterations over geometrically sampled keyframes (Mapper.optimize),
+    prune by opacity (Mapper.prune), engine.remap."""
+    dev = torch.device(dev)
+    rng = np.random.default_rng(0)
+    K = synth.spherical_K(H, W).astype(np.float64)
+    gt = [pose_of([0.25 * k, 0.04 * k, 0.0], yaw_deg=1.2 * k) for k in range(n_frames)]
+    cfg = MappingConfig()
+    proj = DeviceProjector(H, W, 0.5, 100.0, device=dev)
+    Kd = torch.tensor(K.reshape(-1), dtype=torch.float32, device=dev)
+
+    def frame(k):      # unordered cloud -> images on the device
+        dk, pk = room_scan(K, H, W, gt[k])
+        cloud = torch.tensor(pk[dk > 0.5][rng.permutation(int((dk > 0.5).sum()))].astype(np.float32), device=dev)
+        lut, depth, normals, valid = proj.project(cloud, Kd)
+        points = cloud[lut.reshape(-1).clamp_min(0).long()] * valid.reshape(-1, 1)
+        return depth, normals, valid, points
+
+    def add_keyframe(model, eng, est_pose, depth, normals, valid, points, first):
+        cam = Camera(K, depth[None], normals.permute(2, 0, 1), valid[None], est_pose, data_device=str(dev))
+        if first:
+            mask = valid.clone(); mask[:, 1::2] = False
+        else:
+            with torch.no_grad():
+                alpha = render(cam, model, cfg.depth_ratio)["rend_alpha"][0]
+            mask = (alpha <= 0.5) & valid                       # densify_threshold_opacity
+            mask &= torch.rand(mask.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(len(kfs))) < 0.5
+        sel = mask.reshape(-1).cpu().numpy()
+        n_new = int(sel.sum())
+        if n_new >= 2:
+            R, t = est_pose[:3, :3], est_pose[:3, 3]
+            pw = points.cpu().numpy()[sel].astype(np.float64) @ R.T + t
+            nw = normals.reshape(-1, 3).cpu().numpy()[sel].astype(np.float64) @ R.T
+            new = _new_surfels(pw, nw, None if first else model._xyz, cfg.opt_scaling_max, dev)
+            if first:
+                model = new
+                eng = MappingEngine(model, cfg)
+            else:
+                for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+                    setattr(model, name, torch.nn.Parameter(torch.cat([getattr(model, name).detach(), getattr(new, name).detach()]).contiguous()))
+                eng.remap(None, appended=n_new)
+        kfs.append(cam)
+        p = np.array([0.4 * 0.6 ** (len(kfs) - 1 - i) for i in range(len(kfs))]); p /= p.sum()   # sample_geometric
+        for it in range(n_iter):
+            eng.step(kfs[rng.choice(len(kfs), p=p)], sync="lagged")
+        eng.flush()
+        keep = model.get_opacity.detach().reshape(-1) >= 0.1         # pruning_min_opacity
+        if not bool(keep.all()):
+            for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+                setattr(model, name, torch.nn.Parameter(getattr(model, name).detach()[keep].contiguous()))
+            eng.remap(keep)
+        return model, eng, cam, n_new, int((~keep).sum())
+
+    kfs, est = [], [gt[0].copy()]
+    t0 = time.perf_counter()
+    model, eng, kf_cam, n_new, n_pruned = add_keyframe(None, None, est[0], *frame(0), first=True)
+    kf_pose = est[0]
+    log = [(0, n_new, n_pruned, eng.N)]
+    prm = GSAlignerParams(image_height=H, image_width=W)
+    al = GSAligner(**prm.__dict__)
+
+    def set_reference(cam):
+        with torch.no_grad():
+            ref_depth = render(cam, model, cfg.depth_ratio)["surf_depth"]
+            ref_points = depth_to_points(cam, ref_depth, transform_in_world=False).permute(1, 2, 0).reshape(-1, 3)
+        al.set_reference(ref_depth, ref_points, cam.projection_matrix)
+
+    set_reference(kf_cam)
+    kf_T_frame = torch.eye(4, device=dev)
+    errs = [(0.0, 0.0)]
+    for k in range(1, n_frames):
+        depth, normals, valid, points = frame(k)
+        al.set_query(depth[None], points, kf_cam.projection_matrix)
+        kf_T_frame, fitness, _ = al.align(kf_T_frame)
+        pose = kf_pose @ kf_T_frame.cpu().numpy().astype(np.float64)
+        est.append(pose)
+        errs.append(pose_error(pose, gt[k]))
+        if k % kf_every == 0:
+            model, eng, kf_cam, n_new, n_pruned = add_keyframe(model, eng, pose, depth, normals, valid, points, first=False)
+            kf_pose, kf_T_frame = pose, torch.eye(4, device=dev)
+            set_reference(kf_cam)
+            log.append((k, n_new, n_pruned, eng.N))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if verbose:
+        for k, n_new, n_pruned, n in log:
+            print(f"keyframe at frame {k}: +{n_new} surfels, -{n_pruned} pruned, model {n}")
+        print("pose error per frame [cm]:", " ".join(f"{e[0] * 100:.1f}" for e in errs))
+        print(f"{n_frames} frames, {len(kfs)} keyframes in {dt * 1e3:.0f} ms; final error {errs[-1][0] * 100:.2f} cm / {math.degrees(errs[-1][1]):.3f} deg "
+              f"after {np.linalg.norm(gt[-1][:3, 3]):.2f} m; engine stats {eng.stats}")
+    return dict(errs=errs, log=log, N=eng.N)
+
+
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:]]
-    run(*a)
+    if len(sys.argv) > 1 and sys.argv[1] == "sequence":
+        run_sequence(*[int(x) for x in sys.argv[2:]])
+    else:
+        run(*[int(x) for x in sys.argv[1:]])
