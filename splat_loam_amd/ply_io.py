@@ -18,8 +18,9 @@ PROPS = ["x", "y", "z", "opacity", "scale_0", "scale_1", "rot_0", "rot_1", "rot_
 
 
 def save_ply(path, xyz, opacity_raw, scaling_raw, rotation_raw) -> None:
-    xyz, opacity_raw, scaling_raw, rotation_raw = (np.asarray(a, dtype=np.float32) for a in
-                                                   (xyz, opacity_raw, scaling_raw, rotation_raw))
+    def host(a):      # NumPy, or tensors on any device (the reference saves `.detach().cpu().numpy()`, gaussian_model.py:133-141)
+        return np.asarray(a.detach().cpu().numpy() if hasattr(a, "detach") else a, dtype=np.float32)
+    xyz, opacity_raw, scaling_raw, rotation_raw = (host(a) for a in (xyz, opacity_raw, scaling_raw, rotation_raw))
     n = xyz.shape[0]
     data = np.concatenate([xyz.reshape(n, 3), opacity_raw.reshape(n, 1), scaling_raw.reshape(n, 2),
                            rotation_raw.reshape(n, 4), np.zeros((n, 3), np.float32)], axis=1).astype("<f4")

@@ -199,7 +199,7 @@ def test_mapping_then_tracking_against_the_rendered_keyframe(device):
 
 
 @pytest.mark.gpu
-def test_sequence_tracking_densify_optimize_prune(device):
+def test_sequence_tracking_densify_optimize_prune(device, tmp_path):
     """The reference's per-frame loop on a synthetic sequence with every component of this
     repository in its role (tools/slam_demo.py::run_sequence): DeviceProjector -> GSAligner against the rendered
     keyframe -> keyframes at the ESTIMATED poses: densify (distCUDA2 scales), MappingEngine.remap, iterations over
@@ -207,9 +207,18 @@ def test_sequence_tracking_densify_optimize_prune(device):
     must not accumulate."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import slam_demo
-    out = slam_demo.run_sequence(H=32, W=512, n_frames=9, kf_every=4, n_iter=40, verbose=False, dev=str(device))
+    out = slam_demo.run_sequence(H=32, W=512, n_frames=9, kf_every=4, n_iter=40, verbose=False, dev=str(device),
+                                 out_dir=str(tmp_path))
     assert [k for k, *_ in out["log"]] == [0, 4, 8]
     assert all(n_new > 0 for _, n_new, _, _ in out["log"]) and out["N"] > 5000
     errs = out["errs"]
     assert max(e[0] for e in errs) < 0.10 and max(e[1] for e in errs) < math.radians(0.5), errs
     assert errs[-1][0] < errs[1][0] + 0.03, "drift"
+    # the run's results in the reference's on-disk formats (slam/slam.py:130-170) read back
+    from splat_loam_amd import ply_io, traj_io
+    stamps, poses = traj_io.read_tum(tmp_path / "odom.txt")
+    assert len(poses) == 9 and pose_error(poses[-1], pose_of([0.25 * 8, 0.04 * 8, 0.0], yaw_deg=1.2 * 8))[0] < 0.10
+    ply = ply_io.load_ply(tmp_path / "models" / "0000.ply")
+    assert ply["xyz"].shape == (out["N"], 3)
+    g = traj_io.read_graph(tmp_path / "graph.yaml")
+    assert len(g["frames"]) == 9 and g["models"][0]["filename"] == "models/0000.ply"

@@ -115,7 +115,7 @@ def _new_surfels(points_world, normals_world, existing_xyz, smax, dev):
                                       torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
 
 
-def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0"):
+def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0", out_dir=None):
     """Odometry + mapping over a sequence, the reference's per-frame loop with this repository's
     components: every scan is registered against the latest keyframe as the MODEL renders it (tracker); every
     `kf_every`-th frame becomes a keyframe at its ESTIMATED pose: densify where the model is transparent
@@ -201,6 +201,17 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
             set_reference(kf_cam)
             log.append((k, n_new, n_pruned, eng.N))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if out_dir is not None:
+        # what SLAM.save_results leaves behind (slam/slam.py:130-170): odom.txt, graph.yaml, models/%04d.ply
+        from splat_loam_amd import ply_io, traj_io
+        os.makedirs(os.path.join(out_dir, "models"), exist_ok=True)
+        traj_io.write_tum(os.path.join(out_dir, "odom.txt"), est, [0.1 * k for k in range(n_frames)])
+        ply_io.save_ply(os.path.join(out_dir, "models", "0000.ply"), model._xyz.detach(), model._opacity.detach(),
+                        model._scaling.detach(), model._rotation.detach())
+        traj_io.write_graph(os.path.join(out_dir, "graph.yaml"),
+                            [dict(id=0, world_T_model=np.eye(4), filename="models/0000.ply", frame_ids=list(range(n_frames)))],
+                            [dict(id=k, timestamp=0.1 * k, model_T_frame=est[k], projmatrix=kf_cam.projection_matrix.cpu().numpy(),
+                                  model_id=0) for k in range(n_frames)])
     if verbose:
         for k, n_new, n_pruned, n in log:
             print(f"keyframe at frame {k}: +{n_new} surfels, -{n_pruned} pruned, model {n}")
