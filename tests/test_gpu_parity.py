@@ -597,6 +597,33 @@ def test_mapping_engine_remap_after_prune_and_densify(device):
         eng.remap(None, appended=7)                     # the model was not resized accordingly
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 16, 64), (2, 16, 64), (3, 16, 64), (100, 16, 64), (500, 48, 80), (1000, 128, 1024),
+                                   (50_000, 16, 16), (4096, 64, 8192), (300_000, 128, 4096)])
+def test_engine_edge_sizes(device, N, H, W):
+    """Whole iterations at the corners of the size space: fewer surfels than a wave / a sort chunk / an Adam
+    vector, a single tile, tile counts that are not a multiple of the XCD interleave, 2048 tiles (two-pass tile
+    sort), a capacity that has to grow; lagged status read throughout."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    sc = synth.make_scene(N, H, W, seed=N % 97)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, None, data_device=str(device))
+    model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+    eng = MappingEngine(model, MappingConfig())
+    losses = []
+    for it in range(6):
+        st = eng.step(cam, sync="lagged")
+        if st is not None:
+            losses.append(st["loss"])
+    losses.append(eng.flush()["loss"])
+    assert len(losses) == 6 and eng.t == 6 and all(np.isfinite(losses))
+    for p in (model._xyz, model._scaling, model._rotation, model._opacity):
+        assert bool(torch.isfinite(p).all())
+    assert eng.stats["repeated_resort"] == 0
+
+
 def test_depth_order_repair_rounds(device):
     """A surfel that has to travel more than half a window (512 positions) defeats one repair round — the
     iteration is voided and repeated — but not two; the engine switches to two rounds after such a failure."""
