@@ -606,8 +606,10 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
 {
     // pack_shift > 0 (vals == null): one word per instance, (tile << pack_shift) | surfel
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = (i < N) ? order[i] : 0u;
-    const uint32_t t = (i < N) ? tiles[g] : 0u;
+    // ONE dependent gather per surfel: the rectangle (all zeros for a culled surfel) also gives the tile count
+    const uint32_t g = order[min(i, N - 1)];
+    const int4 rc = rect[g];
+    const uint32_t t = (i < N) ? (uint32_t)(rc.y * rc.w) : 0u;
     uint32_t end;
     if (fused.block_sums) {
         // level 2 of the scan of tiles_touched done here (no scan launch, no offsets array): prefix of the
@@ -644,7 +646,6 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
         if (overflow) atomicOr(overflow, 1u);
         if (off >= cap) return;
     }
-    const int4 rc = rect[g];
     for (int y = 0; y < rc.w; ++y) {
         const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
         for (int k = 0; k < rc.y; ++k) {
