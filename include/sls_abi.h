@@ -191,7 +191,7 @@ typedef struct SlsMappingConfig {
                               * accumulation buffers inside the workspace zeroed for its successor */
     double beta1, beta2, eps;
     uint32_t *depth_order;   /* optional DEVICE buffer of N uint32: where this keyframe's depth order is kept
-                              * (read with reuse_depth_order = 1, always written); null: inside the workspace */
+                              * (read with reuse_depth_order >= 1, always written); null: inside the workspace */
     struct SlsMappingStatus *status_mirror; /* optional, HOST-visible (pinned, device-mapped) memory: the last
                               * kernel of the iteration copies *status_dev there, so the caller can read the
                               * status after an event/stream wait without enqueuing a device->host copy */
