@@ -18,6 +18,7 @@ Adam update.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -67,7 +68,7 @@ class MappingEngine:
         # for (the reference drops its gradients right after optimizer.step() as well)
         self.keep_grads = False
         self._ws_ready = False
-        import os
+        self._ws_hw = None
         self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
         # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
         # id(camera) -> [order tensor, iteration it was last written]; an order older than max_order_age
@@ -88,8 +89,8 @@ class MappingEngine:
 
     def _ensure_workspace(self, H, W, capacity):
         lib = _abi.lib()
-        if self.workspace is None or capacity > self.capacity:
-            self.capacity = int(capacity)
+        if self.workspace is None or capacity > self.capacity or (H, W) != self._ws_hw:
+            self.capacity, self._ws_hw = int(max(capacity, self.capacity)), (H, W)   # (keyframes of another size: re-carve)
             nbytes = int(lib.sls_mapping_workspace_bytes(self.N, H, W, self.capacity))
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
