@@ -153,11 +153,16 @@ __global__ __launch_bounds__(256) void consumer_c_kernel(ConsumerArgs a)
     float s;
     (void)surf_point(a, r, c, s);
     // gather the stencil adjoint: P(r,c) enters u(r-1,c) with +, u(r+1,c) with -, v(r,c-1) with +, v(r,c+1) with -
+    // (four unconditional loads at clamped addresses, masked afterwards: a load under a condition compiles into a
+    //  branch with a full wait each — four serialised round trips in a kernel that is nothing but latency)
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-    if (r > 0) { const float4 t = a.du[pix - a.W]; g0 += t.x; g1 += t.y; g2 += t.z; }
-    if (r < a.H - 1) { const float4 t = a.du[pix + a.W]; g0 -= t.x; g1 -= t.y; g2 -= t.z; }
-    if (c > 0) { const float4 t = a.dv[pix - 1]; g0 += t.x; g1 += t.y; g2 += t.z; }
-    if (c < a.W - 1) { const float4 t = a.dv[pix + 1]; g0 -= t.x; g1 -= t.y; g2 -= t.z; }
+    const bool up = r > 0, down = r < a.H - 1, left = c > 0, right = c < a.W - 1;
+    const float4 tu = a.du[up ? pix - a.W : pix], td = a.du[down ? pix + a.W : pix];
+    const float4 tl = a.dv[left ? pix - 1 : pix], tr = a.dv[right ? pix + 1 : pix];
+    g0 += up ? tu.x : 0.0f; g1 += up ? tu.y : 0.0f; g2 += up ? tu.z : 0.0f;
+    g0 -= down ? td.x : 0.0f; g1 -= down ? td.y : 0.0f; g2 -= down ? td.z : 0.0f;
+    g0 += left ? tl.x : 0.0f; g1 += left ? tl.y : 0.0f; g2 += left ? tl.z : 0.0f;
+    g0 -= right ? tr.x : 0.0f; g1 -= right ? tr.y : 0.0f; g2 -= right ? tr.z : 0.0f;
     const float2 cc = a.col_h[c], rr = a.row_h[r];
     float ds = g0 * cc.x * rr.x + g1 * cc.y * rr.x + g2 * rr.y;
     const float4 nsd = a.ns[pix];

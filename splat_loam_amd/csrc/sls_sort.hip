@@ -431,15 +431,18 @@ __global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, cons
 {
     __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
     const int base = blockIdx.x * kResortWindow;
+    // (unconditional loads at clamped addresses, all of a level before the next: two dependent round trips
+    //  instead of one branch + full wait per element)
+    uint32_t gq[kResortE], kq[kResortE];
+#pragma unroll
+    for (int q = 0; q < kResortE; ++q)
+        gq[q] = min(prev_order[min(base + q * kResortThreads + (int)threadIdx.x, N - 1)], (uint32_t)(N - 1));   // (memory-safe whatever the caller kept)
+#pragma unroll
+    for (int q = 0; q < kResortE; ++q) kq[q] = keys_by_surfel[gq[q]];
 #pragma unroll
     for (int q = 0; q < kResortE; ++q) {
         const int o = q * kResortThreads + threadIdx.x, pos = base + o;
-        uint64_t c = ~0ull;                        // padding behind the end sorts last
-        if (pos < N) {
-            const uint32_t g = min(prev_order[pos], (uint32_t)(N - 1));   // (memory-safe whatever the caller kept)
-            c = ((uint64_t)keys_by_surfel[g] << 32) | g;
-        }
-        s_a[o] = c;
+        s_a[o] = pos < N ? (((uint64_t)kq[q] << 32) | gq[q]) : ~0ull;      // padding behind the end sorts last
     }
     __syncthreads();
     bitonic_lds<2>(s_a);
@@ -500,19 +503,19 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         // the second half is loaded back to front: ascending + descending = bitonic
         const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
         const int pos = base + src;
-        s_a[o] = pos < 0 ? 0ull : (pos < N ? comp[pos] : ~0ull);
+        const uint64_t c = comp[min(max(pos, 0), N - 1)];
+        s_a[o] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
     }
     __syncthreads();
     bitonic_lds<kResortWindow>(s_a);
 #pragma unroll
     for (int q = 0; q < kResortE; ++q) {
         const int o = q * kResortThreads + threadIdx.x, pos = base + o;
-        uint32_t v = 0;
-        if (pos >= 0 && pos < N) {
-            const uint32_t g = (uint32_t)s_a[o];
-            order[pos] = g;
-            v = tiles[g];
-        }
+        const bool real = pos >= 0 && pos < N;
+        const uint32_t g = real ? (uint32_t)s_a[o] : 0u;
+        uint32_t v = tiles[g];                    // (surfel 0 for the padding: a valid address, masked below)
+        v = real ? v : 0u;
+        if (real) order[pos] = g;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if ((threadIdx.x & 63) == 0) s_part[o >> 8][(o >> 6) & 3] = v;
