@@ -62,7 +62,7 @@ size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st, bool sums_zeroed = false);
+                    hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr);
 extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
 extern int g_fwd_variant, g_bwd_variant, g_pad_lds_fwd, g_pad_lds_bwd;
 size_t knn_scratch_bytes(int M);

@@ -18,35 +18,9 @@
 // term) + the stencil's adjoint pieces dL/du, dL/dv; kernel C (per pixel):
 // gathers the four neighbours' pieces and writes dL/dallmap.  HBM-bound,
 // ~100 B/pixel.
-#include "sls_common.hpp"
+#include "sls_consumer_dev.hpp"
 
 namespace sls {
-
-struct ConsumerArgs {
-    int H, W;
-    float depth_ratio, lambda_n, lambda_a;
-    float inv_P, inv_nv;      // 1/(H*W), 1/n_valid (0 if n_valid == 0)
-    const float *allmap, *gt_depth;
-    const uint8_t *valid;
-    const float2 *col_h, *row_h;   // half-pixel ray tables
-    float4 *du, *dv, *ns;          // scratch: dL/du, dL/dv, (n_surf, dot)
-    float *sums;                   // [geom, normal, alpha, total]
-    float *partials;               // scratch: 3 floats per block of kernel B (no same-address atomics)
-    float *dL_dallmap;
-};
-
-__device__ __forceinline__ float3 surf_point(const ConsumerArgs &a, int r, int c, float &s_out)
-{
-    const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
-    const float al = a.allmap[SLS_CH_ALPHA * P + pix];
-    const float D = a.allmap[SLS_CH_DEPTH * P + pix];
-    const float med = a.allmap[SLS_CH_MEDIAN * P + pix];
-    const float Dh = (al > 0.0f) ? D / al : D;
-    const float s = Dh * (1.0f - a.depth_ratio) + med * a.depth_ratio;
-    const float2 cc = a.col_h[c], rr = a.row_h[r];
-    s_out = s;
-    return make_float3(s * cc.x * rr.x, s * cc.y * rr.x, s * rr.y);
-}
 
 __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a)
 {
@@ -142,47 +116,15 @@ __global__ __launch_bounds__(256) void consumer_c_kernel(ConsumerArgs a)
     }
     if (c >= a.W || r >= a.H) return;
     const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
-    const bool valid = a.valid[pix] == 1;
-    const float al = a.allmap[SLS_CH_ALPHA * P + pix];
-    const float D = a.allmap[SLS_CH_DEPTH * P + pix];
-    const float N0 = a.allmap[(SLS_CH_NORMAL + 0) * P + pix];
-    const float N1 = a.allmap[(SLS_CH_NORMAL + 1) * P + pix];
-    const float N2 = a.allmap[(SLS_CH_NORMAL + 2) * P + pix];
-    const bool hit = al > 0.0f;
-    const float inv = hit ? 1.0f / al : 1.0f;
-    float s;
-    (void)surf_point(a, r, c, s);
-    // gather the stencil adjoint: P(r,c) enters u(r-1,c) with +, u(r+1,c) with -, v(r,c-1) with +, v(r,c+1) with -
-    // (four unconditional loads at clamped addresses, masked afterwards: a load under a condition compiles into a
-    //  branch with a full wait each — four serialised round trips in a kernel that is nothing but latency)
-    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-    const bool up = r > 0, down = r < a.H - 1, left = c > 0, right = c < a.W - 1;
-    const float4 tu = a.du[up ? pix - a.W : pix], td = a.du[down ? pix + a.W : pix];
-    const float4 tl = a.dv[left ? pix - 1 : pix], tr = a.dv[right ? pix + 1 : pix];
-    g0 += up ? tu.x : 0.0f; g1 += up ? tu.y : 0.0f; g2 += up ? tu.z : 0.0f;
-    g0 -= down ? td.x : 0.0f; g1 -= down ? td.y : 0.0f; g2 -= down ? td.z : 0.0f;
-    g0 += left ? tl.x : 0.0f; g1 += left ? tl.y : 0.0f; g2 += left ? tl.z : 0.0f;
-    g0 -= right ? tr.x : 0.0f; g1 -= right ? tr.y : 0.0f; g2 -= right ? tr.z : 0.0f;
-    const float2 cc = a.col_h[c], rr = a.row_h[r];
-    float ds = g0 * cc.x * rr.x + g1 * cc.y * rr.x + g2 * rr.y;
-    const float4 nsd = a.ns[pix];
-    float da = 0.0f, dn0 = 0.0f, dn1 = 0.0f, dn2 = 0.0f;
-    if (valid) {
-        const float diff = s - a.gt_depth[pix];
-        ds += ((diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f)) * a.inv_P;
-        const float k = -a.lambda_n * a.inv_nv;
-        dn0 = k * al * nsd.x; dn1 = k * al * nsd.y; dn2 = k * al * nsd.z;
-        da = k * nsd.w + a.lambda_a * a.inv_nv * (al - 1.0f) / fmaxf((1.0f - al) * al, 1e-12f);   // torch BCE backward
-    }
-    const float dDh = (1.0f - a.depth_ratio) * ds;
-    if (hit) da -= (dDh * D + dn0 * N0 + dn1 * N1 + dn2 * N2) * inv * inv;
-    a.dL_dallmap[SLS_CH_DEPTH * P + pix] = dDh * inv;
-    a.dL_dallmap[SLS_CH_ALPHA * P + pix] = da;
-    a.dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix] = dn0 * inv;
-    a.dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix] = dn1 * inv;
-    a.dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix] = dn2 * inv;
-    a.dL_dallmap[SLS_CH_MEDIAN * P + pix] = a.depth_ratio * ds;
-    a.dL_dallmap[SLS_CH_DIST * P + pix] = 0.0f;
+    float g[7];
+    consumer_pixel_grad(a, r, c, g);
+    a.dL_dallmap[SLS_CH_DEPTH * P + pix] = g[0];
+    a.dL_dallmap[SLS_CH_ALPHA * P + pix] = g[1];
+    a.dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix] = g[2];
+    a.dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix] = g[3];
+    a.dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix] = g[4];
+    a.dL_dallmap[SLS_CH_MEDIAN * P + pix] = g[5];
+    a.dL_dallmap[SLS_CH_DIST * P + pix] = g[6];
 }
 
 size_t consumer_scratch_bytes(int H, int W)
@@ -194,7 +136,7 @@ size_t consumer_scratch_bytes(int H, int W)
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st, bool sums_zeroed)
+                    hipStream_t st, bool sums_zeroed, ConsumerArgs *args_out_skip_c)
 {
     if (scratch_bytes < consumer_scratch_bytes(H, W)) {
         set_error("consumer scratch too small");
@@ -218,6 +160,10 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
     const dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(consumer_b_kernel, grid, dim3(256), 0, st, a);
     SLS_LAUNCH_CHECK("consumer_b_kernel");
+    if (args_out_skip_c) {          // kernel C's work is done by the backward tile kernel (FUSED)
+        *args_out_skip_c = a;
+        return SLS_OK;
+    }
     hipLaunchKernelGGL(consumer_c_kernel, grid, dim3(256), 0, st, a);
     SLS_LAUNCH_CHECK("consumer_c_kernel");
     return SLS_OK;

@@ -5,7 +5,7 @@
 // no device->host sync and no torch op in between.
 #include <string.h>
 
-#include "sls_common.hpp"
+#include "sls_consumer_dev.hpp"
 
 namespace sls {
 
@@ -43,14 +43,14 @@ int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const 
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
-                      uint8_t *touched = nullptr);
+                      uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr);
 extern int g_bwd_variant;
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st, bool sums_zeroed = false);
+                    hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                 const uint32_t *skip_flag, hipStream_t stream, const float *void_flags = nullptr,
                 uint32_t *status_block = nullptr, uint32_t *status_mirror = nullptr);
@@ -270,14 +270,19 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                            nullptr, st, true, w.block_masks);   // (nobody reads the consumed counters here)
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
+    // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
+    // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
+    const bool fuse_c = g_bwd_variant == 3 && cfg->depth_ratio == 0.0f;
+    ConsumerArgs cargs;
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
                          cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
-                         w.consumer_scratch, w.consumer_scratch_bytes, st, true);   // sums zeroed with the status
+                         w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr);
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
     uint8_t *touched = g_bwd_variant >= 2 ? w.touched : nullptr;   // (the block kernels mark the surfels they reach)
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
-                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched);   // the consumer's dL/d(median, distortion) are 0 then
+                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
+                           fuse_c ? &cargs : nullptr);
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;

@@ -608,7 +608,8 @@ size_t block_mask_bytes(uint64_t cap, int T);
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
-                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched);
+                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
+                            const struct ConsumerArgs *fused_consumer);
 int g_fwd_variant = 3, g_bwd_variant = 3;
 // unused dynamic LDS requested at launch (caps the workgroups resident per CU)
 int g_pad_lds_fwd = 0, g_pad_lds_bwd = 0;
@@ -650,13 +651,15 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
 int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, const float *pix_state,
                       const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st,
-                      const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched)
+                      const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched,
+                      const struct ConsumerArgs *fused_consumer)
 {
     const int T = cam.GX * cam.GY;
     if (g_bwd_variant >= 2)
         return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                       grec, block_masks, g_bwd_variant - 2, st, no_median_dist_grad, touched);
-    SLS_REQUIRE(!touched, "only the block kernels mark the touched surfels");
+                                       grec, block_masks, g_bwd_variant - 2, st, no_median_dist_grad, touched,
+                                       fused_consumer);
+    SLS_REQUIRE(!touched && !fused_consumer, "only the block kernels mark the touched surfels / fuse the consumer");
     ScopedTimer tm(T_RENDER_BWD, st);
     if (g_bwd_variant == 1) {
         hipLaunchKernelGGL(render_bwd_wave_kernel, dim3(T * kSubPerTile), dim3(64), g_pad_lds_bwd, st, cam,

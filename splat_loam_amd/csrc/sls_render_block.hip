@@ -20,7 +20,9 @@
 //     and one 64-lane float atomic instruction flushes 4 surfels x 16 fields.
 // Survivors of the cull are compacted into a wave-private LDS list (ballot +
 // mbcnt), a step takes the next four.
+#include <cstring>
 #include "sls_tile.hpp"
+#include "sls_consumer_dev.hpp"
 
 namespace sls {
 
@@ -273,14 +275,19 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
 // ---------------------------------------------------------------------------
 // LEAN: the caller guarantees dL/d(median) = dL/d(distortion) = 0 (the mapper's loss at
 // depth_ratio = 0, gaussian_renderer/__init__.py:79-86): their terms are compiled out.
-template <int BW, int BH, bool LEAN>
+// FUSED (sls_mapping_step, LEAN only): dL/dallmap is not read but computed per pixel from the consumer's
+// kernel-B planes (sls_consumer_dev.hpp) — consumer kernel C is not launched; block 0 also turns kernel B's
+// per-block loss partials into the iteration's loss sums.
+template <int BW, int BH, bool LEAN, bool FUSED>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
-    uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles)
+    uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks)
 {
+    static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
+    if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     __shared__ float4 s_rec[64 * kRec4];
@@ -316,11 +323,17 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         last = pcn.x; medc = pcn.y;
         const float4 ps = pix_state[pix];
         Tf = ps.x; M1 = ps.y; M2 = ps.z;
-        dD = dL_dallmap[SLS_CH_DEPTH * P + pix];
-        dA = dL_dallmap[SLS_CH_ALPHA * P + pix];
-        dN0 = dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix];
-        dN1 = dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix];
-        dN2 = dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix];
+        if (FUSED) {
+            float gpix[7];
+            consumer_pixel_grad(ca, py, px, gpix);
+            dD = gpix[0]; dA = gpix[1]; dN0 = gpix[2]; dN1 = gpix[3]; dN2 = gpix[4];
+        } else {
+            dD = dL_dallmap[SLS_CH_DEPTH * P + pix];
+            dA = dL_dallmap[SLS_CH_ALPHA * P + pix];
+            dN0 = dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix];
+            dN1 = dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix];
+            dN2 = dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix];
+        }
         if (!LEAN) {
             dMed = dL_dallmap[SLS_CH_MEDIAN * P + pix];
             dDist = dL_dallmap[SLS_CH_DIST * P + pix];
@@ -461,18 +474,29 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
-                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched)
+                            const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
+                            const ConsumerArgs *fused_consumer)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
-#define SLS_BWD_BLOCK(BW_, BH_, LEAN_)                                                                              \
-    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_>), grid, block, 0, st, cam, (const uint2 *)ranges,   \
+    ConsumerArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    int cblocks = 0;
+    if (fused_consumer) {
+        ca = *fused_consumer;
+        cblocks = ((ca.W + 63) / 64) * ((ca.H + 3) / 4);
+    }
+#define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_)                                                                       \
+    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles)
-    if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true); else SLS_BWD_BLOCK(4, 4, true); }
-    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false); else SLS_BWD_BLOCK(4, 4, false); }
+                       touched, g_dbg_bwd_cycles, ca, cblocks)
+    if (fused_consumer) {
+        SLS_REQUIRE(lean && shape == 1, "the fused consumer gradient exists for the lean 8x2 kernel only");
+        SLS_BWD_BLOCK(8, 2, true, true);
+    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, false); else SLS_BWD_BLOCK(4, 4, true, false); }
+    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, false); else SLS_BWD_BLOCK(4, 4, false, false); }
 #undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");
     return SLS_OK;
