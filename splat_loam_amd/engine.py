@@ -72,9 +72,10 @@ class MappingEngine:
         self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
         # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
         # id(camera) -> [order tensor, iteration it was last written]; an order older than max_order_age
-        # iterations is not worth repairing (the surfels moved too far) and is rebuilt from scratch
+        # iterations gets an extra repair round, one older than max_order_age_extra is rebuilt from scratch
         self._orders = {}
         self.max_order_age = 4
+        self.max_order_age_extra = 12     # up to this age an order is still repaired, with one more round
         self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
@@ -145,14 +146,15 @@ class MappingEngine:
                 self._orders.pop(next(iter(self._orders)))
             ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None]
             self._orders[id(camera)] = ent
-        reuse = (allow_reuse and self.reuse_depth_order and ent[1] is not None
-                 and self._enq - ent[1] <= self.max_order_age)
+        age = self._enq - ent[1] if ent[1] is not None else None
+        reuse = allow_reuse and self.reuse_depth_order and age is not None and age <= self.max_order_age_extra
         # after a failed repair the following iterations repair with one more round (one more window of reach,
         # +16 us); every `repair_span` iterations without a failure the number of rounds steps down again
         if self._repair_rounds > 1 and self._enq >= self._repair_until:
             self._repair_rounds -= 1
             self._repair_until = self._enq + self.repair_span
-        reuse = self._repair_rounds if reuse else 0
+        # an order older than max_order_age iterations gets one more round (the surfels have drifted further)
+        reuse = min(self._repair_rounds + (1 if age is not None and age > self.max_order_age else 0), 3) if reuse else 0
         self._enq += 1
         ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
