@@ -28,6 +28,23 @@ from .fused import camera_aux
 from .rasterizer import GaussianRasterizationSettings, get_camera
 
 
+def carry_bucket(buf: torch.Tensor, keep: torch.Tensor, n_new: int) -> torch.Tensor:
+    """A flat 10*N_old bucket [xyz 3N | opacity N | scaling 2N | rotation 4N] -> the 10*n_new bucket of the surfel
+    set that keeps the rows marked in `keep` (in order) and appends n_new - keep.sum() zero rows per group."""
+    n_old = int(keep.numel())
+    n_keep = int(keep.sum().item())
+    if buf.numel() != 10 * n_old or n_new < n_keep:
+        raise ValueError("bucket / mask / new size do not fit together")
+    out = torch.zeros((10 * n_new,), dtype=buf.dtype, device=buf.device)
+    src_off = dst_off = 0
+    for width in (3, 1, 2, 4):
+        src = buf[src_off:src_off + width * n_old].view(n_old, width)
+        out[dst_off:dst_off + width * n_keep].view(n_keep, width).copy_(src[keep])
+        src_off += width * n_old
+        dst_off += width * n_new
+    return out
+
+
 class MappingEngine:
     def __init__(self, model, cfg, lrs=(5e-4, 5e-2, 5e-3, 1e-3), betas=(0.9, 0.999), eps=1e-15,
                  capacity_factor: float = 1.3):
@@ -350,17 +367,8 @@ class MappingEngine:
         if int(self.model._xyz.shape[0]) != n_new:
             raise RuntimeError(f"the model holds {int(self.model._xyz.shape[0])} surfels, keep/appended describe {n_new}")
 
-        def carry(buf):
-            out = torch.zeros((10 * n_new,), dtype=torch.float32, device=self.dev)
-            src_off = dst_off = 0
-            for width in (3, 1, 2, 4):              # bucket layout [xyz 3N | opacity N | scaling 2N | rotation 4N]
-                src = buf[src_off:src_off + width * n_old].view(n_old, width)
-                out[dst_off:dst_off + width * n_keep].view(n_keep, width).copy_(src[keep])
-                src_off += width * n_old
-                dst_off += width * n_new
-            return out
-
-        self.exp_avg, self.exp_avg_sq = carry(self.exp_avg), carry(self.exp_avg_sq)
+        self.exp_avg = carry_bucket(self.exp_avg, keep, n_new)
+        self.exp_avg_sq = carry_bucket(self.exp_avg_sq, keep, n_new)
         self.N = n_new
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)
         self.workspace = None                        # sized by N: rebuilt at the next step

@@ -90,3 +90,24 @@ def test_product_never_touches_the_checker():
         if re.search(r"oracle", open(os.path.join(ROOT, shim)).read()):
             bad.append(shim)
     assert not bad, bad
+
+
+def test_engine_bucket_surgery_on_cpu():
+    """Host logic of MappingEngine.remap (prune / densify between keyframes): the flat optimiser buckets keep the
+    survivors' rows group by group and append zero rows."""
+    import torch
+    from splat_loam_amd.engine import carry_bucket
+    n_old, n_new = 7, 8
+    groups = [torch.arange(n_old * w, dtype=torch.float32).view(n_old, w) + 100.0 * k for k, w in enumerate((3, 1, 2, 4))]
+    buf = torch.cat([g.reshape(-1) for g in groups])
+    keep = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
+    out = carry_bucket(buf, keep, n_new)
+    assert out.numel() == 10 * n_new
+    off = 0
+    for g, w in zip(groups, (3, 1, 2, 4)):
+        got = out[off:off + w * n_new].view(n_new, w)
+        assert torch.equal(got[:4], g[keep]) and float(got[4:].abs().max()) == 0.0
+        off += w * n_new
+    import pytest
+    with pytest.raises(ValueError):
+        carry_bucket(buf, keep, 3)
