@@ -130,6 +130,20 @@ def main():
                     help="tuning: unused dynamic LDS bytes for the tile kernels (caps workgroups per CU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL over xGMI)
+        import socket
+        import subprocess
+        backend = os.environ.get("SLS_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible (SLS_BENCH_BACKEND=gloo "
+                             "runs several ranks on one device for a functional check)")
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -147,7 +161,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(python bench.py --gpus N does it by itself)")
 
     from splat_loam_amd import _abi, synth
     from splat_loam_amd.mapping import MappingConfig, optimize_step_fused, optimize_step_sharded

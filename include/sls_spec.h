@@ -26,9 +26,10 @@
  *   q0: Hu.xyz , npv      Hu =  sigma (Tv x p)/su   (u = Hu.(d-dc)/nd)
  *   q1: Hv.xyz , rho_c    Hv = -sigma (Tu x p)/sv   (v = Hv.(d-dc)/nd)
  *   q2: n.xyz  , opacity  n = sigma*Tn faces the sensor, npv = n.p <= 0
- *   q3: dc.xyz , 0        dc = p/|p|
+ *   q3: dc.xyz , kc       dc = p/|p|; kc >= sqrt(2 ln(255 o)): no pixel further than kc
+ *                         sigma from the centre (on the surfel plane) reaches alpha >= 1/255
  *   q4: cpx, cpy, ex, ey  centre pixel; conservative support half-extent
- *                         (ex, ey are a kernel-side culling aid only; they
+ *                         (kc, ex, ey are a kernel-side culling aid only; they
  *                          never change a result and are not checked).
  */
 #define SLS_REC_STRIDE 20
@@ -39,6 +40,7 @@
 #define SLS_REC_N 8
 #define SLS_REC_OPAC 11
 #define SLS_REC_DC 12
+#define SLS_REC_KC 15
 #define SLS_REC_CPX 16
 #define SLS_REC_CPY 17
 #define SLS_REC_EX 18

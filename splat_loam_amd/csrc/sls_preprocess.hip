@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 // rho <= rho_max = 2 ln(255 o); in the 3D branch the hit lies inside
                 // the ball of radius sqrt(rho_max)*smax around p, in the 2D branch
                 // within sqrt(rho_max/2) px of the centre.  Never changes a result.
-                float ex = -1.0e30f, ey = -1.0e30f;
+                float ex = -1.0e30f, ey = -1.0e30f, kc = 0.0f;
                 const float lo = 255.0f * o;
                 if (lo > 1.0f) {
                     // (hardware-approximate rcp / sqrt / log here: these extents only have to be
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                     const float rho_max = 2.0f * __logf(lo) * 1.001f + 1.0e-3f;
                     float th2, daz2;
                     const float kk = __builtin_amdgcn_sqrtf(rho_max), rad = kk * smax;
+                    kc = kk * 1.0001f;
                     ball_extent(rad, g.rho, g.rxy, th2, daz2);
                     const float r2 = __builtin_amdgcn_sqrtf(0.5f * rho_max);
                     // Tighter bound for the 3D branch: the hit point is p + u su Tu + v sv Tv with
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 q0 = make_float4(g.Hu[0], g.Hu[1], g.Hu[2], g.sig * g.c);
                 q1 = make_float4(g.Hv[0], g.Hv[1], g.Hv[2], g.rho);
                 q2 = make_float4(g.n[0], g.n[1], g.n[2], o);
-                q3 = make_float4(g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho, 0.0f);
+                q3 = make_float4(g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho, kc);
                 q4 = make_float4(cpx, cpy, ex, ey);
             }
         }

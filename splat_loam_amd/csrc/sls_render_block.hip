@@ -145,6 +145,9 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
     bool wave_done = __all(done);
     uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0, st_slots = 0, st_geom = 0;   // diagnostics only
 
+    // footprint test against the whole block (sls_tile.hpp): rays of the block = d0 + x Dx + y Dy
+    const BlockCone cone = make_block_cone(cam, (float)x0 + 0.5f * (float)(BW - 1), (float)y0 + 0.5f * (float)(BH - 1),
+                                           0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
     const int nr = (n + 63) / 64;
     SLS_STAGE_DECL
     if (nr > 0 && !wave_done) {
@@ -166,7 +169,15 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
         const int cnt = min(64, n - r * 64);
         __builtin_amdgcn_wave_barrier();
         bool pass = false;
-        if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+        if (lane < cnt) {
+            const float4 c4 = s_rec[lane * kRec4 + 4];
+            pass = cull_pass(c4, bcx, bcy, bhx, bhy, wrapW, invW);
+            if (pass) {
+                const float4 c3 = s_rec[lane * kRec4 + 3];
+                pass = !cone_outside(cone, s_rec[lane * kRec4 + 0], s_rec[lane * kRec4 + 1], s_rec[lane * kRec4 + 2], c3) ||
+                       disc_reaches(c3, c4, bcx, bcy, bhx, bhy, wrapW, invW);
+            }
+        }
         const uint64_t mask = __ballot(pass);
         const int npass = __builtin_popcountll(mask);
         if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;

@@ -50,6 +50,70 @@ __device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy,
     return (fabsf(dxc) <= q4.z + bhx) && (fabsf(bcy - q4.y) <= q4.w + bhy);
 }
 
+// ---------------------------------------------------------------------------
+// Footprint test of a surfel against a whole pixel block (forward cull).
+//
+// A pixel ray d can only receive alpha >= 1/255 from the surfel's 3D branch if
+//     G(d) = |(Hu.d, Hv.d)| + kc (n.d) <= 0          (rho3 <= kc^2 and n.d < 0; Hu.dc = Hv.dc = 0)
+// and G is CONVEX in d (a norm of linear forms plus a linear form).  So for any d0
+//     G(d) >= G(d0) + grad G(d0) . (d - d0),
+// and with the block's rays written as d = d0 + x Dx + y Dy + r, |x|,|y| <= 1, |r| <= eps (Taylor
+// remainder of the unit sphere's parametrisation), the right-hand side is bounded below over the
+// whole block by  G(d0) - |gradG.Dx| - |gradG.Dy| - eps |gradG|_1.  If that is positive no pixel of
+// the block lies in the 3D footprint: a separating-line test whose axis is the footprint's own
+// boundary normal at the block centre — nearly exact for footprints larger than the block, which
+// are the near surfels that dominate the consumed part of every list (tools/sim_lane_use.py:
+// 31 % fewer evaluated (block, surfel) pairs than the support box alone, 2.5 % above the exact
+// count, nothing missed).  The 2D (low-pass) branch reaches sqrt(kc^2/2) pixels from the centre:
+// tested as the distance from the centre to the block's pixel box.
+// Everything is multiplied through by |(a,b)| so that no division is needed.
+struct BlockCone {
+    float d0[3], Dx[3], Dy[3], eps;
+};
+__device__ __forceinline__ BlockCone make_block_cone(const DevCam &cam, float pcx, float pcy, float hx, float hy)
+{
+    BlockCone c;
+    float sa, ca, se, ce;
+    sincosf((pcx - cam.cx) / cam.fx, &sa, &ca);
+    sincosf((pcy - cam.cy) / cam.fy, &se, &ce);
+    c.d0[0] = ca * ce; c.d0[1] = sa * ce; c.d0[2] = se;
+    const float kx = hx / cam.fx, ky = hy / cam.fy;
+    c.Dx[0] = -kx * sa * ce; c.Dx[1] = kx * ca * ce; c.Dx[2] = 0.0f;
+    c.Dy[0] = -ky * ca * se; c.Dy[1] = -ky * sa * se; c.Dy[2] = ky * ce;
+    const float span = fabsf(kx) + fabsf(ky);
+    c.eps = 0.5f * span * span * 1.01f + 4.0e-6f;     // second-order remainder + float32 slop of d0 / Dx / Dy
+    return c;
+}
+// true: the 3D footprint cannot reach any pixel of the block.
+__device__ __forceinline__ bool cone_outside(const BlockCone &c, const float4 q0, const float4 q1, const float4 q2,
+                                             const float4 q3)
+{
+    const float l0 = c.d0[0] - q3.x, l1 = c.d0[1] - q3.y, l2 = c.d0[2] - q3.z;   // d0 - dc: exact cancellation
+    const float a = q0.x * l0 + q0.y * l1 + q0.z * l2;
+    const float b = q1.x * l0 + q1.y * l1 + q1.z * l2;
+    const float e = q2.x * c.d0[0] + q2.y * c.d0[1] + q2.z * c.d0[2];
+    const float n2 = a * a + b * b, nrm = __builtin_amdgcn_sqrtf(n2), kn = q3.w * nrm;
+    const float g0 = a * q0.x + b * q1.x + kn * q2.x;      // |(a,b)| * grad G
+    const float g1 = a * q0.y + b * q1.y + kn * q2.y;
+    const float g2 = a * q0.z + b * q1.z + kn * q2.z;
+    const float tx = g0 * c.Dx[0] + g1 * c.Dx[1];
+    const float ty = g0 * c.Dy[0] + g1 * c.Dy[1] + g2 * c.Dy[2];
+    const float reach = fabsf(tx) + fabsf(ty) + c.eps * (fabsf(g0) + fabsf(g1) + fabsf(g2));
+    // 2e-4 relative slack on both terms of G: rounding of a, b, e, the approximate sqrt, and the
+    // tile kernels' own approximate rcp / exp when they decide alpha >= 1/255 at the boundary
+    return n2 + kn * e - reach > 2.0e-4f * (n2 + kn * fabsf(e));
+}
+// true: the low-pass disc (radius kc / sqrt 2 pixels around the centre) reaches the pixel box.
+__device__ __forceinline__ bool disc_reaches(const float4 q3, const float4 q4, float bcx, float bcy, float bhx,
+                                             float bhy, float wrapW, float invW)
+{
+    const float dx0 = bcx - q4.x;
+    const float dxc = dx0 - wrapW * __builtin_rintf(dx0 * invW);
+    const float ex = fmaxf(fabsf(dxc) - bhx, 0.0f), ey = fmaxf(fabsf(bcy - q4.y) - bhy, 0.0f);
+    const float r = q3.w * 0.70781f + 0.05f;               // kc / sqrt 2, +0.1 % and 0.05 px as in (ex, ey)
+    return ex * ex + ey * ey <= r * r;
+}
+
 // Box of the active lanes of an 8x8 sub-tile at (x0, y0); false if none.
 __device__ __forceinline__ bool active_box(uint64_t m, int x0, int y0, float &bcx, float &bcy, float &bhx,
                                            float &bhy)

@@ -44,9 +44,10 @@ def _compare_forward(oracle32, st, ost, cam, name):
     # ---- surfel records ---------------------------------------------------------
     rec = st.rec.cpu().numpy()
     ref = pre["rec"]
-    exact = np.array_equal(rec[:, :18].view(np.uint32), ref[:, :18].view(np.uint32))
+    spec = [k for k in range(18) if k != 15]      # (15, 18, 19: kc, ex, ey — culling aids, not part of the contract)
+    exact = np.array_equal(rec[:, spec].view(np.uint32), ref[:, spec].view(np.uint32))
     if not exact:
-        e = rel_err(rec[:, :18], ref[:, :18], scale=np.abs(ref[:, :18]).max(axis=0, keepdims=True))
+        e = rel_err(rec[:, spec], ref[:, spec], scale=np.abs(ref[:, spec]).max(axis=0, keepdims=True))
         assert e.max() <= 1e-6, f"{name}: record mismatch {e.max()}"
     # ---- allmap ---------------------------------------------------------------------
     am = st.allmap.cpu().numpy()

@@ -1,0 +1,217 @@
+"""The path bench.py TIMES — `sls_mapping_step`: raw-parameter preprocess (exp / sigmoid / normalize in the
+kernel), tile forward, consumer kernel B, `render_bwd_block_kernel<8,2,LEAN,FUSED>` (dL/dallmap recomputed per
+pixel), raw-parameter preprocess backward with the fused Adam — checked against the CPU checker, not against
+torch autograd wrapped around the same HIP rasterizer.
+
+Reference chain (all on the CPU): torch activations (scene/gaussian_model.py:55-69) -> oracle/sls_oracle.c
+forward -> oracle/consumer_ref.py (float64 restatement of gaussian_renderer/__init__.py:51-82,
+utils/graphic_utils.py:26-88, slam/mapper.py:158-199) -> checker backward -> torch autograd through the
+activations and the scale regulariser.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import RTOL, scene_and_camera, tangent
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def reference_iteration(raw, K, view, proj, H, W, gt_depth, valid, cfg, allmap_value=None):
+    """Loss and raw-parameter gradients of one mapping iteration through the checker.  `allmap_value`: evaluate the
+    consumer at THIS allmap (e.g. the engine's) while the gradient still flows into the checker's backward."""
+    from oracle.consumer_ref import pixel_loss64
+    from oracle.torch_function import GaussianRasterizationSettings, GaussianRasterizer
+    leaves = {k: torch.tensor(np.asarray(v, np.float32)).requires_grad_(True) for k, v in raw.items()}
+    scales = torch.exp(leaves["scaling"])
+    rots = torch.nn.functional.normalize(leaves["rotation"])
+    opac = torch.sigmoid(leaves["opacity"])
+    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view), torch.tensor(proj))
+    radii, allmap = GaussianRasterizer(raster_settings=settings)(
+        means3D=leaves["xyz"], means2D=torch.zeros_like(leaves["xyz"]), opacities=opac, scales=scales, rotations=rots)
+    am = allmap
+    if allmap_value is not None:
+        am = allmap + (torch.as_tensor(allmap_value) - allmap).detach()
+    total, geom, normal, bce = pixel_loss64(am.double(), K, gt_depth, valid, cfg.depth_ratio,
+                                            cfg.opt_lambda_normal, cfg.opt_lambda_alpha)
+    smax = scales.max(dim=1).values
+    reg = (cfg.opt_scaling_max_penalty * (smax[smax >= cfg.opt_scaling_max] - cfg.opt_scaling_max)).sum()
+    loss = total + reg.double()
+    loss.backward()
+    return {"loss": float(loss), "pixel": float(total), "reg": float(reg), "allmap": allmap.detach().numpy(),
+            "radii": radii.numpy(), "grads": {k: v.grad.numpy() for k, v in leaves.items()}}
+
+
+def _engine_once(device, raw, K, pose, gt_depth, valid, cfg):
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.scene import Camera, SurfelModel
+    cam = Camera(K, gt_depth, None, valid, pose, data_device=str(device))
+    model = SurfelModel(raw["xyz"], raw["scaling"], raw["rotation"], raw["opacity"], device=str(device))
+    eng = MappingEngine(model, cfg)
+    eng.keep_grads = True
+    st = eng.step(cam)
+    H, W = cam.image_height, cam.image_width
+    g = {k: v.detach().cpu().numpy().copy() for k, v in eng.grad_views().items()}
+    return st, g, eng.allmap(H, W).cpu().numpy(), eng, model, cam
+
+
+def _raw_scene(N, H, W, seed, **kw):
+    from splat_loam_amd import synth
+    sc = synth.make_scene(N, H, W, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 1000)
+    raw = {"xyz": sc["means"], "scaling": np.log(sc["scales"]),
+           # un-normalised quaternions: the engine normalises in the kernel, and so does the model's getter
+           "rotation": sc["rots"] * rng.uniform(0.5, 2.0, (N, 1)).astype(np.float32),
+           "opacity": np.log(sc["opac"] / (1 - sc["opac"])).reshape(N, 1)}
+    raw = {k: np.ascontiguousarray(v, np.float32) for k, v in raw.items()}
+    depth, valid = synth.make_targets(H, W, sc)
+    return sc, raw, depth, valid
+
+
+@pytest.mark.parametrize("name,N,H,W,kw", [
+    ("small", 6000, 32, 256, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25)),
+    ("c2_50k_64x1024", 50000, 64, 1024, {}),
+], ids=["small", "c2"])
+def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw):
+    """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
+    chain.  Two comparisons:
+      * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
+        same image and the bar is the north-star 1e-5 (max-norm per tensor);
+      * `own-allmap`: each side differentiates its own image.  The two images agree to <=1e-5, but the normal term
+        amplifies an image perturbation by ~1/(2 pixel pitch) (oracle/consumer_ref.py), so this comparison is
+        bounded by the conditioning of the LOSS, not by the kernels; its bar is stated below and printed."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.mapping import MappingConfig
+    sc, raw, depth, valid = _raw_scene(N, H, W, seed=23, **kw)
+    valid = valid.copy(); valid[0, :2, :9] = 0
+    pose = synth.keyframe_poses(2)[1]
+    view, proj = synth.camera_matrices(sc["K"], pose)
+    cfg = MappingConfig()
+    st, g, am, eng, model, cam = _engine_once(device, raw, sc["K"], pose, depth, valid, cfg)
+    own = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg)
+    same = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am)
+    # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image
+    for c in range(5):
+        scale = max(np.abs(own["allmap"][c]).max(), 1e-12)
+        e = np.abs(am[c].astype(np.float64) - own["allmap"][c]) / scale
+        frac_bad = float((e > RTOL).mean())
+        assert frac_bad <= 0.02, f"{name}: allmap ch{c}: {frac_bad:.4f} of the pixels off by more than {RTOL}"
+    assert abs(st["loss"] - same["loss"]) <= 2e-5 * abs(same["loss"]), (st, same["loss"])
+    assert abs(st["loss_reg"] - same["reg"]) <= 1e-5 * max(abs(same["reg"]), 1e-6)
+    rot = raw["rotation"].astype(np.float64)
+    report = {}
+    for tag, ref, bar in (("same-allmap", same, RTOL), ("own-allmap", own, 2e-3)):
+        for k in ("xyz", "opacity", "scaling", "rotation"):
+            a, b = g[k].astype(np.float64), ref["grads"][k].astype(np.float64)
+            if k == "rotation":
+                a, b = tangent(a, rot), tangent(b, rot)
+            scale = np.abs(b).max()
+            e = np.abs(a - b).max() / scale
+            big = np.abs(b) > 1e-3 * scale
+            er = (np.abs(a - b)[big] / np.abs(b)[big]).max()
+            report[(tag, k)] = (e, er)
+    print(f"\n[{name}] engine vs checker chain (max-norm rel, worst element-wise rel above 1e-3 of max): "
+          + "; ".join(f"{t}/{k}: {e:.1e}, {er:.1e}" for (t, k), (e, er) in report.items()))
+    for (tag, k), (e, er) in report.items():
+        bar = RTOL if tag == "same-allmap" else 2e-3
+        assert e <= bar, f"{name}: {tag} d{k} max-norm rel err {e:.3e} > {bar}"
+        if tag == "same-allmap":
+            assert er <= 2e-3, f"{name}: {tag} d{k} element-wise rel err {er:.3e}"
+    # the fused Adam consumed exactly these gradients: first step = -lr * sign(g) wherever |g| is not ~0
+    lrs = {"xyz": 5e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
+    for k, p in (("xyz", model._xyz), ("opacity", model._opacity), ("scaling", model._scaling), ("rotation", model._rotation)):
+        gg = g[k]
+        sure = np.abs(gg) > 1e-6 * np.abs(gg).max()
+        step = p.detach().cpu().numpy() - raw[k]
+        assert np.allclose(step[sure], (-lrs[k] * np.sign(gg))[sure], rtol=1e-3, atol=1e-9), k
+
+
+def test_g5_reference_trajectory_through_engine(device):
+    """VERDICT r1 item 1(b).  tests/golden/g5_mapper.npz holds 3 iterations of the REFERENCE's Mapper.optimize
+    (its loss code, its GaussianModel.training_setup Adam; tools/make_golden.py).  Replayed here through
+    MappingEngine on the GPU: same bound as the CPU replay (tests/test_golden.py)."""
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    g = np.load(os.path.join(GOLD, "g5_mapper.npz"))
+    cam = Camera(g["K"], g["depth"], None, g["valid"], g["pose"], data_device=str(device))
+    model = SurfelModel(g["init_xyz"], g["init_scaling"], g["init_rotation"], g["init_opacity"], device=str(device))
+    cfg = MappingConfig(opt_lambda_alpha=0.4, opt_lambda_normal=0.5, opt_scaling_max=0.1, opt_scaling_max_penalty=1.0)
+    eng = MappingEngine(model, cfg, lrs=tuple(float(x) for x in g["lr"]))
+    for mode in (True, "lagged", "lagged"):
+        eng.step(cam, sync=mode)
+    eng.flush()
+    assert eng.t == 3
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        got = getattr(model, name).detach().cpu().numpy()
+        ref, init = g["final" + name], g["init" + name]
+        moved = np.abs(ref - init).max()
+        assert moved > 0
+        assert np.abs(got - ref).max() <= 2e-3 * moved + 1e-7, (name, np.abs(got - ref).max(), moved)
+
+
+def test_c3_full_parity(device, oracle32):
+    """VERDICT r1 item 1(c).  BASELINE config 3 — the bench scene itself (500k surfels, 64x2048, seed 0): integers
+    bit-exact, allmap and gradients <= 1e-5 against the checker, forward and backward."""
+    from splat_loam_amd import _abi
+    from helpers import hip_forward
+    from test_gpu_parity import _compare_backward, _compare_forward
+    N, H, W = 500000, 64, 2048
+    sc, view, proj = scene_and_camera(N, H, W, seed=0)
+    st, t = hip_forward(device, sc, view, proj, H, W)
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    oracle32.set_threads(oracle32.max_threads())
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    wf, nfrag = _compare_forward(oracle32, st, ost, cam, "c3")
+    wb = _compare_backward(oracle32, st, t, ost, sc, "c3")
+    print(f"\n[c3] R={st.R} fragile={nfrag} fwd worst={ {k: f'{v:.1e}' for k, v in wf.items()} } "
+          f"bwd worst={ {k: f'{v:.1e}' for k, v in wb.items()} }")
+
+
+def test_reference_style_render_under_autograd(device):
+    """VERDICT r1 weak #8.  The reference's render() divides views of `allmap` in place under autograd
+    (gaussian_renderer/__init__.py:55-62,69-71: the normal image is rotated into a new tensor and divided where
+    alpha > 0; `allmap[0:1]` is divided IN PLACE, i.e. the rasterizer's own output is overwritten before
+    backward).  The same sequence on `_RasterizeGaussians` must give the gradients of the out-of-place
+    `postprocess` path, and the rasterizer's backward must not depend on the overwritten buffer."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.mapping import MappingConfig, mapping_loss
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splat_loam_amd.renderer import depth_to_normal, postprocess
+    from splat_loam_amd.scene import Camera, SurfelModel
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=19, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+    cfg = MappingConfig()
+    grads = []
+    for style in ("inplace", "functional"):
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
+        settings = GaussianRasterizationSettings(H, W, 1.0, cam.world_view_transform, cam.projection_matrix, False, False)
+        means3D = model.get_xyz
+        radii, allmap = GaussianRasterizer(raster_settings=settings)(
+            means3D=means3D, means2D=torch.zeros_like(means3D), opacities=model.get_opacity,
+            scales=model.get_scaling, rotations=model.get_rotation, cov3D_precomp=None)
+        if style == "inplace":
+            alpha = allmap[1:2]
+            mask = (alpha > 0.0).squeeze(0)
+            nrm = (allmap[2:5].permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T).permute(2, 0, 1)
+            nrm[..., mask] = nrm[..., mask] / alpha[..., mask]
+            dexp = allmap[0:1]                                     # a VIEW of the rasterizer's output ...
+            dexp[..., mask] = dexp[..., mask] / alpha[..., mask]   # ... overwritten in place
+            surf_depth = dexp * (1 - cfg.depth_ratio) + allmap[5:6] * cfg.depth_ratio
+            surf_normal = depth_to_normal(cam, surf_depth)
+            surf_normal *= alpha
+            pkg = {"rend_alpha": alpha, "rend_normal": nrm, "surf_depth": surf_depth, "surf_normal": surf_normal}
+        else:
+            pkg = postprocess(cam, allmap, cfg.depth_ratio)
+        loss = mapping_loss(pkg, cam, model, cfg)
+        loss.backward()
+        grads.append({k: getattr(model, k).grad.detach().cpu().numpy() for k in ("_xyz", "_scaling", "_rotation", "_opacity")})
+    for k in grads[0]:
+        scale = np.abs(grads[1][k]).max()
+        # (float atomics order the sums differently from run to run; the two torch graphs round differently)
+        assert np.abs(grads[0][k] - grads[1][k]).max() <= 1e-4 * scale, k
