@@ -199,6 +199,13 @@ typedef struct SlsMappingConfig {
                               * gradient bucket): [0] = 1.0 if bit 0 of status.overflow is set, [1] = 1.0 if any
                               * other bit is, else 0.0 — summed over ranks by the gradient all-reduce and then
                               * handed to sls_adam_step_reduced */
+    uint32_t grad_chunk;     /* 0: `grads` is the flat bucket [xyz 3N | opacity N | scaling 2N | rotation 4N].
+                              * C > 0 (a multiple of 4, N even, apply_adam = 0): reduce-scatter layout for
+                              * `grad_ranks` ranks — flat element e lives at e + 4 * (e / C), i.e. rank g's chunk of C
+                              * elements is followed by 4 words whose first two receive the void flags (as
+                              * void_flags_out, which is ignored then): after a SUM reduce-scatter every rank finds the
+                              * group's verdict behind its own chunk.  `grads` holds grad_ranks * (C + 4) floats. */
+    uint32_t grad_ranks;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
@@ -336,15 +343,11 @@ int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
  * load balance across tiles.  Pass nulls to switch it off (the default). */
 int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles);
 
-/* Tuning/diagnostic: choose the tile-kernel variant (0 = one workgroup per tile with
- * shared LDS staging, 1 = one independent wave per 8x8 sub-tile, 2 / 3 = one wave per
- * 4x4 / 8x2 pixel block x 4 surfel slots [3 is the default]; negative = keep).
- * All produce the same results; tests run them all. */
+/* Tuning/diagnostic: choose the tile kernels' pixel-block shape: 2 = 4x4, 3 = 8x2 (the default);
+ * negative = keep.  Both produce the same results; the tests run both.  Like sls_timing_* and
+ * sls_debug_wave_cycles this acts on the CALLING THREAD only (thread-local state: the library keeps
+ * no process-global mutable state). */
 int sls_debug_variant(int fwd_variant, int bwd_variant);
-
-/* Tuning: bytes of unused dynamic LDS requested by the tile kernels; caps the
- * workgroups resident per CU so that later workgroups are dispatched dynamically. */
-int sls_debug_pad_lds(int fwd_bytes, int bwd_bytes);
 
 /* Device self-test of the wave64 primitives (DPP reduction, ballot ranking).
  * Returns 0 if they behave as the kernels assume.  Synchronises. */

@@ -35,6 +35,7 @@ class SlsMappingConfig(C.Structure):
         ("depth_order", C.c_void_p),
         ("status_mirror", C.c_void_p),
         ("void_flags_out", C.c_void_p),
+        ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
     ]
 
 
@@ -110,7 +111,6 @@ _PROTOS = {
     "sls_timing_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sls_debug_wave_cycles": (C.c_int, [_VP, _VP]),
     "sls_debug_variant": (C.c_int, [C.c_int, C.c_int]),
-    "sls_debug_pad_lds": (C.c_int, [C.c_int, C.c_int]),
     "sls_selftest": (C.c_int, [_VP]),
 }
 

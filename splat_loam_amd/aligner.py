@@ -19,33 +19,33 @@ Device only: there is no CPU path in the product.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
+import warnings
 
 import torch
 
 from . import _abi
 
 
+@dataclasses.dataclass
 class GSAlignerParams:
-    """Plain attribute bag, as the reference uses it (`GSAligner(**params.__dict__)`)."""
-
-    def __init__(self, **kw):
-        self.image_height = 64
-        self.image_width = 1024
-        self.num_iterations = 15
-        self.min_inliers = 64
-        self.max_distance = 1.0              # association gate (m)
-        self.max_angle_deg = 80.0            # reference normal vs viewing ray
-        self.huber_delta = 0.10              # point-to-plane residual (m)
-        self.range_weight = 0.25             # range-image term (0 switches it off)
-        self.range_huber = 0.30
-        self.depth_min = 0.5
-        self.depth_max = 100.0
-        self.damping = 1e-6
-        for k, v in kw.items():
-            if not hasattr(self, k):
-                raise TypeError(f"unknown GSAlignerParams field {k!r}")
-            setattr(self, k, v)
+    """Parameter bag as the reference uses it: default-constructed, fields assigned, then
+    `GSAligner(**params.__dict__)` (slam/tracker.py:146-160); a dataclass, because the reference also
+    names it as a field type of its OmegaConf structured config (utils/config_utils.py:95:
+    `gsaligner: Optional[GSAlignerParams]`), which accepts dataclass / attrs types only."""
+    image_height: int = 64
+    image_width: int = 1024
+    num_iterations: int = 15
+    min_inliers: int = 64
+    max_distance: float = 1.0              # association gate (m)
+    max_angle_deg: float = 80.0            # reference normal vs viewing ray
+    huber_delta: float = 0.10              # point-to-plane residual (m)
+    range_weight: float = 0.25             # range-image term (0 switches it off)
+    range_huber: float = 0.30
+    depth_min: float = 0.5
+    depth_max: float = 100.0
+    damping: float = 1e-6
 
 
 def _f32(t, dev):
@@ -57,7 +57,13 @@ def _f32(t, dev):
 
 class GSAligner:
     def __init__(self, **kw):
-        self.params = GSAlignerParams(**kw)
+        # a YAML written for the original gsaligner may carry fields this implementation does not have
+        # (its parameter list is not in the reference tree): they are ignored with a warning, not fatal
+        known = {f.name for f in dataclasses.fields(GSAlignerParams)}
+        unknown = sorted(set(kw) - known)
+        if unknown:
+            warnings.warn(f"GSAligner: ignoring unknown parameter(s) {unknown}", stacklevel=2)
+        self.params = GSAlignerParams(**{k: v for k, v in kw.items() if k in known})
         self.H, self.W = int(self.params.image_height), int(self.params.image_width)
         self._ref = None
         self._query = None

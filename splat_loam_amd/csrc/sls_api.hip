@@ -23,7 +23,7 @@ void set_error(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 static const char *kTimerNames[T_COUNT] = {
     "preprocess_fwd", "scan", "emit_keys", "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges",
-    "render_fwd", "grec_memset", "render_bwd", "preprocess_bwd", "adam", "knn", "consumer"
+    "render_fwd", "grec_memset", "render_bwd", "preprocess_bwd", "adam", "knn", "consumer", "resort"
 };
 constexpr int kTimerPool = 8192;
 struct TimerState {
@@ -34,11 +34,13 @@ struct TimerState {
     hipEvent_t start[kTimerPool], stop[kTimerPool];
     int slot[kTimerPool];
 };
-static TimerState g_timer;
+// the recorder belongs to the thread that enabled it (allocated on first use, one per thread that asks)
+static thread_local TimerState *t_timer = nullptr;
+#define g_timer (*t_timer)
 
 static inline bool timer_wants(int slot)
 {
-    if (!g_timer.enabled) return false;
+    if (!t_timer || !g_timer.enabled) return false;
     if (g_timer.mode == 1) return true;
     if (g_timer.mode == 2) return slot == T_RENDER_FWD || slot == T_RENDER_BWD;
     return slot == T_RENDER_BWD;
@@ -63,8 +65,6 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr);
-extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
-extern int g_fwd_variant, g_bwd_variant, g_pad_lds_fwd, g_pad_lds_bwd;
 size_t knn_scratch_bytes(int M);
 int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
 
@@ -257,8 +257,9 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
     for (int i = ngroups; i < kMaxAdamGroups; ++i) a.unit_end[i] = units;
     a.ngroups = ngroups;
     a.c = make_adam_coef(beta1, beta2, eps, step);
-    if (units == 0) return SLS_OK;
+    if (units == 0 && !void_flags) return SLS_OK;   // (with void flags the verdict is still published)
     int64_t blocks = (units + 255) / 256;
+    if (blocks < 1) blocks = 1;
     if (blocks > 256 * 8) blocks = 256 * 8;   // 8 blocks per CU, grid-stride beyond
     {
         ScopedTimer tm(T_ADAM, (hipStream_t)stream);
@@ -330,22 +331,18 @@ int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t 
 
 int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles)
 {
-    g_dbg_fwd_cycles = fwd_cycles;
-    g_dbg_bwd_cycles = bwd_cycles;
+    debug_state().dbg_fwd_cycles = fwd_cycles;
+    debug_state().dbg_bwd_cycles = bwd_cycles;
     return SLS_OK;
 }
 
 int sls_debug_variant(int fwd_variant, int bwd_variant)
 {
-    if (fwd_variant >= 0) g_fwd_variant = fwd_variant;
-    if (bwd_variant >= 0) g_bwd_variant = bwd_variant;
-    return SLS_OK;
-}
-
-int sls_debug_pad_lds(int fwd_bytes, int bwd_bytes)
-{
-    g_pad_lds_fwd = fwd_bytes;
-    g_pad_lds_bwd = bwd_bytes;
+    SLS_REQUIRE((fwd_variant < 0 || fwd_variant == 2 || fwd_variant == 3) &&
+                    (bwd_variant < 0 || bwd_variant == 2 || bwd_variant == 3),
+                "variants: 2 = 4x4 pixel blocks, 3 = 8x2 pixel blocks (negative: leave as it is)");
+    if (fwd_variant >= 0) debug_state().fwd_variant = fwd_variant;
+    if (bwd_variant >= 0) debug_state().bwd_variant = bwd_variant;
     return SLS_OK;
 }
 
@@ -354,6 +351,10 @@ const char *sls_timing_name(int slot) { return (slot >= 0 && slot < T_COUNT) ? k
 
 int sls_timing_enable(int on)
 {
+    if (!t_timer) {
+        if (!on) return SLS_OK;
+        t_timer = new TimerState();
+    }
     if (on && g_timer.created == 0) {
         for (int i = 0; i < kTimerPool; ++i) {
             if (hipEventCreate(&g_timer.start[i]) != hipSuccess || hipEventCreate(&g_timer.stop[i]) != hipSuccess) break;
@@ -370,6 +371,7 @@ int sls_timing_collect(double *total_ms, int64_t *counts)
 {
     SLS_REQUIRE(total_ms && counts, "null pointer");
     for (int s = 0; s < T_COUNT; ++s) { total_ms[s] = 0.0; counts[s] = 0; }
+    if (!t_timer) return SLS_OK;
     for (int i = 0; i < g_timer.used; ++i) {
         SLS_HIP_CHECK(hipEventSynchronize(g_timer.stop[i]));
         float ms = 0.0f;

@@ -36,8 +36,15 @@ void set_error(const char *fmt, ...);
 // figures).  Disabled: zero cost beyond one branch per launch.
 enum TimerSlot {
     T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT_KEYS, T_SORT_HIST, T_SORT_ROWSCAN, T_SORT_SCATTER, T_TILE_RANGES,
-    T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_COUNT
+    T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_RESORT, T_COUNT
 };
+// Debug / tuning switches of the CALLING THREAD (sls_debug_variant, sls_debug_wave_cycles, sls_timing_*):
+// thread-local, so that the library has no process-global mutable state.
+struct DebugState {
+    int fwd_variant = 3, bwd_variant = 3;                      // 2: 4x4 pixel blocks, 3: 8x2 (default)
+    uint32_t *dbg_fwd_cycles = nullptr, *dbg_bwd_cycles = nullptr;
+};
+DebugState &debug_state();
 void timer_begin(int slot, hipStream_t st);
 void timer_end(int slot, hipStream_t st);
 struct ScopedTimer {
@@ -267,6 +274,9 @@ struct AdamFuse {
     uint32_t *status_mirror;
     uint8_t *touched;       // optional: per surfel, set by the backward tile kernel if its gradient record was written
     float *void_flags;      // optional: 2 floats, the void bits for the keyframe-parallel all-reduce
+    int void_count, void_stride;   // the flags are written void_count times, void_stride floats apart (one copy per rank's chunk)
+    uint32_t gchunk;        // > 0: gradients leave in the reduce-scatter layout (SlsMappingConfig.grad_chunk) ...
+    float *gbase;           // ... relative to this base (the flat layout's element 0)
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
 };
 

@@ -44,7 +44,6 @@ int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
                       uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr);
-extern int g_bwd_variant;
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -272,14 +271,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     // ---- loss + dL/dallmap --------------------------------------------------------
     // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
     // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
-    const bool fuse_c = g_bwd_variant == 3 && cfg->depth_ratio == 0.0f;
+    const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
     ConsumerArgs cargs;
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
                          cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
                          w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr);
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
-    uint8_t *touched = g_bwd_variant >= 2 ? w.touched : nullptr;   // (the block kernels mark the surfels they reach)
+    uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                            w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
                            fuse_c ? &cargs : nullptr);
@@ -298,6 +297,18 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.touched = touched;
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     fuse.void_flags = cfg->void_flags_out;
+    fuse.void_count = 1; fuse.void_stride = 0;
+    if (cfg->grad_chunk) {
+        SLS_REQUIRE(!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
+                        (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&
+                        (uint64_t)10 * (uint64_t)N < (1ull << 32),
+                    "reduce-scatter gradient layout: apply_adam = 0, even N, chunk a multiple of 4 covering 10 N");
+        fuse.gchunk = cfg->grad_chunk;
+        fuse.gbase = grads;
+        fuse.void_flags = grads + cfg->grad_chunk;
+        fuse.void_count = (int)cfg->grad_ranks;
+        fuse.void_stride = (int)cfg->grad_chunk + 4;
+    }
     const bool aligned = (N % 2 == 0) && ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
     if (cfg->apply_adam && aligned) {
         fuse.enabled = 1;

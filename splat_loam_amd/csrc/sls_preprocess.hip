@@ -309,10 +309,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             reinterpret_cast<float *>(af.status_src)[6] = *af.reg_accum;
             *af.reg_accum = 0.0f;
         }
-        if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM all-reduce
+        if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM collective
             const uint32_t bits = af.status_src[1];
-            af.void_flags[0] = (bits & 1u) ? 1.0f : 0.0f;
-            af.void_flags[1] = (bits & ~1u) ? 1.0f : 0.0f;
+            for (int g = 0; g < (af.void_count > 0 ? af.void_count : 1); ++g) {
+                af.void_flags[(size_t)g * af.void_stride + 0] = (bits & 1u) ? 1.0f : 0.0f;
+                af.void_flags[(size_t)g * af.void_stride + 1] = (bits & ~1u) ? 1.0f : 0.0f;
+            }
         }
         if (af.status_mirror) {
 #pragma unroll
@@ -403,7 +405,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         dq.x = (dq.x - dd * q.x) * inv; dq.y = (dq.y - dd * q.y) * inv;
         dq.z = (dq.z - dd * q.z) * inv; dq.w = (dq.w - dd * q.w) * inv;
     }
-    if (!af.enabled || af.write_grads) {
+    if (af.gchunk) {
+        // reduce-scatter layout: flat element e of [xyz 3N | opacity N | scaling 2N | rotation 4N] lives at
+        // e + 4 * (e / C).  C is a multiple of 4 and N even, so a float2 / float4 never straddles a chunk end.
+        const uint32_t C = af.gchunk, n = (uint32_t)N, ui = (uint32_t)i;
+        uint32_t e = 3u * ui, qd = e / C, lim = (qd + 1u) * C;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (e + (uint32_t)k >= lim) { ++qd; lim += C; }
+            af.gbase[(size_t)(e + (uint32_t)k) + 4u * (size_t)qd] = dm[k];
+        }
+        e = 3u * n + ui;      af.gbase[(size_t)e + 4u * (size_t)(e / C)] = dop;
+        e = 4u * n + 2u * ui; *reinterpret_cast<float2 *>(af.gbase + (size_t)e + 4u * (size_t)(e / C)) = ds;
+        e = 6u * n + 4u * ui; *reinterpret_cast<float4 *>(af.gbase + (size_t)e + 4u * (size_t)(e / C)) = dq;
+    } else if (!af.enabled || af.write_grads) {
         dmeans[3 * i] = dm[0]; dmeans[3 * i + 1] = dm[1]; dmeans[3 * i + 2] = dm[2];
         dscales[i] = ds;
         drots[i] = dq;

@@ -26,7 +26,6 @@
 
 namespace sls {
 
-extern uint32_t *g_dbg_fwd_cycles, *g_dbg_bwd_cycles;
 
 template <int CTRL>
 __device__ __forceinline__ float dppq(float v)
@@ -471,6 +470,8 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
+    uint32_t *const g_dbg_fwd_cycles = debug_state().dbg_fwd_cycles;
+    SLS_REQUIRE(shape == 0 || shape == 1, "tile-kernel variant must be 2 (4x4 blocks) or 3 (8x2 blocks)");
 #define SLS_FWD_BLOCK(BW_, BH_, DBG_)                                                                             \
     hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_>), grid, block, 0, st, block_masks, cam,          \
                        (const uint2 *)ranges, vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
@@ -491,6 +492,8 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
+    uint32_t *const g_dbg_bwd_cycles = debug_state().dbg_bwd_cycles;
+    SLS_REQUIRE(shape == 0 || shape == 1, "tile-kernel variant must be 2 (4x4 blocks) or 3 (8x2 blocks)");
     ConsumerArgs ca;
     memset(&ca, 0, sizeof(ca));
     int cblocks = 0;

@@ -749,7 +749,7 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         uint64_t *edges = (uint64_t *)(((uintptr_t)sort_scratch + 7) & ~(uintptr_t)7);
         const int nA = (N + kResortWindow - 1) / kResortWindow;
         const int nB = (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow;   // windows that hold a real element
-        ScopedTimer tm(T_SORT_SCATTER, st);
+        ScopedTimer tm(T_RESORT, st);
         hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
                            (const uint32_t *)keys, comp);
         SLS_LAUNCH_CHECK("resort_sort_kernel");

@@ -11,14 +11,21 @@ read once at the end, which is the same single sync per iteration the reference
 has (`loss_total.item()`, slam/mapper.py:206-209).
 
 Keyframe-parallel mode: every rank calls step() on ITS keyframe
-with the same replicated model; the flat 10*N gradient bucket (+1 overflow word)
-is all-reduced in one RCCL collective and every rank applies the same guarded
-Adam update.
+with the same replicated model.  Two exchange schemes (`dp_mode`):
+  "rs_ag" (default, even N): the gradients leave the native step in G chunks, a
+      reduce-scatter gives every rank the summed chunk it owns, the rank applies
+      Adam to THAT 1/G of the parameters (its Adam moments are the only ones it
+      keeps: optimiser state sharded G ways), an all-gather republishes the
+      parameters — the bytes of one all-reduce, the optimiser pass divided by G,
+      replicas identical by construction;
+  "allreduce": the flat 10*N bucket (+2 void words) is all-reduced in one RCCL
+      collective and every rank applies the same guarded Adam update.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -43,6 +50,33 @@ def carry_bucket(buf: torch.Tensor, keep: torch.Tensor, n_new: int) -> torch.Ten
         src_off += width * n_old
         dst_off += width * n_new
     return out
+
+
+def dp_chunk(N: int, G: int) -> int:
+    """Elements per rank of the reduce-scatter layout: a multiple of 4 floats with G * C >= 10 N."""
+    return -(-(10 * N) // (4 * G)) * 4
+
+
+def dp_pieces(N: int, lo: int, hi: int, lrs):
+    """The flat range [lo, hi) of [xyz 3N | opacity N | scaling 2N | rotation 4N] cut at the parameter-group
+    boundaries: [(start, stop, learning rate)], at most four pieces."""
+    out = []
+    for g0, g1, lr in ((0, 3 * N, lrs[0]), (3 * N, 4 * N, lrs[1]), (4 * N, 6 * N, lrs[2]), (6 * N, 10 * N, lrs[3])):
+        a, b = max(lo, g0), min(hi, g1)
+        if b > a:
+            out.append((a, b, lr))
+    return out
+
+
+def dp_chunked(flat: torch.Tensor, C: int, G: int) -> torch.Tensor:
+    """Flat bucket -> the physical reduce-scatter layout (element e at e + 4 * (e // C); 4 spare words per chunk,
+    the first two of which carry the void flags).  The native step writes this layout directly; this helper is
+    the layout's definition in torch (tests, CPU emulation)."""
+    out = torch.zeros((G, C + 4), dtype=flat.dtype, device=flat.device)
+    pad = torch.zeros((G * C,), dtype=flat.dtype, device=flat.device)
+    pad[:flat.numel()] = flat
+    out[:, :C] = pad.view(G, C)
+    return out.reshape(-1)
 
 
 class MappingEngine:
@@ -88,7 +122,8 @@ class MappingEngine:
         self._ws_hw = None
         self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
         # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
-        # id(camera) -> [order tensor, iteration it was last written]; an order older than max_order_age
+        # id(camera) -> [order tensor, iteration it was last written, weak reference to the camera (an id can be
+        # reused by a new object once the old keyframe is gone)]; an order older than max_order_age
         # iterations gets an extra repair round, one older than max_order_age_extra is rebuilt from scratch
         self._orders = {}
         self.max_order_age = 4
@@ -96,12 +131,19 @@ class MappingEngine:
         self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
+        # keyframe-parallel exchange (set up at the first sharded step)
+        self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
+        self._dp = None                   # dict(G, rank, C, flat, gshard) once the reduce-scatter layout is in place
+        self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
     # when keep_grads is set; keyframe-parallel mode always fills and all-reduces it)
     def grad_views(self):
         N = self.N
         g = self.grads
+        if self._dp is not None:          # reduce-scatter layout -> flat copy (diagnostics / tests only)
+            C, G = self._dp["C"], self._dp["G"]
+            g = g.view(G, C + 4)[:, :C].reshape(-1)[:10 * N].clone()
         return {"xyz": g[0:3 * N].view(N, 3), "opacity": g[3 * N:4 * N].view(N, 1),
                 "scaling": g[4 * N:6 * N].view(N, 2), "rotation": g[6 * N:10 * N].view(N, 4)}
 
@@ -129,10 +171,16 @@ class MappingEngine:
         c.lr_xyz, c.lr_opacity, c.lr_scaling, c.lr_rotation = self.lrs
         c.apply_adam = 1 if apply_adam else 0
         c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
+        if self._dp is not None and not apply_adam:
+            c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
         return c
 
-    def _forget_order(self, camera, failed_repair=False):
+    def _order_entry(self, camera):
         ent = self._orders.get(id(camera))
+        return ent if ent is not None and ent[2]() is camera else None
+
+    def _forget_order(self, camera, failed_repair=False):
+        ent = self._order_entry(camera)
         if ent is not None:
             ent[1] = None
         if failed_repair:
@@ -157,11 +205,14 @@ class MappingEngine:
             self.capacity = max(4 * self.N, 1 << 16)
         ws_ptr, ws_bytes = self._ensure_workspace(H, W, self.capacity)
         xyz, scaling, rotation, opacity = self._params()
-        ent = self._orders.get(id(camera))
+        ent = self._order_entry(camera)
         if ent is None:
+            stale = [k for k, e in self._orders.items() if e[2]() is None]
+            for k in stale:
+                del self._orders[k]
             if len(self._orders) >= self.max_cached_orders:
                 self._orders.pop(next(iter(self._orders)))
-            ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None]
+            ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None, weakref.ref(camera)]
             self._orders[id(camera)] = ent
         age = self._enq - ent[1] if ent[1] is not None else None
         reuse = allow_reuse and self.reuse_depth_order and age is not None and age <= self.max_order_age_extra
@@ -178,7 +229,7 @@ class MappingEngine:
         cfg.depth_order = ent[0].data_ptr()
         cfg.status_mirror = mirror
         # keyframe-parallel mode: the void bits leave the step as two floats behind the gradient bucket
-        cfg.void_flags_out = None if apply_adam else self.grads.data_ptr() + 4 * 10 * self.N
+        cfg.void_flags_out = None if (apply_adam or self._dp is not None) else self.grads.data_ptr() + 4 * 10 * self.N
         _abi.check(lib.sls_mapping_step(
             C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
             self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
@@ -203,13 +254,19 @@ class MappingEngine:
     @torch.no_grad()
     def step(self, camera, group=None, sync: bool = True):
         """One mapping iteration on `camera`.  Returns the status dict (sync=True)
-        or None (sync=False: fire-and-forget; overflow is then detected at the
-        next synchronous step, the skipped Adam update keeps the model intact).
+        or None (sync=False: fire-and-forget — nobody reads the status, so an iteration
+        that overflowed its instance buffers is DROPPED, not repeated (its Adam update
+        was skipped on the device, the model stays intact), and `self.t` counts enqueued
+        iterations, which can then run ahead of the updates applied; use "lagged" when
+        every iteration has to count).
         sync="lagged": the iteration is enqueued BEFORE the status of
         the previous one is read, so the GPU queue never runs dry while the host
         waits for a loss value; returns the PREVIOUS iteration's status (None on
         the first call) — finish with flush()."""
         sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+        if self._dp is not None and not sharded:
+            raise RuntimeError("this engine's optimiser state is sharded over a process group (dp_mode rs_ag): "
+                               "it cannot take a single-process step")
         self._group = group
         if sync == "lagged":
             return self._step_lagged(camera)
@@ -223,13 +280,12 @@ class MappingEngine:
                 self._enqueue(camera, apply_adam=True, with_regulariser=True, allow_reuse=reuse_ok)
             else:
                 rank = dist.get_rank(group)
+                self._ensure_dp(group)
                 self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0), allow_reuse=reuse_ok)
-                # the step left its two void flags behind the gradients (cfg.void_flags_out): one collective,
-                # no torch glue kernels
-                dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
-                # any rank's flag voids the iteration everywhere: Adam reads the reduced flags and stores the
-                # group's verdict into the local status word, so the one status read below is the only sync
-                self._adam_reduced(self.status, None)
+                # the step left its void flags behind the gradients: no torch glue kernels; any rank's flag voids
+                # the iteration everywhere: Adam reads the reduced flags and stores the group's verdict into the
+                # local status word, so the one status read below is the only sync
+                self._exchange_and_adam(group, self.status, None)
             if not sync:
                 self.t += 1
                 return None
@@ -257,10 +313,11 @@ class MappingEngine:
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             # keyframe-parallel: the group's verdict is known on the device only (the void flags ride the
             # gradient all-reduce and guard Adam), so the host can lag here exactly as on one GPU
+            self._ensure_dp(group)
             self._enqueue(camera, apply_adam=False, with_regulariser=(dist.get_rank(group) == 0),
                           status=self._lag_dev[slot])
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
-            self._adam_reduced(self._lag_dev[slot], self._lag_host[slot].data_ptr() if self.status_mirror else None)
+            self._exchange_and_adam(group, self._lag_dev[slot],
+                                    self._lag_host[slot].data_ptr() if self.status_mirror else None)
             if not self.status_mirror:
                 self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
         elif self.status_mirror:
@@ -293,7 +350,9 @@ class MappingEngine:
         torch.cuda.current_stream(self.dev).synchronize()
         cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
         cur_void = cur_st is not None and cur_st["overflow"]
-        self.t -= 2 if cur_void else 1
+        # both in-flight iterations are taken off the step count; the one that did run is put back after the
+        # redo below, so that the repeated iteration uses the Adam step number it was meant to have
+        self.t -= 2 if cur is not None else 1
         self._forget_order(pcam, failed_repair=st["resort_failed"])     # repeat with the full sort
         if cur_void:
             self._forget_order(cur[1], failed_repair=cur_st["resort_failed"])
@@ -306,6 +365,8 @@ class MappingEngine:
             self._lag_ready.append(cur_st)   # (another keyframe that fitted: it did run, nothing to repeat)
         st = self.step(pcam, group=self._group, sync=True)
         self._lag_ready.append(st)
+        if cur is not None and not cur_void:
+            self.t += 1
         if cur_void:
             if redo_current:
                 # (not through _step_lagged: its return value would take a status off the queue)
@@ -328,6 +389,79 @@ class MappingEngine:
         self.flushed, self._lag_ready = self._lag_ready, []
         return self.flushed[-1] if self.flushed else None
 
+    def _ensure_dp(self, group):
+        """First sharded step: lay the gradient bucket out for the reduce-scatter, move the four parameter tensors
+        into ONE flat buffer (they stay torch Parameters: their storage becomes a view of it) and keep only this
+        rank's 1/G of the Adam moments."""
+        if self._dp is not None or self.dp_mode != "rs_ag" or self.N % 2 != 0 or 10 * self.N >= 2 ** 32:
+            return
+        G, rank, N = dist.get_world_size(group), dist.get_rank(group), self.N
+        C = dp_chunk(N, G)
+        flat = torch.zeros((G * C,), dtype=torch.float32, device=self.dev)
+        m = self.model
+        for p, off, w in ((m._xyz, 0, 3), (m._opacity, 3 * N, 1), (m._scaling, 4 * N, 2), (m._rotation, 6 * N, 4)):
+            view = flat[off:off + w * N].view(N, w)
+            view.copy_(p.data)
+            p.data = view
+        lo, hi = min(rank * C, 10 * N), min((rank + 1) * C, 10 * N)
+        ea, es = torch.zeros((C,), dtype=torch.float32, device=self.dev), torch.zeros((C,), dtype=torch.float32, device=self.dev)
+        ea[:hi - lo].copy_(self.exp_avg[lo:hi])
+        es[:hi - lo].copy_(self.exp_avg_sq[lo:hi])
+        self.exp_avg, self.exp_avg_sq = ea, es                # sharded optimiser state
+        self.grads = torch.zeros((G * (C + 4),), dtype=torch.float32, device=self.dev)
+        self._dp = {"G": G, "rank": rank, "C": C, "flat": flat, "lo": lo, "hi": hi,
+                    "gshard": torch.zeros((C + 4,), dtype=torch.float32, device=self.dev)}
+
+    def _exchange_and_adam(self, group, status, mirror):
+        ev = None
+        if self.comm_events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        if self._dp is None:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+            if ev:
+                ev[1].record()
+            self._adam_reduced(status, mirror)
+            if ev:
+                ev[2].record(); ev[3].record()
+        else:
+            d = self._dp
+            dist.reduce_scatter_tensor(d["gshard"], self.grads, op=dist.ReduceOp.SUM, group=group)
+            if ev:
+                ev[1].record()
+            self._adam_shard(status, mirror)
+            if ev:
+                ev[2].record()
+            C, r = d["C"], d["rank"]
+            dist.all_gather_into_tensor(d["flat"], d["flat"][r * C:(r + 1) * C], group=group)
+            if ev:
+                ev[3].record()
+        if ev:
+            self.comm_events.append(ev)
+
+    def _adam_shard(self, status, mirror):
+        """Adam on the flat elements [lo, hi) this rank owns: up to four pieces, one per parameter group the range
+        crosses (each has its own learning rate); gradients = the reduce-scattered chunk, moments = the local shard."""
+        lib, d, N = _abi.lib(), self._dp, self.N
+        lo, hi, C = d["lo"], d["hi"], d["C"]
+        arr = (_abi.SlsAdamGroup * 4)()
+        k = 0
+        for a, b, lr in dp_pieces(N, lo, hi, self.lrs):
+            arr[k].param = d["flat"].data_ptr() + 4 * a
+            arr[k].grad = d["gshard"].data_ptr() + 4 * (a - lo)
+            arr[k].exp_avg = self.exp_avg.data_ptr() + 4 * (a - lo)
+            arr[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * (a - lo)
+            arr[k].numel = b - a
+            arr[k].lr = lr
+            k += 1
+        if k == 0:       # (a rank whose chunk lies beyond 10 N: nothing to update, but it publishes the verdict)
+            arr[0].param = arr[0].grad = arr[0].exp_avg = arr[0].exp_avg_sq = d["gshard"].data_ptr()
+            arr[0].numel, arr[0].lr, k = 0, 0.0, 1
+        _abi.check(lib.sls_adam_step_reduced(arr, k, self.betas[0], self.betas[1], self.eps, self.t + 1,
+                                             d["gshard"].data_ptr() + 4 * C, status.data_ptr(), mirror,
+                                             torch.cuda.current_stream(self.dev).cuda_stream),
+                   "sls_adam_step_reduced")
+
     def _adam_reduced(self, status, mirror):
         lib = _abi.lib()
         N = self.N
@@ -348,12 +482,18 @@ class MappingEngine:
                    "sls_adam_step_reduced")
 
     @torch.no_grad()
-    def remap(self, keep=None, appended: int = 0):
+    def remap(self, keep=None, appended: int = 0, reset_state: bool = True):
         """The model's surfel set changed — call this AFTER replacing the model's parameter tensors, as
         Mapper.densify / the opacity pruning do through cat_tensors_to_optimizer / _prune_optimizer
         (scene/gaussian_model.py:223-316).  `keep`: bool (N_old,), the survivors in their old order (None: all);
-        `appended`: number of new surfels that follow them.  The Adam moments of the survivors are kept, the new
-        surfels start from zero moments and the step count goes on, exactly as the reference's optimizer state."""
+        `appended`: number of new surfels that follow them.
+
+        `reset_state=True` (default) is what the reference DOES: `_prune_optimizer` re-files the pruned parameter
+        under `optimizer.state[group["name"]]` (scene/gaussian_model.py:237-256), so torch.optim.Adam finds no
+        state for the new tensor, and since `update_model` runs densify -> optimize -> prune on every keyframe
+        (slam/mapper.py:33-42), each keyframe's `optimize()` starts Adam at step 0 with zero moments.
+        `reset_state=False` is what that code evidently intends (and what `cat_tensors_to_optimizer` does when it
+        finds a state): the survivors keep their moments, new surfels start from zero, the step count goes on."""
         if self._lag_pending is not None or self._lag_ready:
             self.flush()
         n_old = self.N
@@ -367,8 +507,17 @@ class MappingEngine:
         if int(self.model._xyz.shape[0]) != n_new:
             raise RuntimeError(f"the model holds {int(self.model._xyz.shape[0])} surfels, keep/appended describe {n_new}")
 
-        self.exp_avg = carry_bucket(self.exp_avg, keep, n_new)
-        self.exp_avg_sq = carry_bucket(self.exp_avg_sq, keep, n_new)
+        if reset_state:
+            self.exp_avg = torch.zeros((10 * n_new,), dtype=torch.float32, device=self.dev)
+            self.exp_avg_sq = torch.zeros((10 * n_new,), dtype=torch.float32, device=self.dev)
+            self.t = 0
+        else:
+            self.exp_avg = carry_bucket(self.exp_avg, keep, n_new)
+            self.exp_avg_sq = carry_bucket(self.exp_avg_sq, keep, n_new)
+        if self._dp is not None and not reset_state:
+            raise RuntimeError("remap(reset_state=False) is not available once the optimiser state is sharded "
+                               "(keyframe-parallel mode rs_ag): use reset_state=True or dp_mode='allreduce'")
+        self._dp = None                               # re-sharded at the next keyframe-parallel step
         self.N = n_new
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)
         self.workspace = None                        # sized by N: rebuilt at the next step

@@ -24,6 +24,7 @@ class _CameraAux:
 
 def camera_aux(camera) -> _CameraAux:
     key = (camera.projection_matrix.data_ptr(), camera.projection_matrix._version, camera.image_depth.data_ptr(),
+           camera.image_depth._version, tuple(camera.image_depth.shape), camera.image_depth.dtype,
            camera.image_valid.data_ptr(), camera.image_valid._version)
     aux = getattr(camera, "_sls_aux", None)
     if aux is not None and aux.key == key:

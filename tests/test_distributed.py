@@ -67,3 +67,78 @@ def test_two_rank_gloo_matches_summed_single_process(tmp_path):
     for k, p in (("xyz", model._xyz), ("scaling", model._scaling), ("rotation", model._rotation), ("opacity", model._opacity)):
         ref = p.detach().numpy()
         assert np.abs(r0[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6), k
+
+
+# ---------------------------------------------------------------------------
+# The engine's second exchange scheme (engine.py: dp_mode "rs_ag"): gradients in G chunks -> reduce-scatter ->
+# Adam on the rank's own chunk with ITS shard of the moments -> all-gather of the parameters.  Emulated here
+# with torch ops on the CPU over gloo (the native step / Adam kernels need the GPU: tests/test_gpu_parity.py
+# ::test_engine_keyframe_parallel_two_ranks runs the real thing): the layout helpers the engine uses
+# (dp_chunk, dp_pieces, dp_chunked) must reproduce, bit for bit, what one all-reduce + Adam everywhere gives.
+# ---------------------------------------------------------------------------
+def _adam_torch(p, g, m, v, lr, t, b1=0.9, b2=0.999, eps=1e-15):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v.sqrt() / (1 - b2 ** t) ** 0.5).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+
+
+def _rsag_worker(rank, world, port, out_dir, n):
+    from splat_loam_amd.engine import dp_chunk, dp_chunked, dp_pieces
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lrs = (5e-4, 5e-2, 5e-3, 1e-3)
+    g0 = torch.Generator().manual_seed(7)
+    params = torch.randn(10 * n, generator=g0)
+    pa, pb = params.clone(), None
+    C = dp_chunk(n, world)
+    flat = torch.zeros(world * C); flat[:10 * n] = params
+    ma, va = torch.zeros(10 * n), torch.zeros(10 * n)
+    lo, hi = min(rank * C, 10 * n), min((rank + 1) * C, 10 * n)
+    ms, vs = torch.zeros(C), torch.zeros(C)
+    for t in (1, 2, 3):
+        grad = torch.randn(10 * n, generator=torch.Generator().manual_seed(100 * t + rank))
+        void = torch.tensor([0.0, 0.0])
+        # (a) all-reduce of the flat bucket + Adam on everything
+        ga = torch.cat([grad, void]); dist.all_reduce(ga)
+        for a, b, lr in dp_pieces(n, 0, 10 * n, lrs):
+            _adam_torch(pa[a:b], ga[a:b], ma[a:b], va[a:b], lr, t)
+        # (b) chunked layout -> reduce-scatter -> Adam on the own chunk -> all-gather
+        phys = dp_chunked(grad, C, world)
+        phys.view(world, C + 4)[:, C:C + 2] = void
+        shard = torch.empty(C + 4)
+        dist.reduce_scatter_tensor(shard, phys)
+        assert float(shard[C]) == 0.0 and float(shard[C + 1]) == 0.0
+        for a, b, lr in dp_pieces(n, lo, hi, lrs):
+            _adam_torch(flat[a:b], shard[a - lo:b - lo], ms[a - lo:b - lo], vs[a - lo:b - lo], lr, t)
+        dist.all_gather_into_tensor(flat, flat[rank * C:(rank + 1) * C].clone())
+        assert torch.equal(shard[:hi - lo], ga[lo:hi]), "reduce-scattered chunk = slice of the all-reduced bucket"
+    assert torch.equal(flat[:10 * n], pa), "both exchange schemes walk the same parameter trajectory"
+    assert torch.equal(ms[:hi - lo], ma[lo:hi]) and torch.equal(vs[:hi - lo], va[lo:hi])
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), flat.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [2, 6, 300, 1234])        # incl. chunks that end inside a group / ranks with a short chunk
+def test_reduce_scatter_adam_allgather_equals_allreduce_adam(tmp_path, n):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rsag_worker, args=(2, port, str(tmp_path), n), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")), "replicas identical"
+
+
+def test_dp_layout_helpers():
+    from splat_loam_amd.engine import dp_chunk, dp_chunked, dp_pieces
+    for n, G in ((2, 8), (6, 2), (300, 2), (500000, 8), (1234, 3)):
+        C = dp_chunk(n, G)
+        assert C % 4 == 0 and G * C >= 10 * n and (G * (C - 4) < 10 * n or C == 4)
+        flat = torch.arange(10 * n, dtype=torch.float32)
+        phys = dp_chunked(flat, C, G).view(G, C + 4)
+        e = torch.arange(10 * n)
+        assert torch.equal(phys.reshape(-1)[e + 4 * (e // C)], flat), "element e lives at e + 4 * (e // C)"
+        assert float(phys[:, C:].abs().max()) == 0.0
+        cover = []
+        for r in range(G):
+            for a, b, lr in dp_pieces(n, min(r * C, 10 * n), min((r + 1) * C, 10 * n), (1.0, 2.0, 3.0, 4.0)):
+                cover.append((a, b))
+                assert lr == (1.0 if b <= 3 * n else 2.0 if b <= 4 * n else 3.0 if b <= 6 * n else 4.0)
+        assert cover[0][0] == 0 and cover[-1][1] == 10 * n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))

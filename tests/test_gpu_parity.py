@@ -54,6 +54,9 @@ def _compare_forward(oracle32, st, ost, cam, name):
     oam = ost["allmap"]
     frag = ost["fwd"]["fragile"]
     ok = ~frag
+    # "fragile" = a discrete decision of the pixel lies within 1e-4 of its threshold; such pixels are compared
+    # loosely below, so their number is bounded: measured 0.3 .. 1.5 % on the test scenes
+    assert frag.mean() <= 0.02, f"{name}: {frag.mean():.3%} of the pixels are flagged fragile"
     worst = {}
     for c in range(7):
         scale = max(np.abs(oam[c]).max(), 1e-12)
@@ -102,6 +105,10 @@ def _compare_backward(oracle32, st, t, ost, sc, name, seed=3):
         e = np.abs(a.astype(np.float64) - ref).max() / scale
         worst[nm] = e
         assert e <= RTOL, f"{name}: d{nm} max-norm rel err {e:.3e}"
+        big = np.abs(ref) > 1e-3 * scale          # element-wise: entries above 1e-3 of the tensor's maximum
+        er = (np.abs(a.astype(np.float64) - ref)[big] / np.abs(ref)[big]).max() if big.any() else 0.0
+        worst[nm + "_elem"] = er
+        assert er <= 2e-3, f"{name}: d{nm} element-wise rel err {er:.3e}"
     return worst
 
 
@@ -581,7 +588,7 @@ def test_mapping_engine_remap_after_prune_and_densify(device):
 
     moments_before = eng.exp_avg[:3 * N].view(N, 3)[keep.to(device)].clone()
     surgery(a, None)
-    eng.remap(keep, appended=500)
+    eng.remap(keep, appended=500, reset_state=False)
     surgery(b, b.optimizer)
     n2 = int(keep.sum()) + 500
     assert eng.N == n2 and torch.equal(eng.exp_avg[:3 * n2].view(n2, 3)[:n2 - 500], moments_before)
@@ -596,6 +603,13 @@ def test_mapping_engine_remap_after_prune_and_densify(device):
         assert float((getattr(a, name).detach() - getattr(b, name).detach()).abs().max()) <= 0.05 * moved + 1e-6, name
     with pytest.raises(RuntimeError):
         eng.remap(None, appended=7)                     # the model was not resized accordingly
+    # the reference's own behaviour (scene/gaussian_model.py:237-256 drops the state on every prune): Adam restarts
+    eng.remap(None, appended=0)
+    assert eng.t == 0 and float(eng.exp_avg.abs().max()) == 0.0 and float(eng.exp_avg_sq.abs().max()) == 0.0
+    before = a._xyz.detach().clone()
+    eng.step(cam)
+    step = (a._xyz.detach() - before).abs()
+    assert eng.t == 1 and float(step.max()) <= 5e-4 * 1.001     # first Adam step: |update| = lr wherever g != 0
 
 
 @pytest.mark.parametrize("N,H,W", [(1, 16, 64), (2, 16, 64), (3, 16, 64), (100, 16, 64), (500, 48, 80), (1000, 128, 1024),
@@ -675,11 +689,11 @@ def test_depth_order_repair_rounds(device):
         assert np.array_equal(e._orders[id(cam)][0].cpu().numpy(), o0)
 
 
-@pytest.mark.parametrize("fwd_variant,bwd_variant", [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2), (3, 3)],
-                         ids=["workgroup-per-tile", "wave-per-subtile", "block4x4-fwd", "block4x4-bwd", "block4x4", "block8x2"])
+@pytest.mark.parametrize("fwd_variant,bwd_variant", [(2, 2), (2, 3), (3, 2), (3, 3)],
+                         ids=["block4x4", "block4x4-fwd", "block4x4-bwd", "block8x2"])
 def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
-    """Both implementations of the tile kernels (shared-LDS workgroup per tile /
-    independent wave per 8x8 sub-tile) pass the same parity bar."""
+    """Both pixel-block shapes of the tile kernels (4x4 and 8x2, also mixed: the backward of one reading the
+    forward of the other, whose contribution masks it then cannot use) pass the same parity bar."""
     from splat_loam_amd import _abi
     lib = _abi.lib()
     lib.sls_debug_variant(fwd_variant, bwd_variant)
@@ -695,7 +709,7 @@ def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, 
         lib.sls_debug_variant(3, 3)
 
 
-def _engine_rank(rank, world, port, out_dir, mode="sync"):
+def _engine_rank(rank, world, port, out_dir, mode="sync", dp_mode="rs_ag"):
     import os
     import torch.distributed as dist
     from splat_loam_amd import synth
@@ -710,6 +724,7 @@ def _engine_rank(rank, world, port, out_dir, mode="sync"):
     cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[rank], data_device="cuda:0")
     model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
     eng = MappingEngine(model, MappingConfig())
+    eng.dp_mode = dp_mode
     if rank == 1:
         eng.capacity = 1024           # one rank overflows: BOTH must skip Adam and repeat
     if mode == "lagged":
@@ -727,14 +742,24 @@ def _engine_rank(rank, world, port, out_dir, mode="sync"):
         assert moved > 0
         assert (ref._xyz.detach() - model._xyz.detach()).abs().max().item() <= 0.02 * moved
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
-                 rot=model._rotation.detach().cpu().numpy(), g=eng.grads.cpu().numpy(), t=eng.t)
+                 rot=model._rotation.detach().cpu().numpy(), sc=model._scaling.detach().cpu().numpy(),
+                 op=model._opacity.detach().cpu().numpy(), t=eng.t)
         dist.destroy_process_group()
         return
+
+    def reduced():
+        # the summed gradient as this rank holds it: the whole bucket (all-reduce) or its own chunk (reduce-scatter)
+        if eng._dp is None:
+            return eng.grads[:-2].cpu().numpy(), 0
+        d = eng._dp
+        return d["gshard"][:d["hi"] - d["lo"]].cpu().numpy(), d["lo"]
     st = eng.step(cam)
-    g1 = eng.grads[:-2].cpu().numpy()
+    g1, lo = reduced()
     st = eng.step(cam)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
-             rot=model._rotation.detach().cpu().numpy(), g=eng.grads.cpu().numpy(), g1=g1, R=st["R"], t=eng.t)
+             rot=model._rotation.detach().cpu().numpy(), sc=model._scaling.detach().cpu().numpy(),
+             op=model._opacity.detach().cpu().numpy(), g1=g1, lo=lo, R=st["R"], t=eng.t,
+             sharded_state=int(eng._dp is not None), state_len=int(eng.exp_avg.numel()))
     dist.destroy_process_group()
 
 
@@ -747,14 +772,16 @@ def test_engine_keyframe_parallel_lagged_two_ranks(device, tmp_path):
     mp.spawn(_engine_rank, args=(2, port, str(tmp_path), "lagged"), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     assert int(r0["t"]) == int(r1["t"]) == 4
-    for k in ("xyz", "rot", "g"):
+    for k in ("xyz", "rot", "sc", "op"):
         assert np.array_equal(r0[k], r1[k]), f"replicas diverged: {k}"
 
 
-def test_engine_keyframe_parallel_two_ranks(device, tmp_path):
-    """Keyframe-parallel engine with 2 ranks (gloo, one GPU): the all-reduced gradient
-    equals the sum of the two keyframes' gradients (regulariser once), replicas stay
-    bit-identical, an overflow on one rank makes every rank repeat the iteration."""
+@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce"])
+def test_engine_keyframe_parallel_two_ranks(device, tmp_path, dp_mode):
+    """Keyframe-parallel engine with 2 ranks (gloo, one GPU), both exchange schemes (reduce-scatter -> Adam on the
+    rank's half -> all-gather of the parameters / one all-reduce -> Adam everywhere): the reduced gradient equals
+    the sum of the two keyframes' gradients (regulariser once), replicas stay bit-identical, an overflow on
+    one rank makes every rank repeat the iteration."""
     import socket
     import torch.multiprocessing as mp
     from splat_loam_amd import synth
@@ -762,11 +789,18 @@ def test_engine_keyframe_parallel_two_ranks(device, tmp_path):
     from splat_loam_amd.mapping import MappingConfig
     from splat_loam_amd.scene import Camera, SurfelModel
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_engine_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_engine_rank, args=(2, port, str(tmp_path), "sync", dp_mode), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     assert int(r0["t"]) == int(r1["t"]) == 2
-    for k in ("xyz", "rot", "g", "g1"):
+    for k in ("xyz", "rot", "sc", "op"):
         assert np.array_equal(r0[k], r1[k]), f"replicas diverged: {k}"
+    if dp_mode == "rs_ag":
+        assert int(r0["sharded_state"]) == 1 and int(r0["state_len"]) < 10 * 5000, "optimiser state is sharded"
+        assert int(r0["lo"]) == 0 and int(r1["lo"]) == len(r0["g1"])
+        reduced = np.concatenate([r0["g1"], r1["g1"]])
+    else:
+        assert np.array_equal(r0["g1"], r1["g1"])
+        reduced = r0["g1"]
     N, H, W = 5000, 32, 256
     sc = synth.make_scene(N, H, W, seed=31, range_lo=2.0, range_hi=15.0)
     depth, valid = synth.make_targets(H, W, sc)
@@ -779,4 +813,4 @@ def test_engine_keyframe_parallel_two_ranks(device, tmp_path):
         torch.cuda.synchronize()
         total = total + eng.grads[:-2].cpu().numpy().astype(np.float64)
     scale = np.abs(total).max()
-    assert np.abs(r0["g1"] - total).max() <= 1e-5 * scale
+    assert np.abs(reduced - total).max() <= 1e-5 * scale
