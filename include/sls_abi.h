@@ -146,6 +146,20 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R,
                  float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
                  float *dL_dopacities, const uint64_t *block_masks, void *stream);
 
+/* The same backward with DETERMINISTIC accumulation of the per-surfel gradient records: integer atomics
+ * instead of float atomics (first launch: the largest |contribution| per surfel and field; second launch:
+ * every contribution scaled by 2^(40 - exponent of that maximum), rounded, added as a 64-bit integer), so
+ * that two runs on the same inputs return the same bits.  No `grec` buffer; det_scratch: DEVICE scratch of
+ * sls_backward_det_scratch_bytes(N). */
+size_t sls_backward_det_scratch_bytes(int N);
+int sls_backward_det(const SlsCamera *cam, int N, uint64_t R,
+                     const float *means3D, const float *scales, const float *rotations, const int32_t *radii,
+                     const float *rec, const uint32_t *ranges, const uint32_t *vals_sorted,
+                     const float *col_cs, const float *row_cs, const float *pix_state, const uint32_t *pix_contrib,
+                     const float *dL_dallmap,
+                     float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dopacities,
+                     const uint64_t *block_masks, void *det_scratch, size_t det_scratch_bytes, void *stream);
+
 /* ---- fused consumer of allmap: render() post-processing + mapper loss ------
  * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of
  * slam/mapper.py:174-187 on top of the maps of gaussian_renderer/__init__.py:48-93
@@ -173,7 +187,10 @@ int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_dept
  * if R exceeds it the excess is dropped, status.overflow is set and the Adam
  * update is skipped (the caller grows the capacity and repeats the iteration).
  * status_dev lives in DEVICE memory; read it after the stream has drained.
- * *allmap_out (optional) receives the address of allmap inside the workspace. */
+ * *allmap_out (optional) receives the address of allmap inside the workspace; with
+ * depth_ratio == 0 the loss neither reads nor differentiates planes 5 (median) and 6
+ * (distortion) — gaussian_renderer/__init__.py:79-86 — and this call leaves them zero
+ * (sls_forward_stage2 always fills all seven). */
 struct SlsMappingStatus;
 typedef struct SlsMappingConfig {
     float lambda_alpha, lambda_normal, scaling_max, scaling_max_penalty, depth_ratio;
@@ -206,6 +223,11 @@ typedef struct SlsMappingConfig {
                               * void_flags_out, which is ignored then): after a SUM reduce-scatter every rank finds the
                               * group's verdict behind its own chunk.  `grads` holds grad_ranks * (C + 4) floats. */
     uint32_t grad_ranks;
+    int32_t deterministic;   /* 1: the backward tile kernel accumulates the gradient records with integer atomics
+                              * (two launches: per-field maximum, then fixed-point sum scaled by it): bit-identical
+                              * gradients from run to run, about one extra tile-backward per iteration.  0: float
+                              * atomics, whose order — and so the last bits of the sums — changes between runs */
+    int32_t pad0;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */

@@ -36,6 +36,7 @@ class SlsMappingConfig(C.Structure):
         ("status_mirror", C.c_void_p),
         ("void_flags_out", C.c_void_p),
         ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
+        ("deterministic", C.c_int32), ("pad0", C.c_int32),
     ]
 
 
@@ -88,6 +89,8 @@ _PROTOS = {
                          [_VP] * 4 + [C.POINTER(SlsMappingConfig), C.c_uint64, _VP, C.c_size_t, _VP,
                                       C.POINTER(C.c_void_p), _VP]),
     "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 18 + [_VP]),
+    "sls_backward_det_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "sls_backward_det": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP, C.c_size_t, _VP]),
     "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
     "sls_adam_step_guarded": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP]),

@@ -277,6 +277,9 @@ struct AdamFuse {
     int void_count, void_stride;   // the flags are written void_count times, void_stride floats apart (one copy per rank's chunk)
     uint32_t gchunk;        // > 0: gradients leave in the reduce-scatter layout (SlsMappingConfig.grad_chunk) ...
     float *gbase;           // ... relative to this base (the flat layout's element 0)
+    // deterministic accumulation (render_bwd DET): the gradient record is det_acc * 2^(exponent(det_max) - 166)
+    const uint32_t *det_max;
+    const long long *det_acc;
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
 };
 

@@ -39,11 +39,12 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     uint32_t *total_out = nullptr);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
-                      uint64_t *block_masks = nullptr);
+                      uint64_t *block_masks = nullptr, bool no_median_dist = false);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
-                      uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr);
+                      uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr,
+                      uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -63,6 +64,7 @@ struct MapWs {
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
     float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum; uint8_t *touched;
+    uint32_t *det_max; unsigned long long *det_acc; size_t det_bytes;    // deterministic accumulation (zeroed per iteration when used)
     size_t total;
 };
 
@@ -105,6 +107,9 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.touched = (uint8_t *)take(n);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
     w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
+    w.det_max = (uint32_t *)take(n * SLS_GREC_STRIDE * 4);
+    w.det_acc = (unsigned long long *)take(n * SLS_GREC_STRIDE * 8);
+    w.det_bytes = (size_t)((char *)w.det_acc - (char *)w.det_max) + n * SLS_GREC_STRIDE * 8;
     w.total = off;
     return w;
 }
@@ -206,6 +211,45 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
                                  dL_dscales, dL_drotations, dL_dopacities, st);
 }
 
+size_t sls_backward_det_scratch_bytes(int N) { return N > 0 ? (size_t)N * SLS_GREC_STRIDE * 12 + 256 : 256; }
+
+int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
+                     const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
+                     const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
+                     const uint32_t *pix_contrib, const float *dL_dallmap, float *dL_dmeans3D, float *dL_dscales,
+                     float *dL_drotations, float *dL_dopacities, const uint64_t *block_masks, void *det_scratch,
+                     size_t det_scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(cam, "null pointer");
+    SLS_REQUIRE(N >= 0, "negative N");
+    if (N == 0) return SLS_OK;
+    SLS_REQUIRE(means3D && scales && rotations && radii && det_scratch && dL_dmeans3D && dL_dscales && dL_drotations &&
+                    dL_dopacities,
+                "null pointer");
+    if (det_scratch_bytes < sls_backward_det_scratch_bytes(N)) {
+        set_error("deterministic-backward scratch too small");
+        return SLS_E_SCRATCH;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    unsigned long long *acc = (unsigned long long *)(((uintptr_t)det_scratch + 255) & ~(uintptr_t)255);
+    uint32_t *mx = (uint32_t *)(acc + (size_t)N * SLS_GREC_STRIDE);
+    SLS_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * SLS_GREC_STRIDE * 12, st));
+    if (R > 0) {
+        SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
+                    "null pointer");
+        int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
+                                   nullptr, st, block_masks, false, nullptr, nullptr, mx, acc);
+        if (rc) return rc;
+    }
+    AdamFuse fuse;
+    memset(&fuse, 0, sizeof(fuse));
+    fuse.det_max = mx;
+    fuse.det_acc = (const long long *)acc;
+    return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, nullptr, dL_dmeans3D,
+                                 dL_dscales, dL_drotations, dL_dopacities, st, &fuse);
+}
+
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity)
 {
     if (N < 0 || H <= 0 || W <= 0) return 0;
@@ -266,7 +310,8 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
-                           nullptr, st, true, w.block_masks);   // (nobody reads the consumed counters here)
+                           nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
+                           cfg->depth_ratio == 0.0f);           // (nor, then, the median / distortion planes: not tracked)
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
@@ -279,9 +324,11 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
     uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
+    const bool det = cfg->deterministic != 0;
+    if (det) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                            w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
-                           fuse_c ? &cargs : nullptr);
+                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr);
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
@@ -298,6 +345,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     fuse.void_flags = cfg->void_flags_out;
     fuse.void_count = 1; fuse.void_stride = 0;
+    if (det) { fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc; }
     if (cfg->grad_chunk) {
         SLS_REQUIRE(!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
                         (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&

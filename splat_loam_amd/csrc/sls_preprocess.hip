@@ -340,9 +340,21 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (radii[i] > 0 && marked) {
         SurfelGeom g;
         surfel_geom(cam, m, s, q, g);
-        const float4 g0 = grec[(size_t)i * 4 + 0], g1 = grec[(size_t)i * 4 + 1];
-        const float4 g2 = grec[(size_t)i * 4 + 2], g3 = grec[(size_t)i * 4 + 3];
-        if (af.clear_grec) {   // only records of visible surfels are ever touched by the tile kernel
+        float4 g0, g1, g2, g3;
+        if (af.det_max) {
+            float gv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int ex = (int)((af.det_max[(size_t)i * 16 + k] >> 23) & 0xFFu);
+                gv[k] = (float)ldexp((double)af.det_acc[(size_t)i * 16 + k], ex - 166);
+            }
+            g0 = make_float4(gv[0], gv[1], gv[2], gv[3]); g1 = make_float4(gv[4], gv[5], gv[6], gv[7]);
+            g2 = make_float4(gv[8], gv[9], gv[10], gv[11]); g3 = make_float4(gv[12], gv[13], gv[14], gv[15]);
+        } else {
+            g0 = grec[(size_t)i * 4 + 0]; g1 = grec[(size_t)i * 4 + 1];
+            g2 = grec[(size_t)i * 4 + 2]; g3 = grec[(size_t)i * 4 + 3];
+        }
+        if (af.clear_grec && !af.det_max) {   // only records of visible surfels are ever touched by the tile kernel
             const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             grec[(size_t)i * 4 + 0] = z; grec[(size_t)i * 4 + 1] = z; grec[(size_t)i * 4 + 2] = z; grec[(size_t)i * 4 + 3] = z;
         }

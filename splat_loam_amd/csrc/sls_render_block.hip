@@ -102,8 +102,15 @@ __device__ __forceinline__ bool block_active_box(uint64_t m, int x0, int y0, flo
 // ---------------------------------------------------------------------------
 // A6 forward
 // ---------------------------------------------------------------------------
-template <int BW, int BH, bool DBG>
-__global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restrict__ blk_mask,
+// LEAN (sls_mapping_step with depth_ratio = 0): the consumer neither reads the median / distortion channels
+// nor sends a gradient into them (gaussian_renderer/__init__.py:79-86 at depth_ratio 0; dL/dallmap[5:7] == 0),
+// and the LEAN backward does not read the two distortion moments or the median contributor: they are not
+// tracked (planes 5 and 6 are written as zeros) — one reciprocal and ~11 instructions less per step.
+#ifndef SLS_FWD_WAVES
+#define SLS_FWD_WAVES 4
+#endif
+template <int BW, int BH, bool DBG, bool LEAN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVES, SLS_FWD_WAVES))) void render_fwd_block_kernel(uint64_t *__restrict__ blk_mask,
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
@@ -209,31 +216,42 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
             sh = dppq<kQuadShr1>(I); E = slot >= 2 ? sh : E; I = E * f;
             sh = dppq<kQuadShr1>(I); E = slot >= 3 ? sh : E; I = E * f;
             const bool term = live && (I < SLS_T_MIN);
-            const uint32_t nib = (uint32_t)(__ballot(term) >> (lane & 60)) & 15u;   // terminating slots of my pixel
-            const bool first_term = term && !(nib & below);
-            const bool upd = live && !(nib & upto);
+            const uint64_t tb = __ballot(term);
+            // the transmittance behind the four entries (a finished pixel has f = 1 in every slot: Tr stays)
+            const float I3 = dppq<0xFF>(I);
+            bool upd = live;
+            if (tb) {
+                // some pixel of the block terminates in this step (at most once per pixel): cut its quad at the
+                // first terminating slot
+                const uint32_t nib = (uint32_t)(tb >> (lane & 60)) & 15u;   // terminating slots of my pixel
+                const bool first_term = term && !(nib & below);
+                upd = live && !(nib & upto);
+                cons = first_term ? contributor : cons;
+                const float Tt = quad_sum(first_term ? E : 0.0f);          // in front of the first terminating slot
+                Tr = nib ? Tt : I3;
+                done = done || (nib != 0u);
+            } else {
+                Tr = I3;
+            }
             if (blk_mask && upd) s_flag[j] = 1u;   // (same value from every lane: plain LDS store)
             const float w = upd ? e.alpha * E : 0.0f;
             const float dep = upd ? e.depth : 1.0f;
-            const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
-            const float mw = m * w, mmw = m * mw;
-            // Distortion: sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) over the exclusive prefixes is the
-            // pairwise form sum_{j<i} w_i w_j (m_i - m_j)^2 = A * M2 - M1^2 of the TOTALS (A = sum w = 1 - T):
-            // only the two moments are accumulated (per lane), no prefix over the slots, no running term.
-            M1 += mw;
-            M2 += mmw;
             D += dep * w;
             N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
-            const bool is_med = upd && (E > 0.5f);
-            med = is_med ? dep : med;
-            medc = is_med ? contributor : medc;
             last = upd ? contributor : last;
-            cons = first_term ? contributor : cons;
-            // new transmittance: in front of the first terminating slot, else behind slot 3
-            const float cand = first_term ? E : ((slot == 3 && nib == 0u) ? I : 0.0f);
-            Tr = quad_sum(cand);
-            done = done || (nib != 0u);
-            if (__all(done)) { wave_done = true; break; }
+            if (!LEAN) {
+                // Distortion: sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) over the exclusive prefixes is the
+                // pairwise form sum_{j<i} w_i w_j (m_i - m_j)^2 = A * M2 - M1^2 of the TOTALS (A = sum w = 1 - T):
+                // only the two moments are accumulated (per lane), no prefix over the slots, no running term.
+                const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
+                const float mw = m * w;
+                M1 += mw;
+                M2 += m * mw;
+                const bool is_med = upd && (E > 0.5f);
+                med = is_med ? dep : med;
+                medc = is_med ? contributor : medc;
+            }
+            if (tb && __all(done)) { wave_done = true; break; }
         }
         if (blk_mask) {
             __builtin_amdgcn_wave_barrier();
@@ -288,13 +306,22 @@ __global__ __launch_bounds__(64) void render_fwd_block_kernel(uint64_t *__restri
 // FUSED (sls_mapping_step, LEAN only): dL/dallmap is not read but computed per pixel from the consumer's
 // kernel-B planes (sls_consumer_dev.hpp) — consumer kernel C is not launched; block 0 also turns kernel B's
 // per-block loss partials into the iteration's loss sums.
-template <int BW, int BH, bool LEAN, bool FUSED>
+// DET (deterministic accumulation, SlsMappingConfig.deterministic / sls_backward_det): float atomics add in an
+// order that changes from run to run, so the last bits of the gradients do too.  Integer atomics commute:
+//   DET = 1: first launch — per (surfel, field) the LARGEST |contribution| (atomicMax on the float's bit
+//            pattern, order-independent), into det_max;
+//   DET = 2: second launch — every contribution is scaled by 2^(40 - exponent of that maximum), rounded to an
+//            integer (a pure function of the contribution) and added with a 64-bit integer atomic into det_acc:
+//            40 bits below the largest term, 22 bits of headroom for the sum.  preprocess_bwd scales back.
+// Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
+template <int BW, int BH, bool LEAN, bool FUSED, int DET>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
-    uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks)
+    uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
+    uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc)
 {
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
     if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
@@ -454,7 +481,15 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
                 const float tot = block_reduce16(gl, lane);     // field p of the surfel in my slot
                 const uint32_t gidx = s_gidx[j];
-                if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + p], tot);
+                if (DET == 0) {
+                    if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + p], tot);
+                } else if (DET == 1) {
+                    if (valid && tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + p], __float_as_uint(fabsf(tot)));
+                } else if (valid && tot != 0.0f) {
+                    const int ex = (int)((det_max[(size_t)gidx * kGrec + p] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
+                    const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^41
+                    atomicAdd(&det_acc[(size_t)gidx * kGrec + p], (unsigned long long)q);
+                }
             }
         }
     }
@@ -465,19 +500,20 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st)
+                            hipStream_t st, bool lean)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
     uint32_t *const g_dbg_fwd_cycles = debug_state().dbg_fwd_cycles;
     SLS_REQUIRE(shape == 0 || shape == 1, "tile-kernel variant must be 2 (4x4 blocks) or 3 (8x2 blocks)");
-#define SLS_FWD_BLOCK(BW_, BH_, DBG_)                                                                             \
-    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_>), grid, block, 0, st, block_masks, cam,          \
+#define SLS_FWD_BLOCK(BW_, BH_, DBG_, LEAN_)                                                                      \
+    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_, LEAN_>), grid, block, 0, st, block_masks, cam,   \
                        (const uint2 *)ranges, vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
                        (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles)
-    if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true); else SLS_FWD_BLOCK(4, 4, true); }
-    else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false); else SLS_FWD_BLOCK(4, 4, false); }
+    if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true, false); else SLS_FWD_BLOCK(4, 4, true, false); }
+    else if (lean) { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, true); else SLS_FWD_BLOCK(4, 4, false, true); }
+    else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, false); else SLS_FWD_BLOCK(4, 4, false, false); }
 #undef SLS_FWD_BLOCK
     SLS_LAUNCH_CHECK("render_fwd_block_kernel");
     return SLS_OK;
@@ -487,7 +523,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
-                            const ConsumerArgs *fused_consumer)
+                            const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -501,16 +537,23 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
         ca = *fused_consumer;
         cblocks = ((ca.W + 63) / 64) * ((ca.H + 3) / 4);
     }
-#define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_)                                                                       \
-    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
+#define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
+    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks)
-    if (fused_consumer) {
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc)
+    if (det_max) {
+        // deterministic accumulation: two launches of the 8x2 kernel (maximum, then fixed-point sum)
+        SLS_REQUIRE(det_acc && shape == 1, "deterministic accumulation exists for the 8x2 kernel");
+        if (fused_consumer) { SLS_REQUIRE(lean, "the fused consumer gradient exists for the lean kernel only");
+                              SLS_BWD_BLOCK(8, 2, true, true, 1); SLS_BWD_BLOCK(8, 2, true, true, 2); }
+        else if (lean) { SLS_BWD_BLOCK(8, 2, true, false, 1); SLS_BWD_BLOCK(8, 2, true, false, 2); }
+        else { SLS_BWD_BLOCK(8, 2, false, false, 1); SLS_BWD_BLOCK(8, 2, false, false, 2); }
+    } else if (fused_consumer) {
         SLS_REQUIRE(lean && shape == 1, "the fused consumer gradient exists for the lean 8x2 kernel only");
-        SLS_BWD_BLOCK(8, 2, true, true);
-    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, false); else SLS_BWD_BLOCK(4, 4, true, false); }
-    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, false); else SLS_BWD_BLOCK(4, 4, false, false); }
+        SLS_BWD_BLOCK(8, 2, true, true, 0);
+    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, false, 0); else SLS_BWD_BLOCK(4, 4, true, false, 0); }
+    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, false, 0); else SLS_BWD_BLOCK(4, 4, false, false, 0); }
 #undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");
     return SLS_OK;

@@ -34,7 +34,7 @@ __device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, co
     e.use3d = valid3d && (rho3 <= rho2);
     const float rho = e.use3d ? rho3 : rho2;
     e.depth = e.use3d ? e.t : q1.w;
-    e.G = __expf(-0.5f * rho);
+    e.G = __builtin_amdgcn_exp2f(rho * -0.72134752044448170f);   // exp(-rho / 2) = 2^(-rho log2(e) / 2)
     e.og = q2.w * e.G;
     e.alpha = fminf(SLS_ALPHA_MAX, e.og);
     e.skip = (e.depth < near_c) || (e.alpha < SLS_ALPHA_MIN);
@@ -67,6 +67,10 @@ __device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy,
 // count, nothing missed).  The 2D (low-pass) branch reaches sqrt(kc^2/2) pixels from the centre:
 // tested as the distance from the centre to the block's pixel box.
 // Everything is multiplied through by |(a,b)| so that no division is needed.
+__device__ __forceinline__ float uniform_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 struct BlockCone {
     float d0[3], Dx[3], Dy[3], eps;
 };
@@ -82,6 +86,11 @@ __device__ __forceinline__ BlockCone make_block_cone(const DevCam &cam, float pc
     c.Dy[0] = -ky * ca * se; c.Dy[1] = -ky * sa * se; c.Dy[2] = ky * ce;
     const float span = fabsf(kx) + fabsf(ky);
     c.eps = 0.5f * span * span * 1.01f + 4.0e-6f;     // second-order remainder + float32 slop of d0 / Dx / Dy
+    // wave-uniform by construction (one block per wave), but sincosf leaves them in vector registers:
+    // move them to scalar registers (10 VGPRs less in the tile kernel)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c.d0[k] = uniform_f(c.d0[k]); c.Dx[k] = uniform_f(c.Dx[k]); c.Dy[k] = uniform_f(c.Dy[k]); }
+    c.eps = uniform_f(c.eps);
     return c;
 }
 // true: the 3D footprint cannot reach any pixel of the block.

@@ -134,6 +134,8 @@ class MappingEngine:
         # keyframe-parallel exchange (set up at the first sharded step)
         self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
         self._dp = None                   # dict(G, rank, C, flat, gshard) once the reduce-scatter layout is in place
+        from .rasterizer import deterministic_mode
+        self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
         self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
@@ -173,6 +175,7 @@ class MappingEngine:
         c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
         if self._dp is not None and not apply_adam:
             c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
+        c.deterministic = 1 if self.deterministic else 0
         return c
 
     def _order_entry(self, camera):
@@ -525,6 +528,9 @@ class MappingEngine:
         self._params()
 
     def allmap(self, H, W) -> torch.Tensor:
-        """Copy of the last iteration's allmap (7,H,W) out of the workspace."""
+        """Copy of the last iteration's allmap (7,H,W) out of the workspace.  With depth_ratio == 0 the mapper's
+        loss neither reads nor differentiates the median / distortion planes (gaussian_renderer/__init__.py:79-86),
+        and the native iteration does not track them: planes 5 and 6 are zeros then (render() through
+        GaussianRasterizer always fills all seven)."""
         off = int(self.allmap_ptr.value) - self.workspace.data_ptr()
         return self.workspace[off:off + 7 * H * W * 4].view(torch.float32).view(7, H, W).clone()

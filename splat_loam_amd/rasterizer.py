@@ -13,6 +13,7 @@ plumbing only.  There is no CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import NamedTuple, Optional
 
@@ -188,18 +189,35 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     return s
 
 
-def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallmap):
+def deterministic_mode() -> bool:
+    """SLS_DETERMINISTIC=1: gradient records are accumulated with integer atomics (bit-identical gradients from
+    run to run, about one extra tile-backward); default: float atomics, whose order changes between runs."""
+    return os.environ.get("SLS_DETERMINISTIC", "0") == "1"
+
+
+def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallmap, deterministic=None):
     lib = _abi.lib()
     dev = means3D.device
     N = state.N
     f32 = torch.float32
     dL = _f32c(dL_dallmap)
-    grec = torch.empty((N, lib.sls_grec_stride()), dtype=f32, device=dev)
     dmeans = torch.empty((N, 3), dtype=f32, device=dev)
     dscales = torch.empty((N, 2), dtype=f32, device=dev)
     drots = torch.empty((N, 4), dtype=f32, device=dev)
     dopac = torch.empty((N, 1), dtype=f32, device=dev)
     ce = state.cam
+    if deterministic_mode() if deterministic is None else deterministic:
+        nbytes = int(lib.sls_backward_det_scratch_bytes(N))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _abi.check(lib.sls_backward_det(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
+                                        rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
+                                        state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
+                                        ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
+                                        dL.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(), drots.data_ptr(),
+                                        dopac.data_ptr(), state.block_masks.data_ptr(), scratch.data_ptr(), nbytes,
+                                        _stream(dev)), "sls_backward_det")
+        return dmeans, dscales, drots, dopac, None
+    grec = torch.empty((N, lib.sls_grec_stride()), dtype=f32, device=dev)
     _abi.check(lib.sls_backward(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
                                 rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
                                 state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
