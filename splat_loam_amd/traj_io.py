@@ -132,3 +132,43 @@ def write_graph(filename, models: Sequence[dict], frames: Sequence[dict]) -> Non
 
 def read_graph(filename) -> dict:
     return yaml.safe_load(open(filename))
+
+
+def rpe_point_distance(estimated: Sequence, reference: Sequence,
+                       percentages=(0.02, 0.03, 0.05, 0.08, 0.13, 0.21, 0.34, 0.55), rel_delta_tol: float = 0.1):
+    """Relative pose error as utils/eval_utils.py:16-64 defines it (there through `evo`): for every fraction of
+    the path length, delta = fraction * min(path lengths); all pose pairs (i, j) whose distance ALONG THE REFERENCE
+    PATH is closest to delta (within rel_delta_tol * delta) — evo's `filter_pairs_by_path(all_pairs=True)`; the
+    error of a pair is the norm of the translation of (Q_i^-1 Q_j)^-1 (P_i^-1 P_j) (`PoseRelation.point_distance`),
+    divided by delta; the result is the mean and the standard deviation over all pairs of all fractions.
+    Poses are 4x4 world_T_sensor, the two lists are already associated index by index."""
+    est = [np.asarray(p, dtype=np.float64) for p in estimated]
+    ref = [np.asarray(p, dtype=np.float64) for p in reference]
+    if len(est) != len(ref) or len(est) < 2:
+        raise ValueError("need two associated trajectories of at least two poses")
+
+    def path(poses):
+        steps = [np.linalg.norm(b[:3, 3] - a[:3, 3]) for a, b in zip(poses[:-1], poses[1:])]
+        return np.concatenate([[0.0], np.cumsum(steps)])
+    dist_ref = path(ref)
+    length = min(dist_ref[-1], path(est)[-1])
+    errors = []
+    for perc in percentages:
+        delta = length * perc
+        if delta <= 0.0:
+            continue
+        tol = rel_delta_tol * delta
+        for i in range(len(ref)):
+            from_here = dist_ref[i:] - dist_ref[i]
+            c = int(np.argmin(np.abs(from_here - delta)))
+            if abs(from_here[c] - delta) > tol:
+                continue
+            j = i + c
+            q = np.linalg.inv(ref[i]) @ ref[j]
+            p_rel = np.linalg.inv(est[i]) @ est[j]
+            e = np.linalg.inv(q) @ p_rel
+            errors.append(np.linalg.norm(e[:3, 3]) / delta)
+    if not errors:
+        raise ValueError("no pose pair matches any of the requested path fractions")
+    errors = np.asarray(errors)
+    return float(errors.mean()), float(errors.std()), int(errors.size)

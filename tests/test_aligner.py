@@ -222,3 +222,26 @@ def test_sequence_tracking_densify_optimize_prune(device, tmp_path):
     assert ply["xyz"].shape == (out["N"], 3)
     g = traj_io.read_graph(tmp_path / "graph.yaml")
     assert len(g["frames"]) == 9 and g["models"][0]["filename"] == "models/0000.ply"
+
+
+@pytest.mark.gpu
+def test_config4_geometry_sequence_with_rpe(device):
+    """BASELINE config 4 at ITS geometry as far as it can run here: a 128x1024 range image (Newer College's
+    OS-128 layout), the local model growing to ~150k surfels (utils/config_utils.py:119), the whole per-frame loop
+    (projector -> tracker against the rendered keyframe -> densify / optimize / prune at every keyframe), and the
+    relative pose error computed the way utils/eval_utils.py:16-64 defines it — against the trajectory that
+    GENERATED the scans.  An RPE against the reference implementation is impossible here: neither its rasterizer
+    / aligner sources nor the Newer College data exist in this environment."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import slam_demo
+    from splat_loam_amd.traj_io import rpe_point_distance
+    out = slam_demo.run_sequence(H=128, W=1024, n_frames=25, kf_every=4, n_iter=60, verbose=False, dev=str(device),
+                                 first_stride=1, el_deg=(-45.0, 45.0))
+    assert [k for k, *_ in out["log"]] == [0, 4, 8, 12, 16, 20, 24]
+    assert 120_000 <= out["N"] <= 200_000, out["N"]
+    mean, std, pairs = rpe_point_distance(out["est"], out["gt"])
+    print(f"\n[config 4 geometry] {out['N']} surfels, 25 frames / 7 keyframes in {out['seconds']:.2f} s, "
+          f"RPE {100 * mean:.2f} % +- {100 * std:.2f} % over {pairs} pairs, final error "
+          f"{100 * out['errs'][-1][0]:.1f} cm; engine {out['stats']}")
+    assert pairs >= 40 and mean < 0.05, (mean, std, pairs)
+    assert max(e[0] for e in out["errs"]) < 0.10

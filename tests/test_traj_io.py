@@ -69,3 +69,26 @@ def test_graph_yaml_schema(tmp_path):
     assert list(g["frames"][0]) == ["id", "timestamp", "model_T_frame", "projmatrix", "model_id"]
     assert np.allclose(g["models"][0]["world_T_model"], poses[0][:3].reshape(-1))
     assert g["frames"][1]["projmatrix"] == [-163.0, -136.8, 512.0, 4.8] and g["models"][0]["frame_ids"] == [0, 1]
+
+
+def test_rpe_point_distance_definition():
+    """utils/eval_utils.py:16-64 (evo RPE, point_distance, meters, all_pairs): identical trajectories -> 0; a
+    constant offset in the world frame -> 0 (relative motion unchanged); a scale error s on the translation ->
+    |s - 1| for every pair."""
+    import math
+    from splat_loam_amd.traj_io import rpe_point_distance
+
+    def pose(k, scale=1.0):
+        a = math.radians(2.0 * k)
+        T = np.eye(4)
+        T[:3, :3] = [[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]]
+        T[:3, 3] = [scale * 0.5 * k, scale * 0.1 * math.sin(0.3 * k), 0.0]
+        return T
+    gt = [pose(k) for k in range(60)]
+    m, s, n = rpe_point_distance(gt, gt)
+    assert m < 1e-12 and s < 1e-12 and n > 100
+    off = np.eye(4); off[:3, 3] = [3.0, -2.0, 1.0]
+    m, _, _ = rpe_point_distance([off @ p for p in gt], gt)
+    assert m < 1e-12
+    m, s, _ = rpe_point_distance([pose(k, 1.03) for k in range(60)], gt)
+    assert abs(m - 0.03) < 2e-3 and s < 2e-3

@@ -115,7 +115,8 @@ def _new_surfels(points_world, normals_world, existing_xyz, smax, dev):
                                       torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
 
 
-def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0", out_dir=None):
+def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0", out_dir=None,
+                 first_stride=2, el_deg=None):
     """Odometry + mapping over a sequence, the reference's per-frame loop with this repository's
     components: every scan is registered against the latest keyframe as the MODEL renders it (tracker); every
     `kf_every`-th frame becomes a keyframe at its ESTIMATED pose: densify where the model is transparent
@@ -123,7 +124,7 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
     prune by opacity (Mapper.prune), engine.remap."""
     dev = torch.device(dev)
     rng = np.random.default_rng(0)
-    K = synth.spherical_K(H, W).astype(np.float64)
+    K = (synth.spherical_K(H, W) if el_deg is None else synth.spherical_K(H, W, el_deg[0], el_deg[1])).astype(np.float64)
     gt = [pose_of([0.25 * k, 0.04 * k, 0.0], yaw_deg=1.2 * k) for k in range(n_frames)]
     cfg = MappingConfig()
     proj = DeviceProjector(H, W, 0.5, 100.0, device=dev)
@@ -139,7 +140,10 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
     def add_keyframe(model, eng, est_pose, depth, normals, valid, points, first):
         cam = Camera(K, depth[None], normals.permute(2, 0, 1), valid[None], est_pose, data_device=str(dev))
         if first:
-            mask = valid.clone(); mask[:, 1::2] = False
+            mask = valid.clone()
+            if first_stride > 1:
+                keep_cols = torch.zeros(mask.shape[1], dtype=torch.bool, device=dev); keep_cols[::first_stride] = True
+                mask &= keep_cols[None, :]
         else:
             with torch.no_grad():
                 alpha = render(cam, model, cfg.depth_ratio)["rend_alpha"][0]
@@ -218,7 +222,7 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
         print("pose error per frame [cm]:", " ".join(f"{e[0] * 100:.1f}" for e in errs))
         print(f"{n_frames} frames, {len(kfs)} keyframes in {dt * 1e3:.0f} ms; final error {errs[-1][0] * 100:.2f} cm / {math.degrees(errs[-1][1]):.3f} deg "
               f"after {np.linalg.norm(gt[-1][:3, 3]):.2f} m; engine stats {eng.stats}")
-    return dict(errs=errs, log=log, N=eng.N)
+    return dict(errs=errs, log=log, N=eng.N, est=est, gt=gt, seconds=dt, stats=dict(eng.stats))
 
 
 if __name__ == "__main__":
