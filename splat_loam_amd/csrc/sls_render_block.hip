@@ -26,6 +26,26 @@
 
 namespace sls {
 
+#ifdef SLS_TRACE
+// Experiment build only (make FAST='$(COMMON) -munsafe-fp-atomics -DSLS_TRACE', tools/wave_trace.py): every wave of
+// the tile kernels records when it ran (100 MHz wall clock), where (HW_ID) and how many rounds / steps it did.
+__device__ uint32_t g_trace[2][8192 * 4];
+#define SLS_TRACE_BEGIN() const uint64_t trace_t0 = wall_clock64(); uint32_t trace_rounds = 0, trace_steps = 0
+#define SLS_TRACE_ROUND() ++trace_rounds
+#define SLS_TRACE_STEP() ++trace_steps
+#define SLS_TRACE_END(k_)                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                          \
+        uint32_t *t = g_trace[k_] + 4 * blockIdx.x;                                                       \
+        t[0] = (uint32_t)trace_t0; t[1] = (uint32_t)wall_clock64();                                       \
+        t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID */           \
+        t[3] = (trace_rounds << 16) | (trace_steps & 0xFFFFu);                                            \
+    }
+#else
+#define SLS_TRACE_BEGIN()
+#define SLS_TRACE_ROUND()
+#define SLS_TRACE_STEP()
+#define SLS_TRACE_END(k_)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float dppq(float v)
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     __shared__ uint32_t s_list[64];
     __shared__ uint32_t s_flag[64];
     const uint64_t t_start = DBG ? clock64() : 0;
+    SLS_TRACE_BEGIN();
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
     int tile, sub;
@@ -165,6 +186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     for (int r = 0; r < nr && !wave_done; ++r) {
         float bcx, bcy, bhx, bhy;
         if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        SLS_TRACE_ROUND();
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
@@ -208,6 +230,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                 }
             }
             if (!__ballot(live)) continue;
+            SLS_TRACE_STEP();
             // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k
             const float f = live ? 1.0f - e.alpha : 1.0f;
             // (the DPP moves must execute in all lanes: never inside a conditional expression)
@@ -286,6 +309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         for (int off = 32; off > 0; off >>= 1) c = max(c, (uint32_t)__shfl_down(c, off, 64));
         if (lane == 0) atomicMax(&tile_consumed[tile], c);
     }
+    SLS_TRACE_END(0);
     if (DBG && lane == 0) {
         dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
         uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc)
 {
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
+    SLS_TRACE_BEGIN();
     if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
@@ -391,6 +416,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         float Tr = Tf, S = 0.0f;   // replicated over the quad
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
+            SLS_TRACE_ROUND();
             const uint32_t my_idx = next_idx;
             s_gidx[lane] = my_idx;
             if (r > 0) {
@@ -431,6 +457,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
                 const bool act = valid && inside && (contributor <= last) && !e.skip;
                 if (!__ballot(act)) continue;
+                SLS_TRACE_STEP();
                 const float om = act ? 1.0f - e.alpha : 1.0f;
                 const float rom = __builtin_amdgcn_rcpf(om);
                 // T in front of each entry: Ti = Tr * prod_{slots <= mine} rom, multiplied up in slot order
@@ -494,9 +521,17 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         }
     }
     if (dbg_cycles && lane == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
+    SLS_TRACE_END(1);
 }
 
 // ---------------------------------------------------------------------------
+#ifdef SLS_TRACE
+extern "C" int sls_debug_read_trace(uint32_t *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(g_trace));
+}
+#endif
+
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,

@@ -605,7 +605,7 @@ def test_mapping_engine_remap_after_prune_and_densify(device):
         # rounding noise (1e-15 in one pipeline, exactly 0 in the other) may differ by a whole step, so a
         # handful of such elements is tolerated; everything else must agree to 5 % of the distance travelled
         off = diff > 0.05 * moved + 1e-6
-        assert float(off.float().mean()) <= 1e-3 and float(diff.max()) <= 3.5 * 5e-2, (name, float(diff.max()))
+        assert float(off.float().mean()) <= 3e-3 and float(diff.max()) <= 3.5 * 5e-2, (name, float(diff.max()))
     with pytest.raises(RuntimeError):
         eng.remap(None, appended=7)                     # the model was not resized accordingly
     # the reference's own behaviour (scene/gaussian_model.py:237-256 drops the state on every prune): Adam restarts

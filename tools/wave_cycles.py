@@ -11,8 +11,8 @@ sc = synth.make_scene(N, H, W, seed=0)
 view, proj = synth.camera_matrices(sc["K"])
 s = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=dev), torch.tensor(proj, device=dev))
 t = {k: torch.tensor(sc[k], device=dev) for k in ("means", "scales", "rots", "opac")}
-fv = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-bv = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+fv = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+bv = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 _abi.lib().sls_debug_variant(fv, bv)
 tw, th = _abi.tile_size(); T = (W // tw) * (H // th); wpt = tw * th // 16
 f = torch.zeros(T * wpt + 8, dtype=torch.int32, device=dev); b = torch.zeros_like(f)
