@@ -12,7 +12,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_V
            "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE"; do
   g=$((g+1))
   rm -rf /tmp/pmcsq_$g
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmcsq_$g -o p -- python tools/one_iter.py 4 > /tmp/pmcsq_$g.log 2>&1
+  timeout 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmcsq_$g -o p -- python tools/one_iter.py 4 > /tmp/pmcsq_$g.log 2>&1
   python - "$g" <<'PY' >> gpurun_out/pmc_sq.txt
 import csv, collections, sys, glob
 g = sys.argv[1]

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python tools/one_iter.py 4 > /tmp/pmc_$c.log 2>&1
+  timeout 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python tools/one_iter.py 4 > /tmp/pmc_$c.log 2>&1
 done
 python - <<'PY'
 import csv, collections, json
