@@ -30,18 +30,20 @@ namespace sls {
 // Experiment build only (make FAST='$(COMMON) -munsafe-fp-atomics -DSLS_TRACE', tools/wave_trace.py): every wave of
 // the tile kernels records when it ran (100 MHz wall clock), where (HW_ID) and how many rounds / steps it did.
 __device__ uint32_t g_trace[2][8192 * 4];
-#define SLS_TRACE_BEGIN() const uint64_t trace_t0 = wall_clock64(); uint32_t trace_rounds = 0, trace_steps = 0
+#define SLS_TRACE_BEGIN() const uint64_t trace_t0 = wall_clock64(); uint32_t trace_rounds = 0, trace_steps = 0, trace_sparse = 0
+#define SLS_TRACE_ACTIVE(m_) { const int na_ = __builtin_popcountll((m_) & 0x1111111111111111ull); trace_sparse += (na_ <= 1 ? 1u : 0u) + (na_ <= 2 ? 1u << 10 : 0u) + (na_ <= 4 ? 1u << 20 : 0u); }
 #define SLS_TRACE_ROUND() ++trace_rounds
 #define SLS_TRACE_STEP() ++trace_steps
 #define SLS_TRACE_END(k_)                                                                                 \
     if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                          \
         uint32_t *t = g_trace[k_] + 4 * blockIdx.x;                                                       \
         t[0] = (uint32_t)trace_t0; t[1] = (uint32_t)wall_clock64();                                       \
-        t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_REG_HW_ID */           \
+        t[2] = (k_) == 0 ? trace_sparse : __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       \
         t[3] = (trace_rounds << 16) | (trace_steps & 0xFFFFu);                                            \
     }
 #else
 #define SLS_TRACE_BEGIN()
+#define SLS_TRACE_ACTIVE(m_)
 #define SLS_TRACE_ROUND()
 #define SLS_TRACE_STEP()
 #define SLS_TRACE_END(k_)
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         float bcx, bcy, bhx, bhy;
         if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
         SLS_TRACE_ROUND();
+        SLS_TRACE_ACTIVE(__ballot(!done));
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()

@@ -26,6 +26,14 @@ tr = np.frombuffer(buf, dtype=np.uint32).reshape(2, 8192, 4).astype(np.int64)
 for k, name in enumerate(("fwd", "bwd")):
     t0, t1, hw, xcc = tr[k, :, 0], tr[k, :, 1], tr[k, :, 2], 0 * tr[k, :, 3]
     rounds, steps = tr[k, :, 3] >> 16, tr[k, :, 3] & 0xFFFF
+    if k == 0:
+        sp1, sp2, sp4 = tr[k, :, 2] & 1023, (tr[k, :, 2] >> 10) & 1023, (tr[k, :, 2] >> 20) & 1023
+        long_ = rounds >= 12
+        print("  forward waves with >= 12 rounds: %d; of their %d rounds, %d have <= 1 active pixel, %d <= 2, %d <= 4; all waves: %d of %d rounds with <= 1, %d <= 2"
+              % (long_.sum(), rounds[long_].sum(), sp1[long_].sum(), sp2[long_].sum(), sp4[long_].sum(), sp1.sum(), rounds.sum(), sp2.sum()))
+        dsorted = np.sort((tr[k, :, 1] - tr[k, :, 0]) * 0.01)[::-1]
+        print("  longest forward waves (us):", np.round(dsorted[:12], 1), " waves > 45 us:", int((dsorted > 45).sum()), " > 38 us:", int((dsorted > 38).sum()))
+        hw = 0 * hw
     base = t0.min()
     s, f = (t0 - base) * 0.01, (t1 - base) * 0.01            # us
     dur = f - s
