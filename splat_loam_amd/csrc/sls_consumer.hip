@@ -22,10 +22,52 @@
 
 namespace sls {
 
-__global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a)
+// Blocks of one XCD (index i = tile slot * 16 + block, tile = ((slot >> 2) * 8 + xcd) * 4 + (slot & 3), the mapping
+// of tile_of_block) in the order of their backward cost, most expensive first: the launch drains when the queue is
+// empty, and it drains for as long as the last-started waves run — they should be the cheap ones.  The order is a
+// permutation whatever the costs are; only speed depends on it.
+__device__ void order_blocks_by_cost(const ConsumerArgs &a, int xcd)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t s_hist[256];
+    const int n_x = a.order_tiles * 2, tid = threadIdx.x;        // T * 16 / 8 blocks per XCD
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n_x; i += 256) {
+        const int ts = i >> 4;
+        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        atomicAdd(&s_hist[255u - min(a.block_cost[tile * 16 + (i & 15)], 255u)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 256 bins (wave 0)
+    if (tid < 64) {
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = s_hist[tid * 4 + k]; sum += v[k]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (tid >= off) inc += t; }
+        uint32_t base = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_hist[tid * 4 + k] = base; base += v[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_x; i += 256) {
+        const int ts = i >> 4;
+        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        const uint32_t bin = 255u - min(a.block_cost[tile * 16 + (i & 15)], 255u);
+        a.block_order[(size_t)xcd * n_x + atomicAdd(&s_hist[bin], 1u)] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a, int consumer_blocks_x, int consumer_blocks)
+{
+    if ((int)blockIdx.x >= consumer_blocks) {          // the passenger workgroups
+        order_blocks_by_cost(a, (int)blockIdx.x - consumer_blocks);
+        return;
+    }
+    const int bx = (int)blockIdx.x % consumer_blocks_x, by = (int)blockIdx.x / consumer_blocks_x;
+    const int c = bx * 64 + (threadIdx.x & 63);
+    const int r = by * 4 + (threadIdx.x >> 6);
     float lg = 0.0f, ln = 0.0f, la = 0.0f;
     if (c < a.W && r < a.H) {
         const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
@@ -87,7 +129,7 @@ __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a)
     __syncthreads();
     if (threadIdx.x < 3) {
         const float v = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
-        a.partials[(blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+        a.partials[blockIdx.x * 3 + threadIdx.x] = v;
     }
 }
 
@@ -136,7 +178,8 @@ size_t consumer_scratch_bytes(int H, int W)
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st, bool sums_zeroed, ConsumerArgs *args_out_skip_c)
+                    hipStream_t st, bool sums_zeroed, ConsumerArgs *args_out_skip_c, int order_tiles,
+                    const uint32_t *block_cost, uint32_t *block_order)
 {
     if (scratch_bytes < consumer_scratch_bytes(H, W)) {
         set_error("consumer scratch too small");
@@ -155,10 +198,14 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
     a.partials = (float *)(a.ns + (size_t)H * W);
     a.sums = sums;
     a.dL_dallmap = dL_dallmap;
+    a.order_tiles = (order_tiles > 0 && order_tiles % 32 == 0 && block_cost && block_order && kTilePix / 16 == 16) ? order_tiles : 0;
+    a.block_cost = block_cost;
+    a.block_order = block_order;
     ScopedTimer tm(T_CONSUMER, st);
     (void)sums_zeroed;   // (the sums are written, not accumulated)
     const dim3 grid((W + 63) / 64, (H + 3) / 4);
-    hipLaunchKernelGGL(consumer_b_kernel, grid, dim3(256), 0, st, a);
+    const int cb = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL(consumer_b_kernel, dim3(cb + (a.order_tiles ? 8 : 0)), dim3(256), 0, st, a, (int)grid.x, cb);
     SLS_LAUNCH_CHECK("consumer_b_kernel");
     if (args_out_skip_c) {          // kernel C's work is done by the backward tile kernel (FUSED)
         *args_out_skip_c = a;

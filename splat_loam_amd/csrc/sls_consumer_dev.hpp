@@ -17,6 +17,11 @@ struct ConsumerArgs {
     float *sums;                   // [geom, normal, alpha, total]
     float *partials;               // scratch: 3 floats per block of kernel B (no same-address atomics)
     float *dL_dallmap;
+    // optional passenger of kernel B's launch (it runs between the two tile kernels): the backward's blocks sorted by
+    // the cost the forward recorded, most expensive first, per XCD — 8 extra workgroups, one counting sort each
+    int order_tiles;               // T (a multiple of 32), 0: off
+    const uint32_t *block_cost;    // T * 16 quantised costs (0..255)
+    uint32_t *block_order;         // out: per XCD, T * 2 block indices (tile slot * 16 + block)
 };
 
 __device__ __forceinline__ float3 surf_point(const ConsumerArgs &a, int r, int c, float &s_out)

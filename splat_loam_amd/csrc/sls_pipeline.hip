@@ -39,18 +39,20 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     uint32_t *total_out = nullptr);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
-                      uint64_t *block_masks = nullptr, bool no_median_dist = false);
+                      uint64_t *block_masks = nullptr, bool no_median_dist = false, uint32_t *block_cost = nullptr);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
                       uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr,
-                      uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr);
+                      uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr,
+                      const uint32_t *block_order = nullptr);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
-                    hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr);
+                    hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr,
+                    int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                 const uint32_t *skip_flag, hipStream_t stream, const float *void_flags = nullptr,
                 uint32_t *status_block = nullptr, uint32_t *status_mirror = nullptr);
@@ -65,6 +67,7 @@ struct MapWs {
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
     float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum; uint8_t *touched;
     uint32_t *det_max; unsigned long long *det_acc; size_t det_bytes;    // deterministic accumulation (zeroed per iteration when used)
+    uint32_t *block_cost, *block_order;                                  // backward blocks: cost from the forward, order (most expensive first)
     size_t total;
 };
 
@@ -107,6 +110,8 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.touched = (uint8_t *)take(n);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
     w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
+    w.block_cost = (uint32_t *)take(T * (kTilePix / 16) * 4);
+    w.block_order = (uint32_t *)take(T * (kTilePix / 16) * 4);
     w.det_max = (uint32_t *)take(n * SLS_GREC_STRIDE * 4);
     w.det_acc = (unsigned long long *)take(n * SLS_GREC_STRIDE * 8);
     w.det_bytes = (size_t)((char *)w.det_acc - (char *)w.det_max) + n * SLS_GREC_STRIDE * 8;
@@ -311,24 +316,31 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
                            nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
-                           cfg->depth_ratio == 0.0f);           // (nor, then, the median / distortion planes: not tracked)
+                           cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
+                           w.block_cost);
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
     // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
     const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
+    // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
+    // passenger workgroups of the consumer's launch): 8x2 kernels, XCD-interleaved tile mapping (T % 32 == 0)
+    const bool order_bwd = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
+                           (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
     ConsumerArgs cargs;
     rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
                          cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
-                         w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr);
+                         w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr,
+                         order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order);
     if (rc) return rc;
     // ---- backward -----------------------------------------------------------------
     uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
     const bool det = cfg->deterministic != 0;
     if (det) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
+    const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                            w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
-                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr);
+                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order);
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;

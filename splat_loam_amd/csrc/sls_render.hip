@@ -12,13 +12,14 @@ namespace sls {
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean);
+                            hipStream_t st, bool lean, uint32_t *block_cost);
 size_t block_mask_bytes(uint64_t cap, int T);
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
-                            const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc);
+                            const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
+                            const uint32_t *block_order);
 // Debug switches are per calling thread (sls_common.hpp: DebugState): the library keeps no process-global
 // mutable state.
 DebugState &debug_state()
@@ -31,25 +32,28 @@ DebugState &debug_state()
 int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                       uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed,
-                      uint64_t *block_masks, bool no_median_dist)
+                      uint64_t *block_masks, bool no_median_dist, uint32_t *block_cost)
 {
     const int T = cam.GX * cam.GY;
     // the block kernels combine their blocks' counters with atomicMax: start from zero
     if (tile_consumed && !consumed_zeroed)
         SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                                   tile_consumed, block_masks, debug_state().fwd_variant - 2, st, no_median_dist);
+                                   tile_consumed, block_masks, debug_state().fwd_variant - 2, st, no_median_dist,
+                                   debug_state().fwd_variant == 3 ? block_cost : nullptr);
 }
 
 int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, const float *pix_state,
                       const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st,
                       const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched,
-                      const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc)
+                      const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
+                      const uint32_t *block_order)
 {
     return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
                                    grec, block_masks, det_max ? 1 : debug_state().bwd_variant - 2, st, no_median_dist_grad,
-                                   touched, fused_consumer, det_max, det_acc);
+                                   touched, fused_consumer, det_max, det_acc,
+                                   (debug_state().bwd_variant == 3 || det_max) ? block_order : nullptr);
 }
 
 }  // namespace sls

@@ -136,13 +136,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
-    uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles)
+    uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles, uint32_t *__restrict__ block_cost)
 {
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     __shared__ float4 s_rec[64 * kRec4];
     __shared__ uint32_t s_list[64];
     __shared__ uint32_t s_flag[64];
+    uint32_t bwd_rounds = 0, bwd_steps = 0;      // what the backward will have to do for this block (from the masks)
     const uint64_t t_start = DBG ? clock64() : 0;
     SLS_TRACE_BEGIN();
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             __builtin_amdgcn_wave_barrier();
             const uint64_t rmask = __ballot(s_flag[lane] != 0u);
             if (lane == 0) blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)] = rmask;
+            if (rmask) { bwd_rounds = (uint32_t)(r + 1); bwd_steps += (uint32_t)(__builtin_popcountll(rmask) + 3) / 4u; }
         }
     }
 
@@ -306,6 +308,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         pix_state[pix] = make_float4(Tr, M1, M2, 0.0f);
         pix_contrib[pix] = make_uint2(last, medc_q);
     }
+    // cost of this block in the backward, for its longest-first launch order: ~1.7 us per round, ~0.49 us per step
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, (7u * bwd_rounds + 2u * bwd_steps) / 4u);
     if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
         uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
 #pragma unroll
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
     uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
-    uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc)
+    uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order)
 {
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
     SLS_TRACE_BEGIN();
@@ -364,7 +368,16 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
     int tile, sub;
-    tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
+    if (block_order) {
+        // the blocks of this XCD, most expensive first (bwd_block_order_kernel): b -> (XCD b % 8, rank b / 8)
+        const int xcd = blockIdx.x % 8;
+        const int i = (int)block_order[xcd * (T * kPerTile / 8) + blockIdx.x / 8];
+        const int ts = i / kPerTile;
+        tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        sub = i % kPerTile;
+    } else {
+        tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
+    }
     const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
     const uint2 range = ranges[tile];
     const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
@@ -538,7 +551,7 @@ extern "C" int sls_debug_read_trace(uint32_t *host)
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean)
+                            hipStream_t st, bool lean, uint32_t *block_cost)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
@@ -548,7 +561,7 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 #define SLS_FWD_BLOCK(BW_, BH_, DBG_, LEAN_)                                                                      \
     hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_, LEAN_>), grid, block, 0, st, block_masks, cam,   \
                        (const uint2 *)ranges, vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
-                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles)
+                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles, block_cost)
     if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true, false); else SLS_FWD_BLOCK(4, 4, true, false); }
     else if (lean) { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, true); else SLS_FWD_BLOCK(4, 4, false, true); }
     else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, false); else SLS_FWD_BLOCK(4, 4, false, false); }
@@ -561,7 +574,8 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const float *col_cs, const float *row_cs, const float *pix_state,
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
-                            const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc)
+                            const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
+                            const uint32_t *block_order)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -579,7 +593,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc)
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order)
     if (det_max) {
         // deterministic accumulation: two launches of the 8x2 kernel (maximum, then fixed-point sum)
         SLS_REQUIRE(det_acc && shape == 1, "deterministic accumulation exists for the 8x2 kernel");
