@@ -436,7 +436,14 @@ class MappingEngine:
             if ev:
                 ev[2].record()
             C, r = d["C"], d["rank"]
-            dist.all_gather_into_tensor(d["flat"], d["flat"][r * C:(r + 1) * C], group=group)
+            mine = d["flat"][r * C:(r + 1) * C]
+            if d.get("ag_in_place", True):
+                try:            # in place: the rank's shard already sits where the collective puts it
+                    dist.all_gather_into_tensor(d["flat"], mine, group=group)
+                except (RuntimeError, ValueError):     # a backend that refuses aliasing input / output
+                    d["ag_in_place"] = False
+            if not d.get("ag_in_place", True):
+                dist.all_gather_into_tensor(d["flat"], mine.clone(), group=group)
             if ev:
                 ev[3].record()
         if ev:
