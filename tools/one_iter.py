@@ -12,6 +12,9 @@ sc = synth.make_scene(N, H, W, seed=0)
 depth, valid = synth.make_targets(H, W, sc)
 cam = Camera(sc["K"], depth, None, valid, None, data_device="cuda:0")
 model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+if os.environ.get("SLS_VARIANT"):      # experiment: sls_debug_variant(fwd, bwd)
+    from splat_loam_amd import _abi
+    _abi.lib().sls_debug_variant(*[int(x) for x in os.environ["SLS_VARIANT"].split(",")])
 eng = MappingEngine(model, MappingConfig())
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     st = eng.step(cam)

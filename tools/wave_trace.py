@@ -14,6 +14,8 @@ sc = synth.make_scene(N, H, W, seed=0)
 depth, valid = synth.make_targets(H, W, sc)
 cam = Camera(sc["K"], depth, None, valid, None, data_device="cuda:0")
 m = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+if os.environ.get("SLS_VARIANT"):
+    _abi.lib().sls_debug_variant(*[int(x) for x in os.environ["SLS_VARIANT"].split(",")])
 e = MappingEngine(m, MappingConfig())
 for _ in range(6):
     e.step(cam)
