@@ -153,18 +153,12 @@ __global__ void selftest_kernel(int *out)
     if (lane_id() != lane) bad |= 8;
     const uint64_t lt = (1ull << lane) - 1ull;
     if ((lane % 3) == 0 && (int)__popcll(bal & lt) != lane / 3) bad |= 16;
-    // 16-way reduce-scatter: x[k] = (lane+1)(k+1)/4 -> component k sums to 520 (k+1)
-    float x[16];
+    // 16-way reduce-scatter of the backward tile kernel: x[k] = (lane+1)(k+1)/4; lane (pixel p, slot s) gets
+    // component p summed over the 16 lanes of slot s
+    v2f x[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = 0.25f * (float)((lane + 1) * (k + 1));
-    const float r16 = wave_reduce16(x, lane);
-    if (r16 != 520.0f * (float)(reduce16_component(lane) + 1)) bad |= 32;
-    // the first lane of every quad must own 16 distinct components
-    uint32_t seen = 0;
-    for (int l = 0; l < 64; l += 4) seen |= 1u << reduce16_component(l);
-    if (seen != 0xFFFFu) bad |= 64;
-    // block variant: lane (pixel p, slot s) gets component p summed over the 16 lanes of slot s
-    const float b16 = block_reduce16(x, lane);
+    for (int k = 0; k < 8; ++k) x[k] = mk2(0.25f * (float)((lane + 1) * (2 * k + 1)), 0.25f * (float)((lane + 1) * (2 * k + 2)));
+    const float b16 = block_reduce16_pk(x, lane);
     if (b16 != (float)(124 + 4 * (lane & 3)) * (float)((lane >> 2) + 1)) bad |= 256;
     if (dpp_xor4((float)lane) != (float)(lane ^ 4)) bad |= 512;
     int xa, xb, ya, yb;

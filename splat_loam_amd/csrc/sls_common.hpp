@@ -124,46 +124,6 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
-// Reduce-scatter of 16 per-lane values over the wave: returns, in EVERY lane l,
-// the wave-wide sum of component reduce16_component(l) = l >> 2.  Each level
-// halves the number of live values by exchanging one half with a partner lane:
-//   lanes l / l^32 and rows r / r^1 with the gfx950 v_permlane32_swap /
-//   v_permlane16_swap (one swap serves two values, no selects), then row_mirror
-//   and row_half_mirror DPP inside a row, then a quad all-reduce.
-// 35 VALU instructions for the whole 16 x 64 reduction.
-__device__ __forceinline__ int reduce16_component(int lane) { return lane >> 2; }
-
-// a <- [a.lo | b.lo], b <- [a.hi | b.hi] (halves of 32 lanes) for four / two register pairs.
-// The leading s_nop covers the VALU-write -> permlane-swap-read hazard (inline asm is opaque
-// to the compiler's hazard recogniser).
-#define SLS_SWAP4(op, a0, b0, a1, b1, a2, b2, a3, b3)                                              \
-    asm volatile("s_nop 1\n\t" op " %0, %1\n\t" op " %2, %3\n\t" op " %4, %5\n\t" op " %6, %7"      \
-                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
-__device__ __forceinline__ float wave_reduce16(const float (&x)[16], int lane)
-{
-    float a[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = x[i];
-    // lanes < 32 keep components 0..7, lanes >= 32 components 8..15
-    SLS_SWAP4("v_permlane32_swap_b32", a[0], a[8], a[1], a[9], a[2], a[10], a[3], a[11]);
-    SLS_SWAP4("v_permlane32_swap_b32", a[4], a[12], a[5], a[13], a[6], a[14], a[7], a[15]);
-    float y[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = a[i] + a[i + 8];
-    // even rows keep y[0..3], odd rows y[4..7]
-    SLS_SWAP4("v_permlane16_swap_b32", y[0], y[4], y[1], y[5], y[2], y[6], y[3], y[7]);
-    float z[4], w[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z[i] = y[i] + y[i + 4];
-    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) w[i] = (s3 ? z[i + 2] : z[i]) + dpp_mov0<0x140, 0xF>(s3 ? z[i] : z[i + 2]);   // row_mirror
-    float v = (s2 ? w[1] : w[0]) + dpp_mov0<0x141, 0xF>(s2 ? w[0] : w[1]);                                    // row_half_mirror
-    v += dpp_mov0<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_mov0<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    return v;
-}
-
 // lane <- lane ^ 4 inside a row (two bank-masked DPP moves).
 __device__ __forceinline__ float dpp_xor4(float v)
 {
@@ -172,23 +132,48 @@ __device__ __forceinline__ float dpp_xor4(float v)
     return __builtin_bit_cast(float, a);
 }
 
-// Block variant (lane = 4 * pixel + slot): reduce-scatter of 16 per-lane values over the 16
-// PIXELS of each slot.  Lane (pixel p, slot s) receives the sum over the 16 lanes of slot s of
-// component p.  Levels: lane^32 and lane^16 with permlane swaps, lane^8 (row_ror:8), lane^4.
-__device__ __forceinline__ float block_reduce16(const float (&x)[16], int lane)
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
+// a <- [a.lo | b.lo], b <- [a.hi | b.hi] (halves of 32 lanes / of 16 lanes in each half): the gfx950
+// v_permlane32_swap / v_permlane16_swap through the compiler's builtins — it can use the halves of a register
+// pair as operands directly and places the hazard no-ops itself (inline asm cost a v_mov per half and fixed
+// s_nops).
+__device__ __forceinline__ void permlane32_swap(float &a, float &b)
+{
+    const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void permlane16_swap(float &a, float &b)
+{
+    const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+
+// Reduce-scatter of 16 per-lane values over the 16 PIXELS of each slot of a pixel block (lane = 4 * pixel +
+// slot): lane (pixel p, slot s) receives the sum over the 16 lanes of slot s of component p.  The values come
+// as 8 adjacent pairs (component 2j, 2j+1 = x[j]).  Each level halves the number of live values by exchanging
+// one half with a partner lane: lane^32 and lane^16 with the swaps (one swap serves two values, no selects; the
+// adds of these two levels are packed: 6 v_pk_add_f32), lane^8 (row_ror:8) and lane^4 with selects + DPP.
+__device__ __forceinline__ float block_reduce16_pk(const v2f (&x)[8], int lane)
 {
     float a[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = x[i];
-    SLS_SWAP4("v_permlane32_swap_b32", a[0], a[8], a[1], a[9], a[2], a[10], a[3], a[11]);
-    SLS_SWAP4("v_permlane32_swap_b32", a[4], a[12], a[5], a[13], a[6], a[14], a[7], a[15]);
-    float y[8];
+    for (int i = 0; i < 8; ++i) { a[2 * i] = x[i].x; a[2 * i + 1] = x[i].y; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = a[i] + a[i + 8];
-    SLS_SWAP4("v_permlane16_swap_b32", y[0], y[4], y[1], y[5], y[2], y[6], y[3], y[7]);
-    float z[4], w[2];
+    for (int i = 0; i < 8; ++i) permlane32_swap(a[i], a[i + 8]);
+    v2f y[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) z[i] = y[i] + y[i + 4];
+    for (int i = 0; i < 4; ++i) y[i] = mk2(a[2 * i], a[2 * i + 1]) + mk2(a[2 * i + 8], a[2 * i + 9]);
+    float b[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[2 * i] = y[i].x; b[2 * i + 1] = y[i].y; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) permlane16_swap(b[i], b[i + 4]);
+    const v2f z01 = mk2(b[0], b[1]) + mk2(b[4], b[5]), z23 = mk2(b[2], b[3]) + mk2(b[6], b[7]);
+    const float z[4] = { z01.x, z01.y, z23.x, z23.y };
+    float w[2];
     const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) w[i] = (s3 ? z[i + 2] : z[i]) + dpp_mov0<0x128, 0xF>(s3 ? z[i] : z[i + 2]);   // row_ror:8

@@ -158,18 +158,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const bool inside = (px < cam.W) && (py < cam.H);
     const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
 
-    float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
+    v2f d01 = mk2(1.0f, 0.0f);
+    float d2 = 0.0f;
     if (inside) {
         const float2 c = col_cs[px], r = row_cs[py];
-        d0 = c.x * r.x; d1 = c.y * r.x; d2 = r.y;
+        d01 = mk2(c.x * r.x, c.y * r.x); d2 = r.y;
     }
-    const float pc = (float)px, pr = (float)py;
+    const v2f pcr = mk2((float)px, (float)py);
     const float mscale = cam.far_c / (cam.far_c - cam.near_c);
     const uint32_t below = (1u << slot) - 1u, upto = (2u << slot) - 1u;   // quad bits of the earlier slots (and self)
 
     // replicated over the quad: Tr, done.  Per-lane partial sums: D, N*, M1, M2.
     float Tr = 1.0f, M1 = 0.0f, M2 = 0.0f;
-    float D = 0.0f, N0 = 0.0f, N1 = 0.0f, N2 = 0.0f, med = 0.0f;
+    float D = 0.0f, N2 = 0.0f, med = 0.0f;
+    v2f N01 = mk2(0.0f, 0.0f);
     uint32_t medc = 0, last = 0, cons = 0;
     bool done = !inside;
     bool wave_done = __all(done);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
             const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
             Eval e;
-            eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
+            eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
             const bool live = valid && !done && !e.skip;
             if (DBG) {
                 const uint64_t lb = __ballot(live);
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             const float w = upd ? e.alpha * E : 0.0f;
             const float dep = upd ? e.depth : 1.0f;
             D += dep * w;
-            N0 += q2.x * w; N1 += q2.y * w; N2 += q2.z * w;
+            N01 += mk2(q2.x, q2.y) * w; N2 += q2.z * w;
             last = upd ? contributor : last;
             if (!LEAN) {
                 // Distortion: sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) over the exclusive prefixes is the
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     }
 
     // combine the four slots of a pixel
-    D = quad_sum(D); N0 = quad_sum(N0); N1 = quad_sum(N1); N2 = quad_sum(N2);
+    D = quad_sum(D); const float N0 = quad_sum(N01.x), N1 = quad_sum(N01.y); N2 = quad_sum(N2);
     M1 = quad_sum(M1); M2 = quad_sum(M2);
     const float dist = (1.0f - Tr) * M2 - M1 * M1;
     last = quad_max(last);
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 // LAST entry of the four.  T_i = T_{i+1} / (1 - alpha_i) is multiplied up in
 // that order inside the quad, S (the suffix sum of w g) is an exclusive quad
 // prefix.  The 16 gradient fields are reduced over the 16 pixels of a slot with
-// block_reduce16 and flushed with one 64-lane global float atomic per step.
+// block_reduce16_pk and flushed with one 64-lane global float atomic per step.
 // ---------------------------------------------------------------------------
 // LEAN: the caller guarantees dL/d(median) = dL/d(distortion) = 0 (the mapper's loss at
 // depth_ratio = 0, gaussian_renderer/__init__.py:79-86): their terms are compiled out.
@@ -384,17 +386,21 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const int px = x0 + (p % BW), py = y0 + (p / BW);
     const bool inside = (px < cam.W) && (py < cam.H);
     const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
-    const float pc = (float)px, pr = (float)py;
+    const v2f pcr = mk2((float)px, (float)py);
     const float mscale = cam.far_c / (cam.far_c - cam.near_c);
     const float k1 = slot >= 1 ? 1.0f : 0.0f, k2 = slot >= 2 ? 1.0f : 0.0f, k3 = slot >= 3 ? 1.0f : 0.0f;
 
-    float d0 = 1.0f, d1 = 0.0f, d2 = 0.0f;
+    v2f d01 = mk2(1.0f, 0.0f), dN01 = mk2(0.0f, 0.0f);
+    float d2 = 0.0f;
     uint32_t last = 0, medc = 0;
     float Tf = 1.0f, M1 = 0.0f, M2 = 0.0f;
-    float dD = 0, dA = 0, dN0 = 0, dN1 = 0, dN2 = 0, dMed = 0, dDist = 0;
+    float dD = 0, dA = 0, dN2 = 0, dMed = 0, dDist = 0;
+    // the 16 gradient fields are reduced in an order that keeps pairs adjacent (below): position p of the
+    // reduction -> field of the gradient record
+    const int field = p < 8 ? (int)((0x73625410u >> (4 * p)) & 15u) : p;
     if (inside) {
         const float2 c = col_cs[px], r = row_cs[py];
-        d0 = c.x * r.x; d1 = c.y * r.x; d2 = r.y;
+        d01 = mk2(c.x * r.x, c.y * r.x); d2 = r.y;
         const size_t P = (size_t)cam.H * cam.W;
         const size_t pix = (size_t)py * cam.W + px;
         const uint2 pcn = pix_contrib[pix];
@@ -404,12 +410,11 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         if (FUSED) {
             float gpix[7];
             consumer_pixel_grad(ca, py, px, gpix);
-            dD = gpix[0]; dA = gpix[1]; dN0 = gpix[2]; dN1 = gpix[3]; dN2 = gpix[4];
+            dD = gpix[0]; dA = gpix[1]; dN01 = mk2(gpix[2], gpix[3]); dN2 = gpix[4];
         } else {
             dD = dL_dallmap[SLS_CH_DEPTH * P + pix];
             dA = dL_dallmap[SLS_CH_ALPHA * P + pix];
-            dN0 = dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix];
-            dN1 = dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix];
+            dN01 = mk2(dL_dallmap[(SLS_CH_NORMAL + 0) * P + pix], dL_dallmap[(SLS_CH_NORMAL + 1) * P + pix]);
             dN2 = dL_dallmap[(SLS_CH_NORMAL + 2) * P + pix];
         }
         if (!LEAN) {
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
                 const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
                 Eval e;
-                eval_surfel(q0, q1, q2, q3, q4, d0, d1, d2, pc, pr, wrapW, invW, cam.near_c, e);
+                eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
                 const bool act = valid && inside && (contributor <= last) && !e.skip;
                 if (!__ballot(act)) continue;
                 SLS_TRACE_STEP();
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                     gdist = dDist * (M2 + m * m * Af - 2.0f * m * M1);
                     ddist = dDist * 2.0f * (m * Af - M1) * dm_dd;
                 }
-                const float gk = dD * dep + (dN0 * q2.x + dN1 * q2.y + dN2 * q2.z) + dA + gdist;
+                const float gk = dD * dep + (dN01.x * q2.x + dN01.y * q2.y + dN2 * q2.z) + dA + gdist;
                 float Se, St;
                 quad_excl_total(w * gk, k1, k2, k3, Se, St);
                 const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
@@ -507,31 +512,32 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
                 const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
                 const bool a3 = act && e.use3d, a2 = act && !e.use3d;
-                const float dL_du = dL_drho * 2.0f * e.u, dL_dv = dL_drho * 2.0f * e.v;
-                const float dL_dhu = a3 ? dL_du * e.rinv : 0.0f, dL_dhv = a3 ? dL_dv * e.rinv : 0.0f;
-                const float dL_drinv = dL_du * e.hu + dL_dv * e.hv + dL_ddepth * q0.w;
+                const v2f dL_duv = (dL_drho * 2.0f) * e.uv;                     // dL/d(u, v)
+                const v2f dL_dhuv0 = dL_duv * e.rinv;
+                const v2f dL_dhuv = mk2(a3 ? dL_dhuv0.x : 0.0f, a3 ? dL_dhuv0.y : 0.0f);   // dL/d(hu, hv)
+                const float dL_drinv = dL_duv.x * e.huv.x + dL_duv.y * e.huv.y + dL_ddepth * q0.w;
                 const float dL_dnd = a3 ? -dL_drinv * e.rinv * e.rinv : 0.0f;
-                float gl[kGrec];
-                gl[0] = dL_dhu * e.dl0; gl[1] = dL_dhu * e.dl1; gl[2] = dL_dhu * e.dl2;
-                gl[3] = a3 ? dL_ddepth * e.rinv : 0.0f;
-                gl[4] = dL_dhv * e.dl0; gl[5] = dL_dhv * e.dl1; gl[6] = dL_dhv * e.dl2;
-                gl[7] = a2 ? dL_ddepth : 0.0f;
-                gl[8] = w * dN0 + dL_dnd * d0; gl[9] = w * dN1 + dL_dnd * d1; gl[10] = w * dN2 + dL_dnd * d2;
-                gl[11] = dL_do;
-                gl[12] = dL_dhu;
-                gl[13] = dL_dhv;
-                gl[14] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dx : 0.0f;
-                gl[15] = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) * e.dy : 0.0f;
-                const float tot = block_reduce16(gl, lane);     // field p of the surfel in my slot
+                const float lp = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) : 0.0f;
+                // fields of the gradient record, in the order `field` names: pairs that one packed instruction makes
+                v2f gl[kGrec / 2];
+                gl[0] = dL_dhuv.x * e.dl01;                                     // fields 0, 1
+                gl[1] = dL_dhuv.y * e.dl01;                                     // fields 4, 5
+                gl[2] = dL_dhuv * e.dl2;                                        // fields 2, 6
+                gl[3] = mk2(a3 ? dL_ddepth * e.rinv : 0.0f, a2 ? dL_ddepth : 0.0f);   // fields 3, 7
+                gl[4] = w * dN01 + dL_dnd * d01;                                // fields 8, 9
+                gl[5] = mk2(w * dN2 + dL_dnd * d2, dL_do);                      // fields 10, 11
+                gl[6] = dL_dhuv;                                                // fields 12, 13
+                gl[7] = lp * e.dxy;                                             // fields 14, 15
+                const float tot = block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
                 const uint32_t gidx = s_gidx[j];
                 if (DET == 0) {
-                    if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + p], tot);
+                    if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
                 } else if (DET == 1) {
-                    if (valid && tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + p], __float_as_uint(fabsf(tot)));
+                    if (valid && tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
                 } else if (valid && tot != 0.0f) {
-                    const int ex = (int)((det_max[(size_t)gidx * kGrec + p] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
+                    const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
                     const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^41
-                    atomicAdd(&det_acc[(size_t)gidx * kGrec + p], (unsigned long long)q);
+                    atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
                 }
             }
         }

@@ -6,31 +6,37 @@
 
 namespace sls {
 
+// Pairs of values that are produced and consumed together live in 2-vectors (v2f, sls_common.hpp): their
+// arithmetic becomes packed FP32 instructions (v_pk_add/mul/fma_f32) without any packing moves, because the pairs
+// are adjacent from where they are made ((x, y) halves of a ds_read_b128, (d0, d1) of the pixel's ray, (hu, hv),
+// (dx, dy)).  Measured on gfx950 (tools/micro/pk_rate.hip): a packed op occupies the issue port 1.7x as long as
+// a scalar one, so a pair is worth 15 % of two scalar ops — and nothing once a v_mov is needed to form it, which
+// is why the auto-vectoriser is off for the tile kernels (-fno-slp-vectorize: it paired values that were NOT
+// adjacent and paid more moves than it saved: 167 -> 160 VALU instructions per backward step without it).
 struct Eval {
-    float dl0, dl1, dl2, rinv, hu, hv, u, v, t, dx, dy, depth, G, og, alpha;
+    v2f dl01, huv, uv, dxy;       // (dl0, dl1), (hu, hv), (u, v), (dx, dy)
+    float dl2, rinv, t, depth, G, og, alpha;
     bool use3d, skip;
 };
 
-// One (pixel, surfel) evaluation; identical in forward and backward.
+// One (pixel, surfel) evaluation; identical in forward and backward.  d01 = (d0, d1) of the pixel's ray,
+// pcr = (column, row) of the pixel.
 __device__ __forceinline__ void eval_surfel(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
-                                            const float4 q4, float d0, float d1, float d2, float pc, float pr,
+                                            const float4 q4, v2f d01, float d2, v2f pcr,
                                             float wrapW, float invW, float near_c, Eval &e)
 {
-    e.dl0 = d0 - q3.x; e.dl1 = d1 - q3.y; e.dl2 = d2 - q3.z;
-    const float nd = q2.x * d0 + q2.y * d1 + q2.z * d2;
+    e.dl01 = d01 - mk2(q3.x, q3.y); e.dl2 = d2 - q3.z;
+    const float nd = q2.x * d01.x + q2.y * d01.y + q2.z * d2;
     const bool valid3d = nd < 0.0f;
     e.rinv = __builtin_amdgcn_rcpf(nd);
-    e.hu = q0.x * e.dl0 + q0.y * e.dl1 + q0.z * e.dl2;
-    e.hv = q1.x * e.dl0 + q1.y * e.dl1 + q1.z * e.dl2;
-    e.u = e.hu * e.rinv;
-    e.v = e.hv * e.rinv;
+    e.huv = mk2(q0.x * e.dl01.x + q0.y * e.dl01.y + q0.z * e.dl2, q1.x * e.dl01.x + q1.y * e.dl01.y + q1.z * e.dl2);
+    e.uv = e.huv * e.rinv;
     e.t = q0.w * e.rinv;
-    const float rho3 = e.u * e.u + e.v * e.v;
+    const float rho3 = e.uv.x * e.uv.x + e.uv.y * e.uv.y;
     // D5 wrapped azimuth difference, branch-free: wrapW = W (360-degree image) or 0
-    const float dx0 = pc - q4.x;
-    e.dx = dx0 - wrapW * __builtin_rintf(dx0 * invW);
-    e.dy = pr - q4.y;
-    const float rho2 = SLS_FILTER_INV_SQUARE * (e.dx * e.dx + e.dy * e.dy);
+    e.dxy = pcr - mk2(q4.x, q4.y);
+    e.dxy.x = e.dxy.x - wrapW * __builtin_rintf(e.dxy.x * invW);
+    const float rho2 = SLS_FILTER_INV_SQUARE * (e.dxy.x * e.dxy.x + e.dxy.y * e.dxy.y);
     e.use3d = valid3d && (rho3 <= rho2);
     const float rho = e.use3d ? rho3 : rho2;
     e.depth = e.use3d ? e.t : q1.w;
