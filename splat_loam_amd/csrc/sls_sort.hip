@@ -378,79 +378,120 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
 constexpr int kResortWindow = 1024;
 constexpr uint32_t kResortFailed = 2u;            // bit in SlsMappingStatus.overflow
 
-// Stages of the bitonic network on s_a[0..kResortWindow), from width K0 up to the full window.
-//   * partner distances j >= 4 go through LDS; wave w owns the pairs of the slice
-//     [w * W/4, (w+1) * W/4) whenever j fits in it (j <= W/8): those stages need no workgroup
-//     barrier (one wave, LDS in program order), only the stages with j >= W/4 exchange between slices;
-//   * the last two stages of every width (j = 2, 1) run in registers on the 4 consecutive
-//     elements a thread owns (two 128-bit LDS accesses instead of two bank-conflicting stages).
-// Branch-free compare-exchange throughout.
-__device__ __forceinline__ void cx64(uint64_t &a, uint64_t &b, bool desc)
-{
-    const bool sw = (a > b) != desc;
-    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
-    a = lo; b = hi;
-}
-// The network is latency bound (a few LDS round trips per stage, 46 dependent stages), so a
-// window gets kResortThreads = 512 threads (two elements, one pair each): twice the waves per
-// SIMD of a 256-thread block hide each other's LDS latency.
+// The bitonic network of a window, from width K0 up to the full window, on elements held in REGISTERS:
+// thread t of the 512 owns elements 2t and 2t+1 of the window.
+//   * partner distance 1: inside the thread;
+//   * distances 2 .. 64 (thread ^ 1 .. 32): inside the wave — DPP (quad_perm, row_shl/shr:4, row_ror:8) for
+//     thread distances 1, 2, 4, 8, ds_bpermute for 16 and 32: no LDS storage, no barrier;
+//   * distances 128, 256, 512 (thread ^ 64, 128, 256): the only stages that go through LDS (one 128-bit write and
+//     one 128-bit read of the partner thread's pair, two workgroup barriers): 6 of the 55 stages of a sort, 3 of
+//     the 10 of a merge.
+// (The same network with every stage of distance >= 2 in LDS — 45 round trips with bank conflicts on the 64-bit
+//  elements — took 16.5 + 7.8 us per repair on C1 against what this one takes)
+// Branch-free compare-exchange throughout; all elements are distinct (the surfel index is part of the key).
 constexpr int kResortThreads = 512;
-constexpr int kResortE = kResortWindow / kResortThreads;   // consecutive elements a thread owns (2)
-template <int K0>
-__device__ __forceinline__ void bitonic_lds(uint64_t *s_a)
+static_assert(kResortWindow == 2 * kResortThreads, "one pair of elements per thread");
+
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
 {
-    static_assert(kResortE == 2, "one pair per thread");
-    constexpr int kWaves = kResortThreads / 64, kSlice = kResortWindow / kWaves;   // elements per wave slice
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pidx = wave * (kSlice / 2) + lane;
-    for (int k = K0; k <= kResortWindow; k <<= 1) {
-        for (int j = k >> 1; j >= 2; j >>= 1) {
-            const bool cross = j >= kSlice;
-            if (cross) __syncthreads();
-            const int i = 2 * pidx - (pidx & (j - 1));
-            uint64_t a = s_a[i], b = s_a[i + j];
-            cx64(a, b, (i & k) != 0 && k != kResortWindow);
-            s_a[i] = a;
-            s_a[i + j] = b;
-            if (cross) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        }
-        // j = 1 on the two consecutive elements the thread owns (one 128-bit access each way)
-        ulonglong2 *v = reinterpret_cast<ulonglong2 *>(s_a) + threadIdx.x;
-        const ulonglong2 pv = v[0];
-        uint64_t e0 = pv.x, e1 = pv.y;
-        cx64(e0, e1, ((2 * (int)threadIdx.x) & k) != 0 && k != kResortWindow);
-        v[0] = make_ulonglong2(e0, e1);
-        __builtin_amdgcn_wave_barrier();
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane distance inside a wave");
+    if (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    if (M == 4) {
+        int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);                    // row_shl:4 -> banks 0, 2
+        a = __builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);                        // row_shr:4 -> banks 1, 3
+        return (uint32_t)a;
     }
-    __syncthreads();
+    if (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    return (uint32_t)__shfl_xor((int)v, M, 64);                                                    // ds_bpermute_b32
+}
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v)
+{
+    return ((uint64_t)lane_xor_u32<M>((uint32_t)(v >> 32)) << 32) | lane_xor_u32<M>((uint32_t)v);
+}
+// e <- min(e, p) if keep_min else max(e, p)
+__device__ __forceinline__ void keep64(uint64_t &e, uint64_t p, bool keep_min)
+{
+    e = ((p < e) == keep_min) ? p : e;
+}
+// one stage with the partner thread at distance M (element distance 2M) of the width-k step
+template <int M>
+__device__ __forceinline__ void bitonic_stage(uint64_t &e0, uint64_t &e1, bool asc, ulonglong2 *s_pairs)
+{
+    const int t = threadIdx.x;
+    const bool keep_min = ((t & M) == 0) == asc;
+    uint64_t p0, p1;
+    if constexpr (M >= 64) {
+        s_pairs[t] = make_ulonglong2(e0, e1);
+        __syncthreads();
+        const ulonglong2 pp = s_pairs[t ^ M];
+        p0 = pp.x; p1 = pp.y;
+        __syncthreads();
+    } else {
+        p0 = lane_xor_u64<M>(e0); p1 = lane_xor_u64<M>(e1);
+    }
+    keep64(e0, p0, keep_min);
+    keep64(e1, p1, keep_min);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_width(uint64_t &e0, uint64_t &e1, ulonglong2 *s_pairs)
+{
+    // direction of the width-K blocks (the last width sorts ascending throughout)
+    const bool asc = (K == kResortWindow) || ((2 * (int)threadIdx.x) & K) == 0;
+    if constexpr (K >= 1024) bitonic_stage<256>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 512) bitonic_stage<128>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 256) bitonic_stage<64>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 128) bitonic_stage<32>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 64) bitonic_stage<16>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 32) bitonic_stage<8>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 16) bitonic_stage<4>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 8) bitonic_stage<2>(e0, e1, asc, s_pairs);
+    if constexpr (K >= 4) bitonic_stage<1>(e0, e1, asc, s_pairs);
+    // distance 1: the two elements of the thread
+    const bool sw = (e0 > e1) == asc;
+    const uint64_t lo = sw ? e1 : e0, hi = sw ? e0 : e1;
+    e0 = lo; e1 = hi;
+}
+// full sort (K0 = 2) or merge of a bitonic window (K0 = kResortWindow)
+template <int K0>
+__device__ __forceinline__ void bitonic_pairs(uint64_t &e0, uint64_t &e1, ulonglong2 *s_pairs)
+{
+    if constexpr (K0 <= 2) bitonic_width<2>(e0, e1, s_pairs);
+    if constexpr (K0 <= 4) bitonic_width<4>(e0, e1, s_pairs);
+    if constexpr (K0 <= 8) bitonic_width<8>(e0, e1, s_pairs);
+    if constexpr (K0 <= 16) bitonic_width<16>(e0, e1, s_pairs);
+    if constexpr (K0 <= 32) bitonic_width<32>(e0, e1, s_pairs);
+    if constexpr (K0 <= 64) bitonic_width<64>(e0, e1, s_pairs);
+    if constexpr (K0 <= 128) bitonic_width<128>(e0, e1, s_pairs);
+    if constexpr (K0 <= 256) bitonic_width<256>(e0, e1, s_pairs);
+    if constexpr (K0 <= 512) bitonic_width<512>(e0, e1, s_pairs);
+    bitonic_width<1024>(e0, e1, s_pairs);
+}
+// window position of element q (0, 1) of thread t when the window is loaded as a bitonic sequence: the second
+// half back to front (ascending + descending)
+__device__ __forceinline__ int bitonic_src(int o)
+{
+    return o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
 }
 
 __global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, const uint32_t *__restrict__ prev_order,
                                                                      const uint32_t *__restrict__ keys_by_surfel,
                                                                      uint64_t *__restrict__ comp)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
-    const int base = blockIdx.x * kResortWindow;
+    __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
+    const int pos0 = blockIdx.x * kResortWindow + 2 * (int)threadIdx.x;
     // (unconditional loads at clamped addresses, all of a level before the next: two dependent round trips
     //  instead of one branch + full wait per element)
-    uint32_t gq[kResortE], kq[kResortE];
-#pragma unroll
-    for (int q = 0; q < kResortE; ++q)
-        gq[q] = min(prev_order[min(base + q * kResortThreads + (int)threadIdx.x, N - 1)], (uint32_t)(N - 1));   // (memory-safe whatever the caller kept)
-#pragma unroll
-    for (int q = 0; q < kResortE; ++q) kq[q] = keys_by_surfel[gq[q]];
-#pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
-        s_a[o] = pos < N ? (((uint64_t)kq[q] << 32) | gq[q]) : ~0ull;      // padding behind the end sorts last
-    }
-    __syncthreads();
-    bitonic_lds<2>(s_a);
-#pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
-        if (pos < N) comp[pos] = s_a[o];
-    }
+    const uint32_t g0 = min(prev_order[min(pos0, N - 1)], (uint32_t)(N - 1));        // (memory-safe whatever the caller kept)
+    const uint32_t g1 = min(prev_order[min(pos0 + 1, N - 1)], (uint32_t)(N - 1));
+    const uint32_t k0 = keys_by_surfel[g0], k1 = keys_by_surfel[g1];
+    uint64_t e0 = pos0 < N ? (((uint64_t)k0 << 32) | g0) : ~0ull;                    // padding behind the end sorts last
+    uint64_t e1 = pos0 + 1 < N ? (((uint64_t)k1 << 32) | g1) : ~0ull;
+    bitonic_pairs<2>(e0, e1, s_pairs);
+    if (pos0 < N) comp[pos0] = e0;
+    if (pos0 + 1 < N) comp[pos0 + 1] = e1;
 }
 
 // Second repair round, first half (reuse_depth_order = 2): after one round the array is sorted inside every
@@ -460,28 +501,19 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_aligned_kernel(in
                                                                               const uint32_t *__restrict__ keys_by_surfel,
                                                                               uint64_t *__restrict__ comp)
 {
-    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
-    const int base = blockIdx.x * kResortWindow;
+    __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
+    const int base = blockIdx.x * kResortWindow, o0 = 2 * (int)threadIdx.x;
+    uint64_t e[2];
 #pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x;
-        // the second half is loaded back to front: ascending + descending = bitonic
-        const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
-        const int pos = base + src;
-        uint64_t c = ~0ull;                        // padding behind the end sorts last
-        if (pos < N) {
-            const uint32_t g = order[pos];
-            c = ((uint64_t)keys_by_surfel[g] << 32) | g;
-        }
-        s_a[o] = c;
+    for (int q = 0; q < 2; ++q) {
+        const int pos = base + bitonic_src(o0 + q);
+        const uint32_t g = order[min(pos, N - 1)];
+        const uint32_t k = keys_by_surfel[g];
+        e[q] = pos < N ? (((uint64_t)k << 32) | g) : ~0ull;       // padding behind the end sorts last
     }
-    __syncthreads();
-    bitonic_lds<kResortWindow>(s_a);
-#pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
-        if (pos < N) comp[pos] = s_a[o];
-    }
+    bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
+    if (base + o0 < N) comp[base + o0] = e[0];
+    if (base + o0 + 1 < N) comp[base + o0 + 1] = e[1];
 }
 
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
@@ -493,43 +525,43 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
                                                                       const uint32_t *__restrict__ tiles,
                                                                       uint32_t *__restrict__ block_sums)
 {
-    static_assert(kResortWindow == 1024 && kResortThreads == 512, "two 256-blocks of positions per pass of the store loop");
-    __shared__ __attribute__((aligned(16))) uint64_t s_a[kResortWindow];
-    __shared__ uint32_t s_part[4][4];          // [256-block of the window][wave inside it]
-    const int base = blockIdx.x * kResortWindow - kResortWindow / 2;
+    static_assert(kResortWindow == 1024 && kResortThreads == 512, "a 256-block of positions = two waves of pairs");
+    __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
+    __shared__ uint32_t s_part[4][2];          // [256-block of the window][wave inside it]
+    const int base = blockIdx.x * kResortWindow - kResortWindow / 2, o0 = 2 * (int)threadIdx.x;
+    uint64_t e[2];
 #pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x;
-        // the second half is loaded back to front: ascending + descending = bitonic
-        const int src = o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
-        const int pos = base + src;
+    for (int q = 0; q < 2; ++q) {
+        const int pos = base + bitonic_src(o0 + q);
         const uint64_t c = comp[min(max(pos, 0), N - 1)];
-        s_a[o] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
+        e[q] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
     }
-    __syncthreads();
-    bitonic_lds<kResortWindow>(s_a);
+    bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
+    uint32_t v = 0;
 #pragma unroll
-    for (int q = 0; q < kResortE; ++q) {
-        const int o = q * kResortThreads + threadIdx.x, pos = base + o;
+    for (int q = 0; q < 2; ++q) {
+        const int pos = base + o0 + q;
         const bool real = pos >= 0 && pos < N;
-        const uint32_t g = real ? (uint32_t)s_a[o] : 0u;
-        uint32_t v = tiles[g];                    // (surfel 0 for the padding: a valid address, masked below)
-        v = real ? v : 0u;
+        const uint32_t g = real ? (uint32_t)e[q] : 0u;
+        const uint32_t tv = tiles[g];                 // (surfel 0 for the padding: a valid address, masked below)
+        v += real ? tv : 0u;
         if (real) order[pos] = g;
+    }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) s_part[o >> 8][(o >> 6) & 3] = v;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 7][(threadIdx.x >> 6) & 1] = v;
+    // smallest / largest real element of the window (it holds at least one)
+    const int lo = base < 0 ? -base : 0, hi = min(kResortWindow, N - base) - 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (o0 + q == lo) edges[2 * blockIdx.x + 0] = e[q];
+        if (o0 + q == hi) edges[2 * blockIdx.x + 1] = e[q];
     }
     __syncthreads();
     if (threadIdx.x < 4) {
         const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
         if (base + (int)threadIdx.x * 256 >= 0 && blk * 256 < N)
-            block_sums[blk] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1] + s_part[threadIdx.x][2] + s_part[threadIdx.x][3];
-    }
-    if (threadIdx.x == 0) {   // smallest / largest real element of the window (it holds at least one)
-        const int lo = base < 0 ? -base : 0, hi = min(kResortWindow, N - base) - 1;
-        edges[2 * blockIdx.x + 0] = s_a[lo];
-        edges[2 * blockIdx.x + 1] = s_a[hi];
+            block_sums[blk] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1];
     }
 }
 
