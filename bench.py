@@ -162,6 +162,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there (gloo's connection banner,
+    # RCCL warnings) goes to stderr — file descriptor 1 is pointed at 2, the line is written to a saved duplicate
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -440,7 +445,7 @@ def main():
         "comm": comm,
         "roofline": roofline, "cpu_baseline": cpu, "extras": extras, "kernels": breakdown,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), file=result_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
