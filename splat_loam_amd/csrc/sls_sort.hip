@@ -27,13 +27,15 @@
 
 namespace sls {
 
-// (build-time knobs for A/B runs; measured on the bench scene: 8 rounds per wave = twice the waves does not
-//  speed the scatter up and costs the row scan 4 us; 4 waves per block = the old stray-word table access)
+// (build-time knobs for A/B runs; measured on the bench scene, A/B inside one box, iteration time with
+//  rounds x waves per block = 16x16: 0.2652 ms, 16x8: 0.2613 (scatter 18.6 -> 15.8 us: twice the workgroups for
+//  the 1260 wave chunks of the tile sort), 16x4: 0.266 (the stray-word table access), 24x8: 0.2618, 32x8: 0.264,
+//  8x16: 0.268 and 8x8: 0.269 (row scan +4 us), 4x16: 0.280)
 #ifndef SLS_SORT_ROUNDS
 #define SLS_SORT_ROUNDS 16
 #endif
 #ifndef SLS_SORT_WAVES
-#define SLS_SORT_WAVES 16
+#define SLS_SORT_WAVES 8
 #endif
 constexpr int kSortRounds = SLS_SORT_ROUNDS;
 constexpr int kSortWaveItems = kWave * kSortRounds;  // 1024 items per wave
@@ -60,7 +62,7 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
 // A block is WAVES chunks: the count table cnt[digit][chunk] is written (and read back by the scatter)
-// in runs of WAVES consecutive chunks per digit — 64 contiguous bytes with 16 waves — instead of one
+// in runs of WAVES consecutive chunks per digit — 32 contiguous bytes with 8 waves — instead of one
 // stray word per (digit, wave).  The LDS rows are padded by one word so that the transposed access
 // (lanes = consecutive waves of one digit) spreads over the banks.
 template <int BITS> struct SortBlock { static constexpr int kWaves = BITS <= 9 ? SLS_SORT_WAVES : (BITS == 10 ? (SLS_SORT_WAVES < 8 ? SLS_SORT_WAVES : 8) : 4); };
