@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_uni
             if (k < a.ngroups - 1 && u >= a.unit_end[k]) gi = k + 1;
         const SlsAdamGroup grp = a.g[gi];
         const int64_t e0 = (u - (gi ? a.unit_end[gi - 1] : 0)) * 4;
-        const float step_size = grp.lr / a.c.bc1;
+        const float step_size = grp.lr * __builtin_amdgcn_rcpf(a.c.bc1);   // (as the fused update in preprocess_bwd)
         const bool vec = (e0 + 4 <= grp.numel) &&
                          ((((uintptr_t)grp.param | (uintptr_t)grp.grad | (uintptr_t)grp.exp_avg | (uintptr_t)grp.exp_avg_sq) & 15) == 0);
         if (vec) {

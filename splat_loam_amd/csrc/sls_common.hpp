@@ -241,8 +241,9 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 {
     m = m + (g - m) * a.w1;
     v = v * a.b2 + (a.w2 * g) * g;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    p = p - step_size * (m / denom);
+    // (hardware 1-ulp square root and reciprocals: an error of 1e-7 of the step, i.e. of lr-sized changes)
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(a.bc2_sqrt) + a.eps;
+    p = p - step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 // Adam fused into preprocess_bwd (one keyframe per step, sls_mapping_step): moments in the flat
 // [xyz 3N | opacity N | scaling 2N | rotation 4N] layout of the gradient bucket.

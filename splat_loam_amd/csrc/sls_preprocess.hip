@@ -81,7 +81,16 @@ struct SurfelGeom {
     float su, sv, sig, c;
 };
 
-// Shared by forward and backward so both see identical intermediates.
+// Correctly rounded division and square root (-fhip-fp32-correctly-rounded-divide-sqrt) cost ~14 VALU instructions
+// each.  They are kept where an INTEGER output depends on them — the centre's projection and the support extents
+// that become the tile rectangle, the depth key — because those must match the checker bit for bit.  Everything that
+// only feeds float outputs (the record's tangent rows, the whole backward, the optimiser) uses the hardware's
+// 1-ulp v_rcp_f32 / v_sqrt_f32 / v_exp_f32: preprocess_bwd 1279 -> ~500 VALU instructions per surfel.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// Shared by forward and backward.  EXACT_ROOTS: rho and rxy correctly rounded (forward: they enter the projection).
+template <bool EXACT_ROOTS>
 __device__ __forceinline__ void surfel_geom(const DevCam &cam, const float *m, const float2 s, const float4 q,
                                             SurfelGeom &g)
 {
@@ -90,8 +99,8 @@ __device__ __forceinline__ void surfel_geom(const DevCam &cam, const float *m, c
         g.p[k] = fmaf(cam.R[3 * k], m[0], fmaf(cam.R[3 * k + 1], m[1], fmaf(cam.R[3 * k + 2], m[2], cam.t[k])));
     g.rxy2 = fmaf(g.p[0], g.p[0], g.p[1] * g.p[1]);
     g.rho2 = fmaf(g.p[2], g.p[2], g.rxy2);
-    g.rho = sqrtf(g.rho2);
-    g.rxy = sqrtf(g.rxy2);
+    g.rho = EXACT_ROOTS ? sqrtf(g.rho2) : fsqrt(g.rho2);
+    g.rxy = EXACT_ROOTS ? sqrtf(g.rxy2) : fsqrt(g.rxy2);
     float tu[3], tv[3], tn[3];
     quat_axes(q, tu, tv, tn);
     matvec(cam.R, tu, g.Tu);
@@ -101,11 +110,12 @@ __device__ __forceinline__ void surfel_geom(const DevCam &cam, const float *m, c
     g.sv = s.y * cam.mod;
     g.c = dot3(g.Tn, g.p);
     g.sig = (g.c > 0.0f) ? -1.0f : 1.0f;
+    const float isu = g.sig * frcp(g.su), isv = -g.sig * frcp(g.sv);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         g.n[k] = g.sig * g.Tn[k];
-        g.A[k] = (g.sig * g.Tv[k]) / g.su;
-        g.B[k] = (-g.sig * g.Tu[k]) / g.sv;
+        g.A[k] = g.Tv[k] * isu;
+        g.B[k] = g.Tu[k] * isv;
     }
     cross3(g.A, g.p, g.Hu);
     cross3(g.B, g.p, g.Hv);
@@ -123,13 +133,22 @@ struct RegArgs {
                               // (nothing else touches them before this kernel has finished)
 };
 
+// EXACT (forward): the scales enter the support extents, i.e. the tile rectangle.
+template <bool EXACT>
 __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q, float &o)
 {
     if (!ra.raw) return;
-    s.x = expf(s.x); s.y = expf(s.y);
-    o = 1.0f / (1.0f + expf(-o));
-    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    float inv;
+    if (EXACT) {
+        s.x = expf(s.x); s.y = expf(s.y);
+        o = 1.0f / (1.0f + expf(-o));
+        inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    } else {
+        s.x = __expf(s.x); s.y = __expf(s.y);
+        o = frcp(1.0f + __expf(-o));
+        inv = frcp(fmaxf(fsqrt(n2), 1e-12f));
+    }
     q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
 }
 
@@ -161,10 +180,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         float2 s = scales[i];
         float4 q = rots[i];
         float o = opac[i];
-        activate(ra, s, q, o);
+        activate<true>(ra, s, q, o);
         if (ra.pen != 0.0f) my_reg = ra.pen * fmaxf(fmaxf(s.x, s.y) - ra.smax, 0.0f);
         SurfelGeom g;
-        surfel_geom(cam, m, s, q, g);
+        surfel_geom<true>(cam, m, s, q, g);
         bool vis = (g.rho >= cam.near_c) && (g.rho < 1.0e18f);  // D2 near cut; NaN/inf fail
         if (vis) {
             const float az = sls_atan2(g.p[1], g.p[0]);
@@ -244,6 +263,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 q0 = make_float4(g.Hu[0], g.Hu[1], g.Hu[2], g.sig * g.c);
                 q1 = make_float4(g.Hv[0], g.Hv[1], g.Hv[2], g.rho);
                 q2 = make_float4(g.n[0], g.n[1], g.n[2], o);
+                // (correctly rounded: the tile kernels subtract this unit vector from the pixel's — a 1-ulp difference
+                //  here is 1e-4 of (d - dc) for a pixel next to the centre, and the checker rounds it this way)
                 q3 = make_float4(g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho, kc);
                 q4 = make_float4(cpx, cpy, ex, ey);
             }
@@ -332,14 +353,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     float4 q = q_in;
     const float o_in = ra.raw ? opac[i] : 0.0f;
     float o = o_in;
-    activate(ra, s, q, o);
+    activate<false>(ra, s, q, o);
     const float m[3] = { means[3 * i], means[3 * i + 1], means[3 * i + 2] };
     // (an unmarked surfel's record is all zeros and so is its gradient: nothing to read, nothing to clear)
     const bool marked = !af.touched || af.touched[i] != 0;
     if (marked && af.touched) af.touched[i] = 0;
     if (radii[i] > 0 && marked) {
         SurfelGeom g;
-        surfel_geom(cam, m, s, q, g);
+        surfel_geom<false>(cam, m, s, q, g);
         float4 g0, g1, g2, g3;
         if (af.det_max) {
             float gv[16];
@@ -361,8 +382,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         const float gHu[3] = { g0.x, g0.y, g0.z }, gHv[3] = { g1.x, g1.y, g1.z }, gn[3] = { g2.x, g2.y, g2.z };
         const float gnpv = g0.w, grhoc = g1.w, go = g2.w, Su = g3.x, Sv = g3.y, gcpx = g3.z, gcpy = g3.w;
         float dc[3];
+        const float irho = frcp(g.rho), isu = frcp(g.su), isv = frcp(g.sv);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dc[k] = g.p[k] / g.rho;
+        for (int k = 0; k < 3; ++k) dc[k] = g.p[k] * irho;
         float dp[3], dA[3], dB[3], t1[3], t2[3];
         cross3(g.p, gHu, dA); cross3(gHu, g.A, t1);
         cross3(g.p, gHv, dB); cross3(gHv, g.B, t2);
@@ -370,10 +392,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             dp[k] = t1[k] + t2[k];
-            dTv[k] = g.sig * dA[k] / g.su;
-            dTu[k] = -g.sig * dB[k] / g.sv;
+            dTv[k] = g.sig * dA[k] * isu;
+            dTu[k] = -g.sig * dB[k] * isv;
         }
-        const float dsu = -dot3(dA, g.A) / g.su, dsv = -dot3(dB, g.B) / g.sv;
+        const float dsu = -dot3(dA, g.A) * isu, dsv = -dot3(dB, g.B) * isv;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             dTn[k] = g.sig * (gn[k] + gnpv * g.p[k]);
@@ -385,12 +407,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         for (int k = 0; k < 3; ++k) gdc[k] = -(Su * g.Hu[k] + Sv * g.Hv[k]);
         const float gd = dot3(gdc, dc);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dp[k] += (gdc[k] - gd * dc[k]) / g.rho;
+        for (int k = 0; k < 3; ++k) dp[k] += (gdc[k] - gd * dc[k]) * irho;
         if (g.rxy2 > 1e-30f) {
             const float gaz = gcpx * cam.fx, gel = gcpy * cam.fy;
-            dp[0] += gaz * (-g.p[1] / g.rxy2) + gel * (-g.p[2] * g.p[0] / (g.rxy * g.rho2));
-            dp[1] += gaz * (g.p[0] / g.rxy2) + gel * (-g.p[2] * g.p[1] / (g.rxy * g.rho2));
-            dp[2] += gel * (g.rxy / g.rho2);
+            const float irxy2 = frcp(g.rxy2), irr = frcp(g.rxy * g.rho2), irho2 = irho * irho;
+            dp[0] += gaz * (-g.p[1] * irxy2) + gel * (-g.p[2] * g.p[0] * irr);
+            dp[1] += gaz * (g.p[0] * irxy2) + gel * (-g.p[2] * g.p[1] * irr);
+            dp[2] += gel * (g.rxy * irho2);
         }
         matTvec(cam.R, dp, dm);
         ds = make_float2(cam.mod * dsu, cam.mod * dsv);
@@ -411,8 +434,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     if (ra.raw) {
         ds.x *= s.x; ds.y *= s.y;                                   // exp backward
         dop *= o * (1.0f - o);                                      // sigmoid backward
-        const float nrm = sqrtf(q_in.x * q_in.x + q_in.y * q_in.y + q_in.z * q_in.z + q_in.w * q_in.w);
-        const float inv = 1.0f / fmaxf(nrm, 1e-12f);                // F.normalize backward
+        const float nrm = fsqrt(q_in.x * q_in.x + q_in.y * q_in.y + q_in.z * q_in.z + q_in.w * q_in.w);
+        const float inv = frcp(fmaxf(nrm, 1e-12f));                 // F.normalize backward
         const float dd = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w;
         dq.x = (dq.x - dd * q.x) * inv; dq.y = (dq.y - dd * q.y) * inv;
         dq.z = (dq.z - dd * q.z) * inv; dq.w = (dq.w - dd * q.w) * inv;
@@ -441,8 +464,9 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         const size_t n = (size_t)N, ix = 3 * (size_t)i, io = 3 * n + i, is = 4 * n + 2 * (size_t)i, ir = 6 * n + 4 * (size_t)i;
         float *M = af.exp_avg, *V = af.exp_avg_sq;
         float p, mm, vv;
-        const float st_x = af.lr_xyz / af.c.bc1, st_o = af.lr_opacity / af.c.bc1;
-        const float st_s = af.lr_scaling / af.c.bc1, st_r = af.lr_rotation / af.c.bc1;
+        const float ibc1 = frcp(af.c.bc1);
+        const float st_x = af.lr_xyz * ibc1, st_o = af.lr_opacity * ibc1;
+        const float st_s = af.lr_scaling * ibc1, st_r = af.lr_rotation * ibc1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             p = m[k]; mm = M[ix + k]; vv = V[ix + k];
