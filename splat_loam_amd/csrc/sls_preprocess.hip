@@ -66,13 +66,32 @@ __device__ __forceinline__ void quat_axes(const float4 q, float *tu, float *tv, 
 }
 // Angular half-extents (elevation theta, azimuth daz) of a ball of radius rad
 // centred at range rho / horizontal range rxy, seen from the origin (D4).
+// EXACT: the rectangle of tiles comes out of these (integers: the checker's arithmetic, sls_det_math.h).  The
+// approximate variant (hardware rcp / sqrt, same polynomial) serves the support extents of the cull, which only
+// have to be conservative and carry their own margins.
+__device__ __forceinline__ float asin01_approx(float s)
+{
+    // atan2(s, sqrt(1 - s^2)) for s in [0, 1): both arguments non-negative
+    const float c = __builtin_amdgcn_sqrtf(fmaf(-s, s, 1.0f));
+    const float mx = fmaxf(s, c), mn = fminf(s, c);
+    const float r = sls_atan_unit(mn * __builtin_amdgcn_rcpf(mx));
+    return s > c ? SLS_PIO2 - r : r;
+}
+template <bool EXACT>
 __device__ __forceinline__ void ball_extent(float rad, float rho, float rxy, float &theta, float &daz)
 {
     if (!(rad < rho)) { theta = SLS_PI; daz = SLS_PI; return; }
-    theta = sls_asin01(rad / rho);
-    const float q = rad / rxy;
-    if (!(q < 1.0f)) daz = SLS_PI;
-    else daz = sls_asin01(q);
+    if (EXACT) {
+        theta = sls_asin01(rad / rho);
+        const float q = rad / rxy;
+        if (!(q < 1.0f)) daz = SLS_PI;
+        else daz = sls_asin01(q);
+    } else {
+        theta = asin01_approx(rad * __builtin_amdgcn_rcpf(rho));
+        const float q = rad * __builtin_amdgcn_rcpf(rxy);
+        if (!(q < 0.9999f)) daz = SLS_PI;
+        else daz = asin01_approx(q);
+    }
 }
 
 struct SurfelGeom {
@@ -133,7 +152,7 @@ struct RegArgs {
                               // (nothing else touches them before this kernel has finished)
 };
 
-// EXACT (forward): the scales enter the support extents, i.e. the tile rectangle.
+// EXACT (forward): the scales enter the extents of the tile rectangle — library expf for those.
 template <bool EXACT>
 __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q, float &o)
 {
@@ -142,8 +161,9 @@ __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q
     float inv;
     if (EXACT) {
         s.x = expf(s.x); s.y = expf(s.y);
-        o = 1.0f / (1.0f + expf(-o));
-        inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        // (opacity and rotation reach float outputs only)
+        o = frcp(1.0f + __expf(-o));
+        inv = frcp(fmaxf(fsqrt(n2), 1e-12f));
     } else {
         s.x = __expf(s.x); s.y = __expf(s.y);
         o = frcp(1.0f + __expf(-o));
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             const float cpx = fmaf(cam.fx, az, cam.cx), cpy = fmaf(cam.fy, el, cam.cy);
             const float smax = fmaxf(g.su, g.sv);
             float theta, daz;
-            ball_extent(SLS_CUTOFF * smax, g.rho, g.rxy, theta, daz);
+            ball_extent<true>(SLS_CUTOFF * smax, g.rho, g.rxy, theta, daz);
             const float rx = fmaxf(fabsf(cam.fx) * daz, SLS_RMIN_PX);
             const float ry = fmaxf(fabsf(cam.fy) * theta, SLS_RMIN_PX);
             int xlo = to_int_clamped(floorf(cpx - rx + 0.5f));
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                     float th2, daz2;
                     const float kk = __builtin_amdgcn_sqrtf(rho_max), rad = kk * smax;
                     kc = kk * 1.0001f;
-                    ball_extent(rad, g.rho, g.rxy, th2, daz2);
+                    ball_extent<false>(rad, g.rho, g.rxy, th2, daz2);
                     const float r2 = __builtin_amdgcn_sqrtf(0.5f * rho_max);
                     // Tighter bound for the 3D branch: the hit point is p + u su Tu + v sv Tv with
                     // u^2+v^2 <= rho_max, an ellipse; its (az, el) extent to first order, plus a bound
