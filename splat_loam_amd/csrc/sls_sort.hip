@@ -100,39 +100,43 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_hist_kernel
     }
 }
 
-// step 2: block d scans row d of cnt[][] exclusively in place, writes the row total
+// step 2: block d scans row d of cnt[][] exclusively in place, writes the row total.
+// Thread t owns P = ceil(nchunks / 256) CONSECUTIVE entries: one pass to sum them, one wave scan + one barrier for
+// the 256 partial sums, one pass to write the running prefix (a loop over 256-entry slabs with two barriers each
+// cost 2 us more on the 1260-chunk rows of the tile sort: the kernel is nothing but its chain of latencies).
 __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ count_ptr, uint32_t cap,
                                                            int nchunks_cap, uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_carry;
     const uint32_t R = load_count(count_ptr, cap);
     const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
     uint32_t *row = cnt + (size_t)blockIdx.x * nchunks_cap;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int base = 0; base < nchunks; base += 256) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < nchunks) ? row[i] : 0u;
-        uint32_t incl = v;
+    const int P = (nchunks + 255) / 256, i0 = (int)threadIdx.x * P, i1 = min(i0 + P, nchunks);
+    constexpr int kKeep = 8;                 // entries kept in registers between the two passes (P <= 8 up to 2 M items)
+    uint32_t keep[kKeep];
+    uint32_t sum = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-        const uint32_t carry = s_carry;
-        if (i < nchunks) row[i] = carry + wave_prefix + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = carry + wave_prefix + incl;
-        __syncthreads();
+    for (int j = 0; j < kKeep; ++j) { keep[j] = (i0 + j < i1) ? row[i0 + j] : 0u; sum += keep[j]; }
+    for (int i = i0 + kKeep; i < i1; ++i) sum += row[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) {
+        if (i0 + j < i1) row[i0 + j] = run;
+        run += keep[j];
+    }
+    for (int i = i0 + kKeep; i < i1; ++i) { const uint32_t v = row[i]; row[i] = run; run += v; }
+    if (threadIdx.x == 255) totals[blockIdx.x] = run;
 }
 
 // step 3: stable scatter
