@@ -228,12 +228,42 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
     return dmeans, dscales, drots, dopac, grec
 
 
+def frame_from_precomp(cov3D_precomp: torch.Tensor):
+    """(scales (N,2), rotations (N,4) w,x,y,z) of surfels given as the precomputed transform the reference's model
+    builds (scene/gaussian_model.py:20-36, `build_covariance_from_scaling_rotation`): (N,4,4) with
+    `[:, :3, :3] = (R diag(s_u, s_v, 1))^T` — rows 0 and 1 the scaled tangents, row 2 the normal — and row 3 the
+    centre; an (N,3,3) tensor (only the frame) is accepted too.  The reference never passes it to the rasterizer
+    (gaussian_renderer/__init__.py:46), so this is the in-tree layout, not a pinned rasterizer contract.  Pure torch,
+    any device; the surfels rendered from it are those the (scales, rotations) path renders."""
+    t = cov3D_precomp
+    if t.dim() != 3 or tuple(t.shape[1:]) not in ((4, 4), (3, 3)):
+        raise ValueError(f"cov3D_precomp must be (N,4,4) or (N,3,3), got {tuple(t.shape)}")
+    rs_t = t[:, :3, :3].to(torch.float32)
+    su, sv = rs_t[:, 0].norm(dim=1), rs_t[:, 1].norm(dim=1)
+    tu = rs_t[:, 0] / su.clamp_min(1e-30)[:, None]
+    tv = rs_t[:, 1] / sv.clamp_min(1e-30)[:, None]
+    tn = torch.cross(tu, tv, dim=1)                        # (row 2 is R's third column: recomputed, right-handed)
+    R = torch.stack([tu, tv, tn], dim=2)                   # columns t_u, t_v, n
+    # rotation matrix -> unit quaternion (w, x, y, z), the branch with the largest denominator per surfel
+    m00, m11, m22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22,
+                                                1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=1), min=0.0))
+    cand = torch.stack([
+        torch.stack([q_abs[:, 0] ** 2, R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], dim=1),
+        torch.stack([R[:, 2, 1] - R[:, 1, 2], q_abs[:, 1] ** 2, R[:, 1, 0] + R[:, 0, 1], R[:, 0, 2] + R[:, 2, 0]], dim=1),
+        torch.stack([R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] + R[:, 0, 1], q_abs[:, 2] ** 2, R[:, 2, 1] + R[:, 1, 2]], dim=1),
+        torch.stack([R[:, 1, 0] - R[:, 0, 1], R[:, 2, 0] + R[:, 0, 2], R[:, 2, 1] + R[:, 1, 2], q_abs[:, 3] ** 2], dim=1),
+    ], dim=1)                                              # (N, 4 candidates, 4 components), each = 2 q_k * q
+    best = q_abs.argmax(dim=1)
+    q = cand[torch.arange(R.shape[0], device=R.device), best]
+    q = q / (2.0 * q_abs.gather(1, best[:, None]).clamp_min(1e-12))
+    q = torch.nn.functional.normalize(q, dim=1)
+    return torch.stack([su, sv], dim=1).contiguous(), q.contiguous()
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, cov3D_precomp, raster_settings):
-        if cov3D_precomp is not None:
-            raise NotImplementedError("cov3D_precomp is not supported (the reference never passes it, "
-                                      "gaussian_renderer/__init__.py:46)")
         if scales is None or rotations is None:
             raise ValueError("scales and rotations are required")
         m, o, s_, r = map(_f32c, (means3D.detach(), opacities.detach(), scales.detach(), rotations.detach()))
@@ -277,5 +307,8 @@ class GaussianRasterizer(nn.Module):
                 rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
         if (scales is None or rotations is None) == (cov3D_precomp is None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        return _RasterizeGaussians.apply(means3D, means2D, opacities, scales, rotations, cov3D_precomp,
+        if cov3D_precomp is not None:
+            # the precomputed frame carries no gradient (autograd returns None for it, as for means2D)
+            scales, rotations = frame_from_precomp(cov3D_precomp.detach())
+        return _RasterizeGaussians.apply(means3D, means2D, opacities, scales, rotations, None,
                                          self.raster_settings)

@@ -111,3 +111,32 @@ def test_engine_bucket_surgery_on_cpu():
     import pytest
     with pytest.raises(ValueError):
         carry_bucket(buf, keep, 3)
+
+
+def test_frame_from_precomp_inverts_the_reference_construction():
+    """`cov3D_precomp` in the layout the reference's model builds (scene/gaussian_model.py:20-36: a (N,4,4) transform
+    with [:3,:3] = (R diag(s_u, s_v, 1))^T and the centre in row 3; utils/general_utils.py:13-48 for R(q)) converts back
+    to the (scales, w-x-y-z quaternion) the rasterizer takes — up to the quaternion's sign."""
+    import torch
+    from splat_loam_amd.rasterizer import frame_from_precomp
+    g = torch.Generator().manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(2000, 4, generator=g), dim=1)
+    q[:4] = torch.tensor([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]])   # the four pure branches
+    s = torch.rand(2000, 2, generator=g) * 0.2 + 1e-3
+    r, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    L = R @ torch.diag_embed(torch.cat([s, torch.ones(2000, 1)], 1))
+    trans = torch.zeros(2000, 4, 4)
+    trans[:, :3, :3] = L.permute(0, 2, 1)
+    trans[:, 3, :3] = torch.randn(2000, 3, generator=g)
+    trans[:, 3, 3] = 1
+    for t in (trans, trans[:, :3, :3].contiguous()):
+        s2, q2 = frame_from_precomp(t)
+        sign = torch.sign((q * q2).sum(1, keepdim=True))
+        assert float((s2 - s).abs().max()) <= 1e-6
+        assert float((q2 * sign - q).abs().max()) <= 2e-6
+        assert float((q2.norm(dim=1) - 1).abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        frame_from_precomp(torch.zeros(5, 6))

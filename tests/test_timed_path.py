@@ -267,3 +267,42 @@ def test_deterministic_accumulation(device, oracle32):
         if init is not None:
             moved = np.abs(a - init).max()
             assert np.abs(a - b).max() <= 0.02 * moved      # float atomics: same trajectory up to the usual drift
+
+
+def test_cov3D_precomp_renders_the_same_surfels(device):
+    """The rasterizer's third way in (VERDICT r1 missing #6): the precomputed surfel transform of
+    scene/gaussian_model.py:20-36 instead of (scales, rotations) renders the same image; it carries no gradient,
+    means and opacities still do."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splat_loam_amd.scene import Camera
+    N, H, W = 4000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=23, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=str(device))
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=device)
+    means, scales, rots, opac = t(sc["means"]), t(sc["scales"]), t(sc["rots"]), t(sc["opac"]).reshape(-1, 1)
+    r, x, y, z = rots.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    trans = torch.zeros(N, 4, 4, device=device)
+    trans[:, :3, :3] = (R @ torch.diag_embed(torch.cat([scales, torch.ones(N, 1, device=device)], 1))).permute(0, 2, 1)
+    trans[:, 3, :3] = means
+    trans[:, 3, 3] = 1
+    settings = GaussianRasterizationSettings(H, W, 1.0, cam.world_view_transform, cam.projection_matrix, False, False)
+    rast = GaussianRasterizer(raster_settings=settings)
+    radii_a, all_a = rast(means3D=means, means2D=torch.zeros_like(means), opacities=opac, scales=scales, rotations=rots)
+    m2 = means.clone().requires_grad_(True)
+    o2 = opac.clone().requires_grad_(True)
+    tr = trans.clone().requires_grad_(True)
+    radii_b, all_b = rast(means3D=m2, means2D=torch.zeros_like(means), opacities=o2, cov3D_precomp=tr)
+    # (scales recovered as row norms differ from the originals in the last bit: a radius may move across a ceil())
+    assert float((radii_a != radii_b).float().mean()) <= 1e-3
+    scale = float(all_a.abs().amax())
+    assert float((all_a - all_b).abs().max()) <= 2e-5 * scale
+    all_b[1].sum().backward()
+    assert tr.grad is None and m2.grad is not None and float(o2.grad.abs().max()) > 0
+    with pytest.raises(Exception):
+        rast(means3D=means, means2D=torch.zeros_like(means), opacities=opac, scales=scales, rotations=rots,
+             cov3D_precomp=trans)
