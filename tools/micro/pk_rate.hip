@@ -1,5 +1,7 @@
 // Micro-benchmark: issue rate of packed FP32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) against their
-// scalar forms on gfx950, 4 waves per SIMD, independent accumulators (no dependency stalls).
+// scalar forms on gfx950, 4 waves per SIMD, independent accumulators (no dependency stalls).  Measured on MI355X:
+// v_fma_f32 0.655 ms, v_mul_f32 0.601 ms, v_pk_fma_f32 1.121 ms, v_pk_mul_f32 1.106 ms, v_pk_add_f32 1.081 ms for the
+// same number of instructions: a packed instruction holds the issue port 1.7-1.8x as long as a scalar one.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/pk_rate.hip -o /tmp/pk_rate && /tmp/pk_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -50,8 +52,9 @@ static void run(const char *name, float *d)
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double insts = (double)iters * 64.0 * 16.0;           // VALU instructions per SIMD (4 waves x 64 per iteration)
-    printf("%-14s %8.3f ms  -> %.2f ns per instruction per SIMD (4 clocks at 2.4 GHz = 1.67 ns)\n", name, ms, ms * 1e6 / insts);
+    // per SIMD: 4 waves x 64 instructions per iteration (8 asm statements of 8 instructions)
+    const double insts = (double)iters * 64.0 * 4.0;
+    printf("%-14s %8.3f ms  -> %.2f ns per instruction per SIMD\n", name, ms, ms * 1e6 / insts);
 }
 int main()
 {
