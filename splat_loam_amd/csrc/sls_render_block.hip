@@ -30,6 +30,13 @@ namespace sls {
 // Experiment build only (make FAST='$(COMMON) -munsafe-fp-atomics -DSLS_TRACE', tools/wave_trace.py): every wave of
 // the tile kernels records when it ran (100 MHz wall clock), where (HW_ID) and how many rounds / steps it did.
 __device__ uint32_t g_trace[2][8192 * 4];
+// forward: shader clocks a wave spent waiting for the staged records (+ LDS store) / in cull + compaction / in the
+// steps / at the round's end
+__device__ uint32_t g_trace_phase[8192 * 4];
+#define SLS_PHASE_DECL() uint64_t ph_t = clock64(); uint32_t ph_acc[4] = { 0, 0, 0, 0 }
+#define SLS_PHASE(k_) { const uint64_t now_ = clock64(); ph_acc[k_] += (uint32_t)(now_ - ph_t); ph_t = now_; }
+#define SLS_PHASE_RESET() ph_t = clock64()
+#define SLS_PHASE_END() if (threadIdx.x == 0 && blockIdx.x < 8192) { for (int k_ = 0; k_ < 4; ++k_) g_trace_phase[4 * blockIdx.x + k_] = ph_acc[k_]; }
 #define SLS_TRACE_BEGIN() const uint64_t trace_t0 = wall_clock64(); uint32_t trace_rounds = 0, trace_steps = 0, trace_sparse = 0
 #define SLS_TRACE_ACTIVE(m_) { const int na_ = __builtin_popcountll((m_) & 0x1111111111111111ull); trace_sparse += (na_ <= 1 ? 1u : 0u) + (na_ <= 2 ? 1u << 10 : 0u) + (na_ <= 4 ? 1u << 20 : 0u); }
 #define SLS_TRACE_ROUND() ++trace_rounds
@@ -47,6 +54,10 @@ __device__ uint32_t g_trace[2][8192 * 4];
 #define SLS_TRACE_ROUND()
 #define SLS_TRACE_STEP()
 #define SLS_TRACE_END(k_)
+#define SLS_PHASE_DECL()
+#define SLS_PHASE(k_)
+#define SLS_PHASE_RESET()
+#define SLS_PHASE_END()
 #endif
 
 template <int CTRL>
@@ -188,9 +199,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, 1, n) }
     }
     if (blk_mask && blockIdx.x == 0 && lane == 0) blk_mask[0] = block_mask_tag(BW);
+    SLS_PHASE_DECL();
     for (int r = 0; r < nr && !wave_done; ++r) {
         float bcx, bcy, bhx, bhy;
         if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        SLS_PHASE_RESET();
         SLS_TRACE_ROUND();
         SLS_TRACE_ACTIVE(__ballot(!done));
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         }
         const int cnt = min(64, n - r * 64);
         __builtin_amdgcn_wave_barrier();
+        SLS_PHASE(0);
         bool pass = false;
         if (lane < cnt) {
             const float4 c4 = s_rec[lane * kRec4 + 4];
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         const int npass = __builtin_popcountll(mask);
         if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
         __builtin_amdgcn_wave_barrier();
+        SLS_PHASE(1);
         if (DBG) { st_staged += (uint32_t)cnt; st_pass += (uint32_t)npass; }
         for (int k = 0; k < npass; k += 4) {
             const bool valid = (k + slot) < npass;
@@ -282,12 +297,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             }
             if (tb && __all(done)) { wave_done = true; break; }
         }
+        SLS_PHASE(2);
         if (blk_mask) {
             __builtin_amdgcn_wave_barrier();
             const uint64_t rmask = __ballot(s_flag[lane] != 0u);
             if (lane == 0) blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)] = rmask;
             if (rmask) { bwd_rounds = (uint32_t)(r + 1); bwd_steps += (uint32_t)(__builtin_popcountll(rmask) + 3) / 4u; }
         }
+        SLS_PHASE(3);
     }
 
     // combine the four slots of a pixel
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         if (lane == 0) atomicMax(&tile_consumed[tile], c);
     }
     SLS_TRACE_END(0);
+    SLS_PHASE_END();
     if (DBG && lane == 0) {
         dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
         uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
@@ -551,6 +569,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
 extern "C" int sls_debug_read_trace(uint32_t *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(g_trace));
+}
+extern "C" int sls_debug_read_trace_phases(uint32_t *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_phase), sizeof(g_trace_phase));
 }
 #endif
 

@@ -25,6 +25,19 @@ buf = (C.c_uint32 * (2 * 8192 * 4))()
 lib.sls_debug_read_trace.argtypes = [C.c_void_p]
 assert lib.sls_debug_read_trace(buf) == 0
 tr = np.frombuffer(buf, dtype=np.uint32).reshape(2, 8192, 4).astype(np.int64)
+if hasattr(lib, "sls_debug_read_trace_phases"):
+    pb = (C.c_uint32 * (8192 * 4))()
+    lib.sls_debug_read_trace_phases.argtypes = [C.c_void_p]
+    if lib.sls_debug_read_trace_phases(pb) == 0:
+        ph = np.frombuffer(pb, dtype=np.uint32).reshape(8192, 4).astype(np.float64)
+        rounds_f = (tr[0, :, 3] >> 16).astype(np.float64)
+        steps_f = (tr[0, :, 3] & 0xFFFF).astype(np.float64)
+        dur_f = (tr[0, :, 1] - tr[0, :, 0]) * 0.01
+        for name_, sel in (("all", rounds_f > 0), (">= 12 rounds", rounds_f >= 12), ("the 10 longest", dur_f >= np.sort(dur_f)[-10])):
+            tot = ph[sel].sum(0)
+            print(f"  forward phases [{name_}: {int(sel.sum())} waves, {rounds_f[sel].sum():.0f} rounds, {steps_f[sel].sum():.0f} steps]: shader clocks per round - "
+                  f"wait for the staged records + store {tot[0] / rounds_f[sel].sum():.0f}, cull + compaction {tot[1] / rounds_f[sel].sum():.0f}, "
+                  f"steps {tot[2] / rounds_f[sel].sum():.0f} ({tot[2] / max(steps_f[sel].sum(), 1):.0f} per step), round end {tot[3] / rounds_f[sel].sum():.0f}")
 for k, name in enumerate(("fwd", "bwd")):
     t0, t1, hw, xcc = tr[k, :, 0], tr[k, :, 1], tr[k, :, 2], 0 * tr[k, :, 3]
     rounds, steps = tr[k, :, 3] >> 16, tr[k, :, 3] & 0xFFFF
