@@ -148,7 +148,8 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R,
 
 /* The same backward with DETERMINISTIC accumulation of the per-surfel gradient records: integer atomics
  * instead of float atomics (first launch: the largest |contribution| per surfel and field; second launch:
- * every contribution scaled by 2^(40 - exponent of that maximum), rounded, added as a 64-bit integer), so
+ * every contribution scaled by 2^(39 - unbiased exponent of that maximum), rounded, added as a 64-bit integer:
+ * 39 fractional bits below the largest term, |q| < 2^40, 23 bits of headroom for the sum), so
  * that two runs on the same inputs return the same bits.  No `grec` buffer; det_scratch: DEVICE scratch of
  * sls_backward_det_scratch_bytes(N). */
 size_t sls_backward_det_scratch_bytes(int N);
@@ -238,6 +239,10 @@ typedef struct SlsMappingStatus {
     uint32_t pad;
 } SlsMappingStatus;
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity);
+/* The same for ONE configuration: without cfg->deterministic the two fixed-point accumulators (192 B per
+ * surfel, about as much as the rest of the per-surfel workspace) are not reserved.  A workspace sized by
+ * sls_mapping_workspace_bytes fits every configuration. */
+size_t sls_mapping_workspace_bytes_cfg(int N, int H, int W, uint64_t R_capacity, const struct SlsMappingConfig *cfg);
 int sls_mapping_step(const SlsCamera *cam, int N,
                      float *xyz, float *scaling_raw, float *rotation_raw, float *opacity_raw,
                      float *grads, float *exp_avg, float *exp_avg_sq, int64_t adam_step,
@@ -367,8 +372,8 @@ int sls_debug_wave_cycles(uint32_t *fwd_cycles, uint32_t *bwd_cycles);
 
 /* Tuning/diagnostic: choose the tile kernels' pixel-block shape: 2 = 4x4, 3 = 8x2 (the default);
  * negative = keep.  Both produce the same results; the tests run both.  Like sls_timing_* and
- * sls_debug_wave_cycles this acts on the CALLING THREAD only (thread-local state: the library keeps
- * no process-global mutable state). */
+ * sls_debug_wave_cycles this is a PROCESS-wide diagnostic switch (torch runs backward nodes on its autograd
+ * device thread, which must see what the calling thread chose); the data path itself keeps no mutable state. */
 int sls_debug_variant(int fwd_variant, int bwd_variant);
 
 /* Device self-test of the wave64 primitives (DPP reduction, ballot ranking).

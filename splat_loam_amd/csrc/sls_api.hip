@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "sls_common.hpp"
 
 namespace sls {
@@ -30,12 +32,18 @@ struct TimerState {
     bool enabled = false;
     int mode = 0;          // 1: every launch, 2: the two tile kernels only, 3: render_bwd only
     int used = 0;
+    int open = -1;         // index of the pair whose start was recorded and whose stop is pending
     int created = 0;
     hipEvent_t start[kTimerPool], stop[kTimerPool];
     int slot[kTimerPool];
 };
-// the recorder belongs to the thread that enabled it (allocated on first use, one per thread that asks)
-static thread_local TimerState *t_timer = nullptr;
+// ONE recorder per process (allocated on first use), guarded by a mutex: a backward that torch's autograd engine
+// runs on its own device thread records into the recorder the Python thread enabled (a per-thread recorder would
+// silently miss render_bwd / preprocess_bwd in every autograd-driven mode).  Launches of one stream are enqueued
+// in order, so begin/end pairs of different threads do not interleave inside a stream.
+static TimerState *t_timer = nullptr;
+static std::mutex g_timer_mutex;
+static std::atomic<bool> g_timer_on{false};
 #define g_timer (*t_timer)
 
 static inline bool timer_wants(int slot)
@@ -45,16 +53,23 @@ static inline bool timer_wants(int slot)
     if (g_timer.mode == 2) return slot == T_RENDER_FWD || slot == T_RENDER_BWD;
     return slot == T_RENDER_BWD;
 }
+// begin reserves an event pair and hands its index back through the ScopedTimer (slot field reused: -1 = untimed)
 void timer_begin(int slot, hipStream_t st)
 {
+    if (!g_timer_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
     if (!timer_wants(slot) || g_timer.used >= g_timer.created) return;
     g_timer.slot[g_timer.used] = slot;
     (void)hipEventRecord(g_timer.start[g_timer.used], st);
+    g_timer.open = g_timer.used;
 }
 void timer_end(int slot, hipStream_t st)
 {
-    if (!timer_wants(slot) || g_timer.used >= g_timer.created) return;
+    if (!g_timer_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
+    if (!timer_wants(slot) || g_timer.used >= g_timer.created || g_timer.open != g_timer.used) return;
     (void)hipEventRecord(g_timer.stop[g_timer.used], st);
+    g_timer.open = -1;
     ++g_timer.used;
 }
 
@@ -346,6 +361,7 @@ const char *sls_timing_name(int slot) { return (slot >= 0 && slot < T_COUNT) ? k
 
 int sls_timing_enable(int on)
 {
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
     if (!t_timer) {
         if (!on) return SLS_OK;
         t_timer = new TimerState();
@@ -359,6 +375,8 @@ int sls_timing_enable(int on)
     g_timer.enabled = on != 0;
     g_timer.mode = on;
     g_timer.used = 0;
+    g_timer.open = -1;
+    g_timer_on.store(on != 0, std::memory_order_relaxed);
     return SLS_OK;
 }
 
@@ -366,6 +384,7 @@ int sls_timing_collect(double *total_ms, int64_t *counts)
 {
     SLS_REQUIRE(total_ms && counts, "null pointer");
     for (int s = 0; s < T_COUNT; ++s) { total_ms[s] = 0.0; counts[s] = 0; }
+    std::lock_guard<std::mutex> lk(g_timer_mutex);
     if (!t_timer) return SLS_OK;
     for (int i = 0; i < g_timer.used; ++i) {
         SLS_HIP_CHECK(hipEventSynchronize(g_timer.stop[i]));
@@ -376,6 +395,7 @@ int sls_timing_collect(double *total_ms, int64_t *counts)
     }
     const int dropped = (g_timer.used >= g_timer.created) ? 1 : 0;
     g_timer.used = 0;
+    g_timer.open = -1;
     return dropped ? 1 : SLS_OK;   // 1: pool exhausted, later launches were not timed
 }
 

@@ -1,6 +1,7 @@
 // sls_common.hpp — shared by the HIP translation units of libsls_hip.so.
 // gfx950 only: wave = 64 lanes, DPP row_bcast available (GFX9 family).
 #pragma once
+#include <atomic>
 #include <cmath>
 
 #include <hip/hip_runtime.h>
@@ -38,11 +39,12 @@ enum TimerSlot {
     T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT_KEYS, T_SORT_HIST, T_SORT_ROWSCAN, T_SORT_SCATTER, T_TILE_RANGES,
     T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_RESORT, T_COUNT
 };
-// Debug / tuning switches of the CALLING THREAD (sls_debug_variant, sls_debug_wave_cycles, sls_timing_*):
-// thread-local, so that the library has no process-global mutable state.
+// Debug / tuning switches (sls_debug_variant, sls_debug_wave_cycles, sls_timing_*): ONE set per process, relaxed
+// atomics — a backward reached through torch autograd runs on the autograd engine's device thread and must see
+// what the Python thread chose.  Diagnostics only; the data path itself keeps no mutable state.
 struct DebugState {
-    int fwd_variant = 3, bwd_variant = 3;                      // 2: 4x4 pixel blocks, 3: 8x2 (default)
-    uint32_t *dbg_fwd_cycles = nullptr, *dbg_bwd_cycles = nullptr;
+    std::atomic<int> fwd_variant{3}, bwd_variant{3};           // 2: 4x4 pixel blocks, 3: 8x2 (default)
+    std::atomic<uint32_t *> dbg_fwd_cycles{nullptr}, dbg_bwd_cycles{nullptr};
 };
 DebugState &debug_state();
 void timer_begin(int slot, hipStream_t st);

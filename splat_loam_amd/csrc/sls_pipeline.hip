@@ -71,7 +71,7 @@ struct MapWs {
     size_t total;
 };
 
-static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
+static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool deterministic)
 {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     MapWs w;
@@ -112,9 +112,13 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base)
     w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
     w.block_cost = (uint32_t *)take(T * (kTilePix / 16) * 4);
     w.block_order = (uint32_t *)take(T * (kTilePix / 16) * 4);
-    w.det_max = (uint32_t *)take(n * SLS_GREC_STRIDE * 4);
-    w.det_acc = (unsigned long long *)take(n * SLS_GREC_STRIDE * 8);
-    w.det_bytes = (size_t)((char *)w.det_acc - (char *)w.det_max) + n * SLS_GREC_STRIDE * 8;
+    // deterministic accumulation only (192 B per surfel: as much again as everything per-surfel above)
+    w.det_max = nullptr; w.det_acc = nullptr; w.det_bytes = 0;
+    if (deterministic) {
+        w.det_max = (uint32_t *)take(n * SLS_GREC_STRIDE * 4);
+        w.det_acc = (unsigned long long *)take(n * SLS_GREC_STRIDE * 8);
+        w.det_bytes = (size_t)((char *)w.det_acc - (char *)w.det_max) + n * SLS_GREC_STRIDE * 8;
+    }
     w.total = off;
     return w;
 }
@@ -258,7 +262,13 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity)
 {
     if (N < 0 || H <= 0 || W <= 0) return 0;
-    return carve(N, H, W, R_capacity, nullptr).total;
+    return carve(N, H, W, R_capacity, nullptr, true).total;      // fits either setting of cfg->deterministic
+}
+
+size_t sls_mapping_workspace_bytes_cfg(int N, int H, int W, uint64_t R_capacity, const SlsMappingConfig *cfg)
+{
+    if (N < 0 || H <= 0 || W <= 0) return 0;
+    return carve(N, H, W, R_capacity, nullptr, !cfg || cfg->deterministic != 0).total;
 }
 
 int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw, float *rotation_raw,
@@ -277,7 +287,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_REQUIRE(R_capacity > 0 && R_capacity < (1ull << 32), "bad instance capacity");
     SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     const int H = cam->H, W = cam->W;
-    const MapWs w = carve(N, H, W, R_capacity, workspace);
+    const MapWs w = carve(N, H, W, R_capacity, workspace, cfg->deterministic != 0);
     if (workspace_bytes < w.total) {
         set_error("mapping workspace too small: %zu < %zu", workspace_bytes, w.total);
         return SLS_E_SCRATCH;

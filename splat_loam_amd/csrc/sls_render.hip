@@ -20,11 +20,13 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
                             const uint32_t *block_order);
-// Debug switches are per calling thread (sls_common.hpp: DebugState): the library keeps no process-global
-// mutable state.
+// Diagnostic switches are per PROCESS (sls_common.hpp: DebugState): torch runs a backward node on its autograd
+// device thread, not on the thread that called sls_debug_variant / sls_debug_wave_cycles, so per-thread state
+// would silently not reach sls_backward under loss.backward().  They are tuning / test aids only: the data path
+// keeps no mutable state of its own.
 DebugState &debug_state()
 {
-    static thread_local DebugState s;
+    static DebugState s;
     return s;
 }
 

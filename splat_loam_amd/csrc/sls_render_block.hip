@@ -361,9 +361,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 // order that changes from run to run, so the last bits of the gradients do too.  Integer atomics commute:
 //   DET = 1: first launch — per (surfel, field) the LARGEST |contribution| (atomicMax on the float's bit
 //            pattern, order-independent), into det_max;
-//   DET = 2: second launch — every contribution is scaled by 2^(40 - exponent of that maximum), rounded to an
-//            integer (a pure function of the contribution) and added with a 64-bit integer atomic into det_acc:
-//            40 bits below the largest term, 22 bits of headroom for the sum.  preprocess_bwd scales back.
+//   DET = 2: second launch — every contribution is scaled by 2^(39 - unbiased exponent of that maximum) (=
+//            2^(166 - biased exponent)), rounded to an integer (a pure function of the contribution) and added
+//            with a 64-bit integer atomic into det_acc: 39 fractional bits below the largest term, |q| < 2^40,
+//            23 bits of headroom for the sum.  preprocess_bwd scales back by 2^(biased exponent - 166).
 // Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
 template <int BW, int BH, bool LEAN, bool FUSED, int DET>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                     if (valid && tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
                 } else if (valid && tot != 0.0f) {
                     const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
-                    const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^41
+                    const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
                     atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
                 }
             }

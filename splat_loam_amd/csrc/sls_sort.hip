@@ -4,20 +4,25 @@
 // The sorted list is defined by the 64-bit key (tile << 32 | depth bits) with
 // ties broken by surfel index (D3, D9).  It is produced WITHOUT ever sorting
 // 64-bit keys over the R tile instances:
-//   1. the N surfels are sorted by (depth bits, index)   — 4 passes over N pairs;
+//   1. the N surfels are sorted by (29-bit depth key, index) — 3 passes of 10-bit digits
+//      over N (u32 key, u32 index) pairs, or the previous iteration's order is REPAIRED
+//      (windowed bitonic re-sort + exactness check, see "Temporal re-sort" below);
 //   2. instances are emitted in that order                — so within any tile
 //      the emission order already is the final order;
-//   3. one STABLE sort of the R instances by tile id      — ceil(tile_bits/8)
-//      passes (2 for up to 65,536 tiles) over (u32 tile, u32 surfel) pairs.
+//   3. one STABLE pass over the R instances by tile id (9-bit digit for T <= 512, up to
+//      11 bits; two passes beyond 2048 tiles); when tile id and surfel index fit 32 bits
+//      together an instance is ONE packed word.  The pass's digit bases are the tile ranges.
 // LSD radix principle (least-significant part first, stable passes after); the
-// result is bit-identical to a stable 64-bit sort and costs ~40 B of HBM traffic
+// result is bit-identical to a stable 64-bit sort and costs ~24 B of HBM traffic
 // per instance instead of ~190 B.
 //
 // Radix sort building block (wave64-native, no vendor library):
-//   * 8-bit digits; the unit of work is ONE WAVE owning 1024 consecutive items
-//     (16 rounds of 64): no workgroup barrier inside a pass, each wave keeps its
-//     256 running bucket cursors in a private LDS slice;
-//   * stable ranking inside a round by 8 ballots (the set of lanes holding my
+//   * 8..11-bit digits (sort_plan); the unit of work is ONE WAVE owning kSortWaveItems =
+//     1024 consecutive items (16 rounds of 64): no workgroup barrier inside a pass, each
+//     wave keeps its 2^BITS running bucket cursors in a private LDS slice; a workgroup is
+//     SortBlock<BITS>::kWaves waves (8 up to 10-bit digits, 4 for 11) so that the count
+//     table is written and read back in runs of that many chunks per digit;
+//   * stable ranking inside a round by BITS ballots (the set of lanes holding my
 //     digit), rank = popcount(peers below me);
 //   * per pass: histogram -> per-digit row scan over chunks -> scatter;
 //   * the item count is read from DEVICE memory (count_ptr), grids are sized for
@@ -39,7 +44,6 @@ namespace sls {
 #endif
 constexpr int kSortRounds = SLS_SORT_ROUNDS;
 constexpr int kSortWaveItems = kWave * kSortRounds;  // 1024 items per wave
-constexpr int kSortWavesPerBlock = 4;
 constexpr int kSortMaxBins = 2048;   // 11-bit digits at most
 constexpr int kDepthKeyBits = 29;    // compressed depth key, see depth_order_key()
 
@@ -326,7 +330,6 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         return SLS_E_SCRATCH;
     }
     const int nchunks = (int)(((uint64_t)cap + kSortWaveItems - 1) / kSortWaveItems);
-    const int nblocks = (nchunks + kSortWavesPerBlock - 1) / kSortWavesPerBlock;
     uint32_t *cnt = (uint32_t *)scratch;
     int npasses, bits;
     sort_plan(nbits, npasses, bits);
@@ -345,7 +348,7 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         int rc;
         KeyT *kout = (drop_sorted_keys && p + 1 == npasses) ? nullptr : kb[dst];
 #define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kout, vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
-                                        nblocks, ranges_out, nranges, packed_val_mask, st)
+                                        0, ranges_out, nranges, packed_val_mask, st)
         switch (bits) {
         case 8: rc = SLS_PASS(8); break;
         case 9: rc = SLS_PASS(9); break;

@@ -120,6 +120,7 @@ class MappingEngine:
         self.keep_grads = False
         self._ws_ready = False
         self._ws_hw = None
+        self._ws_det = None
         self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
         # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
         # id(camera) -> [order tensor, iteration it was last written, weak reference to the camera (an id can be
@@ -134,8 +135,10 @@ class MappingEngine:
         # keyframe-parallel exchange (set up at the first sharded step)
         self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
         self._dp = None                   # dict(G, rank, C, flat, gshard) once the reduce-scatter layout is in place
+        self._dp_agreed, self._dp_use_rs = None, False    # (G, rank) the scheme was agreed for; the agreed verdict
         from .rasterizer import deterministic_mode
         self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
+        self.exchange_at_world_1 = False  # take the keyframe-parallel path (collectives + separate Adam) in a 1-rank group too
         self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
@@ -151,9 +154,13 @@ class MappingEngine:
 
     def _ensure_workspace(self, H, W, capacity):
         lib = _abi.lib()
-        if self.workspace is None or capacity > self.capacity or (H, W) != self._ws_hw:
+        if (self.workspace is None or capacity > self.capacity or (H, W) != self._ws_hw
+                or self._ws_det != bool(self.deterministic)):
+            self._ws_det = bool(self.deterministic)
             self.capacity, self._ws_hw = int(max(capacity, self.capacity)), (H, W)   # (keyframes of another size: re-carve)
-            nbytes = int(lib.sls_mapping_workspace_bytes(self.N, H, W, self.capacity))
+            wcfg = _abi.SlsMappingConfig()
+            wcfg.deterministic = 1 if self.deterministic else 0     # (the fixed-point accumulators only when asked for)
+            nbytes = int(lib.sls_mapping_workspace_bytes_cfg(self.N, H, W, self.capacity, C.byref(wcfg)))
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
             self._ws_ready = False
@@ -242,6 +249,13 @@ class MappingEngine:
             torch.cuda.current_stream(self.dev).cuda_stream),
             "sls_mapping_step")
 
+    def _sharded(self, group):
+        """Keyframe-parallel path?  World size > 1 — or 1 with `exchange_at_world_1` (the collectives then move
+        a rank's data onto itself: how the RCCL path is exercised on a one-GPU box)."""
+        if not dist.is_initialized():
+            return False
+        return dist.get_world_size(group) > 1 or self.exchange_at_world_1
+
     def _read_status(self):
         return self._parse_status(self.status.cpu())   # the one sync of the iteration
 
@@ -266,7 +280,7 @@ class MappingEngine:
         the previous one is read, so the GPU queue never runs dry while the host
         waits for a loss value; returns the PREVIOUS iteration's status (None on
         the first call) — finish with flush()."""
-        sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+        sharded = self._sharded(group)
         if self._dp is not None and not sharded:
             raise RuntimeError("this engine's optimiser state is sharded over a process group (dp_mode rs_ag): "
                                "it cannot take a single-process step")
@@ -313,7 +327,7 @@ class MappingEngine:
     def _step_lagged(self, camera):
         slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
         group = self._group
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if self._sharded(group):
             # keyframe-parallel: the group's verdict is known on the device only (the void flags ride the
             # gradient all-reduce and guard Adam), so the host can lag here exactly as on one GPU
             self._ensure_dp(group)
@@ -396,9 +410,24 @@ class MappingEngine:
         """First sharded step: lay the gradient bucket out for the reduce-scatter, move the four parameter tensors
         into ONE flat buffer (they stay torch Parameters: their storage becomes a view of it) and keep only this
         rank's 1/G of the Adam moments."""
-        if self._dp is not None or self.dp_mode != "rs_ag" or self.N % 2 != 0 or 10 * self.N >= 2 ** 32:
-            return
+        if self.dp_mode not in ("rs_ag", "allreduce"):
+            raise ValueError(f"dp_mode must be 'rs_ag' or 'allreduce', not {self.dp_mode!r}")
         G, rank, N = dist.get_world_size(group), dist.get_rank(group), self.N
+        if self._dp is not None:
+            if self._dp["G"] != G or self._dp["rank"] != rank:
+                raise RuntimeError("the process group changed under an engine whose optimiser state is sharded "
+                                   f"({self._dp['G']} ranks -> {G}): build a new engine (or remap(reset_state=True))")
+            return
+        if self._dp_agreed != (G, rank):
+            # every rank must run the SAME collective sequence: agree on the scheme once (MIN over ranks of
+            # "this rank can and wants to shard"), instead of trusting that SLS_DP_MODE / N agree everywhere
+            want = 1 if (self.dp_mode == "rs_ag" and N % 2 == 0 and 10 * N < 2 ** 32) else 0
+            t = torch.tensor([want], dtype=torch.int32, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            self._dp_use_rs = bool(int(t.item()))
+            self._dp_agreed = (G, rank)
+        if not self._dp_use_rs:
+            return
         C = dp_chunk(N, G)
         flat = torch.zeros((G * C,), dtype=torch.float32, device=self.dev)
         m = self.model
@@ -516,6 +545,9 @@ class MappingEngine:
         n_new = n_keep + int(appended)
         if int(self.model._xyz.shape[0]) != n_new:
             raise RuntimeError(f"the model holds {int(self.model._xyz.shape[0])} surfels, keep/appended describe {n_new}")
+        if self._dp is not None and not reset_state:      # (before any state is touched: the engine stays consistent)
+            raise RuntimeError("remap(reset_state=False) is not available once the optimiser state is sharded "
+                               "(keyframe-parallel mode rs_ag): use reset_state=True or dp_mode='allreduce'")
 
         if reset_state:
             self.exp_avg = torch.zeros((10 * n_new,), dtype=torch.float32, device=self.dev)
@@ -524,9 +556,7 @@ class MappingEngine:
         else:
             self.exp_avg = carry_bucket(self.exp_avg, keep, n_new)
             self.exp_avg_sq = carry_bucket(self.exp_avg_sq, keep, n_new)
-        if self._dp is not None and not reset_state:
-            raise RuntimeError("remap(reset_state=False) is not available once the optimiser state is sharded "
-                               "(keyframe-parallel mode rs_ag): use reset_state=True or dp_mode='allreduce'")
+        self._dp_agreed = None
         self._dp = None                               # re-sharded at the next keyframe-parallel step
         self.N = n_new
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)

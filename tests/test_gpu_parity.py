@@ -819,3 +819,64 @@ def test_engine_keyframe_parallel_two_ranks(device, tmp_path, dp_mode):
         total = total + eng.grads[:-2].cpu().numpy().astype(np.float64)
     scale = np.abs(total).max()
     assert np.abs(reduced - total).max() <= 1e-5 * scale
+
+
+def _engine_rccl_rank(rank, port, out_dir, dp_mode):
+    import os
+    import torch.distributed as dist
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # "nccl" IS RCCL on ROCm
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=31, range_lo=2.0, range_hi=15.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[0], data_device="cuda:0")
+
+    def run(exchange, lagged):
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+        eng = MappingEngine(model, MappingConfig())
+        eng.dp_mode = dp_mode
+        eng.exchange_at_world_1 = exchange
+        eng.deterministic = True           # integer-atomic accumulation: both paths must then agree to the bit
+        losses = []
+        if lagged:
+            sts = [eng.step(cam, sync="lagged") for _ in range(4)]
+            eng.flush()
+            losses = [s["loss"] for s in sts[1:]] + [s["loss"] for s in eng.flushed]
+        else:
+            losses = [eng.step(cam)["loss"] for _ in range(4)]
+        return model, eng, losses
+    ref, _, l_ref = run(False, False)
+    got, eng, l_got = run(True, False)
+    lag, eng_l, l_lag = run(True, True)
+    np.savez(os.path.join(out_dir, "rccl.npz"),
+             **{f"ref_{k}": getattr(ref, k).detach().cpu().numpy() for k in ("_xyz", "_rotation", "_scaling", "_opacity")},
+             **{f"got_{k}": getattr(got, k).detach().cpu().numpy() for k in ("_xyz", "_rotation", "_scaling", "_opacity")},
+             **{f"lag_{k}": getattr(lag, k).detach().cpu().numpy() for k in ("_xyz", "_rotation", "_scaling", "_opacity")},
+             l_ref=np.array(l_ref), l_got=np.array(l_got), l_lag=np.array(l_lag), sharded=int(eng._dp is not None),
+             in_place=int(eng._dp.get("ag_in_place", True)) if eng._dp else -1, t=eng.t, backend=dist.get_backend())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce"])
+def test_engine_exchange_through_rccl_world_1(device, tmp_path, dp_mode):
+    """The keyframe-parallel exchange executed by RCCL itself (backend "nccl", one rank, one GPU): reduce_scatter_tensor
+    -> Adam on the shard -> all_gather_into_tensor in place (rs_ag), or all_reduce -> Adam (allreduce).  With one
+    rank the collectives are identities, so — with deterministic accumulation — the parameters after 4 iterations
+    must equal the single-GPU path's (fused Adam inside the backward) to the bit, in the synchronous and in the
+    lagged mode."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_engine_rccl_rank, args=(port, str(tmp_path), dp_mode), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert str(r["backend"]) == "nccl" and int(r["t"]) == 4
+    assert int(r["sharded"]) == (1 if dp_mode == "rs_ag" else 0)
+    assert np.allclose(r["l_ref"], r["l_got"], rtol=1e-6) and np.allclose(r["l_ref"], r["l_lag"], rtol=1e-6)
+    for k in ("_xyz", "_rotation", "_scaling", "_opacity"):
+        assert np.array_equal(r["ref_" + k], r["got_" + k]), f"RCCL path differs from the single-GPU path: {k}"
+        assert np.array_equal(r["ref_" + k], r["lag_" + k]), f"RCCL path (lagged) differs: {k}"

@@ -1,0 +1,64 @@
+#!/bin/bash
+# VALU issue-rate calibration: tools/micro/valu_calib.hip once plain (clocks per
+# wave-instruction per SIMD by instruction class at 1/2/4/8 waves per SIMD, shader MHz) and once under the SAME
+# SQ counter pass as tools/pmc_sq.sh, so that "valu_issue_busy" is known at a known issue rate.
+#   (build here:  hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/micro/valu_calib.hip -o gpurun_tmp_valu_calib)
+#   gpurun -- 'bash tools/valu_calib.sh'   ->  gpurun_out/valu_calibration.json
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+BIN=$PWD/gpurun_tmp_valu_calib
+[ -x "$BIN" ] || { echo "build $BIN first"; exit 1; }
+timeout 120 "$BIN" /tmp/valu_plain.json | tee gpurun_out/valu_calibration.txt
+rm -rf /tmp/valu_pmc
+(cd /tmp && timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace \
+    --output-format csv -d /tmp/valu_pmc -o p -- "$BIN" /tmp/valu_underpmc.json > /tmp/valu_pmc.log 2>&1)
+python - <<'PY'
+import csv, glob, json, collections
+plain = json.load(open("/tmp/valu_plain.json"))
+cus = plain["cus"]
+names = ["v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mov_b32_dpp", "v_add_f32_dpp",
+         "v_permlane32_swap", "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b128", "v_fma_f32 chain", "v_exp_f32 chain",
+         "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix"]
+pmc = {}
+f = glob.glob("/tmp/valu_pmc/**/*counter_collection.csv", recursive=True)
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    by_disp = collections.OrderedDict()
+    for r in rows:
+        if "calib_kernel" not in r["Kernel_Name"]:
+            continue
+        d = by_disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "grid": int(r["Grid_Size"]),
+                                                       "wg": int(r["Workgroup_Size"])})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    seen = collections.Counter()
+    for did in sorted(by_disp):
+        d = by_disp[did]
+        op = int(d["name"].split("<")[1].split(">")[0].replace("(Op)", "").strip() or 0) if "<" in d["name"] else 0
+        blocks = d["grid"] // d["wg"]
+        w = d["wg"] // 256 * (blocks // cus)
+        key = (op, w)
+        seen[key] += 1
+        if seen[key] == 2:          # the first dispatch of a configuration is the 20-iteration warm-up
+            pmc[key] = d
+out = {"note": "tools/micro/valu_calib.hip on this device: clocks per wave-instruction per SIMD (s_memtime over the "
+               "timed loop / instructions issued on the SIMD), shader MHz from s_memtime against the 100 MHz wall clock; "
+               "SQ counters of the same dispatch from a separate rocprofv3 --pmc run.  valu_issue_busy_quad = "
+               "SQ_ACTIVE_INST_VALU / (SQ_BUSY_CYCLES/32 * 1024 / 4): the figure bench.py used to print as valu_frac.",
+       "device": plain["device"], "cus": cus, "rows": []}
+for r in plain["rows"]:
+    op = names.index(r["class"])
+    row = dict(r)
+    d = pmc.get((op, r["waves_per_simd"]))
+    if d and d.get("SQ_BUSY_CYCLES"):
+        slots = d["SQ_BUSY_CYCLES"] / 32 * 1024 / 4
+        row.update({k: d.get(k) for k in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")})
+        row["valu_issue_busy_quad"] = round(d.get("SQ_ACTIVE_INST_VALU", 0.0) / slots, 4)
+        if d.get("SQ_INSTS_VALU"):
+            row["quad_cycles_per_valu_inst"] = round(d.get("SQ_ACTIVE_INST_VALU", 0.0) / d["SQ_INSTS_VALU"], 4)
+            row["busy_clk_per_valu_inst_per_simd"] = round(d["SQ_BUSY_CYCLES"] / 32 * 1024 / d["SQ_INSTS_VALU"], 4)
+    out["rows"].append(row)
+json.dump(out, open("gpurun_out/valu_calibration.json", "w"), indent=1)
+for r in out["rows"]:
+    print(r["class"], r["waves_per_simd"], r["clk_per_inst_per_simd"], r.get("valu_issue_busy_quad"), r.get("quad_cycles_per_valu_inst"))
+PY
