@@ -79,6 +79,39 @@ def _latest_profile(pattern):
     return files[-1] if files else None
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (splat_loam_amd/csrc/*.hip|*.hpp|Makefile, include/*.h): what the replayed PMC
+    counters must have been measured on.  tools/pmc_*.sh store it in their JSON; bench.py compares (`stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "splat_loam_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "splat_loam_amd", "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(ROOT, "splat_loam_amd", "csrc", "Makefile")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def valu_calibration():
+    """Peak reading of the VALU counters on this hardware (tools/micro/valu_calib.hip, committed as
+    profiles/*valu_calibration.json): what `SQ_ACTIVE_INST_VALU / SIMD quad-cycles` shows for a stream of independent
+    v_fma_f32 at 4 resident waves per SIMD (the tile kernels' occupancy).  A kernel's calibrated VALU fraction is its
+    own reading divided by this."""
+    f = _latest_profile("*valu_calibration.json")
+    if not f:
+        return None
+    try:
+        rows = json.load(open(f))["rows"]
+        peak = [r for r in rows if r["class"] == "v_fma_f32" and r["waves_per_simd"] == 4][0]
+        return {"peak_valu_issue_busy_quad": peak["valu_issue_busy_quad"],
+                "fma_ns_per_inst_per_simd": peak["ns_per_inst_per_simd"],
+                "source": "profiles/" + os.path.basename(f)}
+    except Exception:
+        return None
+
+
 def pmc_traffic(slot, N, H, W):
     """HBM bytes per launch of the kernel behind a timing slot, REPLAYED from the newest committed PMC pass
     (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes, FETCH_SIZE x2 as
@@ -87,14 +120,15 @@ def pmc_traffic(slot, N, H, W):
     carries the file it came from; null for any other workload."""
     f = _latest_profile("*pmc_traffic.json")
     if (N, H, W) != (500_000, 64, 2048) or not f:
-        return None, None
+        return None, None, None
     try:
-        for name, v in json.load(open(f))["kernels"].items():
+        d = json.load(open(f))
+        for name, v in d["kernels"].items():
             if name.startswith(slot):
-                return int(v["hbm_bytes_corrected"]), "replayed from profiles/" + os.path.basename(f)
+                return int(v["hbm_bytes_corrected"]), "replayed from profiles/" + os.path.basename(f), d.get("kernel_source_hash")
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def pmc_valu(slot, N, H, W):
@@ -104,10 +138,14 @@ def pmc_valu(slot, N, H, W):
     if (N, H, W) != (500_000, 64, 2048) or not f:
         return None
     try:
-        for name, v in json.load(open(f))["kernels"].items():
+        d = json.load(open(f))
+        for name, v in d["kernels"].items():
             if name.startswith(slot):
-                return {"valu_issue_busy": v["valu_issue_busy"], "valu_insts": v["SQ_INSTS_VALU"],
-                        "source": "replayed from profiles/" + os.path.basename(f)}
+                return {"valu_issue_busy_quad": v["valu_issue_busy"], "valu_insts": v["SQ_INSTS_VALU"],
+                        "valu_active_quad_cycles": v.get("SQ_ACTIVE_INST_VALU"),
+                        "avg_waves_per_simd": v.get("avg_waves_per_simd"),
+                        "source": "replayed from profiles/" + os.path.basename(f),
+                        "kernel_source_hash": d.get("kernel_source_hash")}
     except Exception:
         pass
     return None
@@ -141,6 +179,16 @@ def main():
                     help="N > 1: gradient exchange.  rs_ag: reduce-scatter -> Adam on the rank's 1/N -> all-gather of "
                          "the parameters; allreduce: one all-reduce -> Adam everywhere; auto: time both for a few "
                          "un-timed iterations and take the faster one")
+    ap.add_argument("--iters-per-step", type=int, default=10,
+                    help="mapping iterations inside ONE bench step (the driver's --steps 20 then times 200 iterations: "
+                         "20 alone are 5 ms of GPU time, too few for a stable figure); ms_per_step is the time of a "
+                         "whole step, config.ms_per_iteration the time of one iteration")
+    ap.add_argument("--keyframes", type=int, default=8,
+                    help="size of the keyframe window an iteration draws its keyframe from, as Mapper.optimize does "
+                         "(slam/mapper.py:142-156: np.random.choice with sample_geometric(prob_view_last_keyframe)); "
+                         "1 = re-render one keyframe every iteration (round 1/2's headline, now extras.single_keyframe)")
+    ap.add_argument("--prob-view-last-keyframe", type=float, default=0.4,
+                    help="configs/kitti/kitti.yaml:22, utils/config_utils.py:104")
     ap.add_argument("--variant", type=int, nargs=2, default=None, metavar=("FWD", "BWD"),
                     help="tuning: tile-kernel pixel-block shapes (sls_debug_variant: 2 = 4x4, 3 = 8x2)")
     args = ap.parse_args()
@@ -257,7 +305,17 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0), one
 
-    cam = camera(rank)
+    from splat_loam_amd.slam_rules import keyframe_probabilities
+    ips = max(1, args.iters_per_step)
+    n_kf = max(1, args.keyframes)
+    # the keyframe window: poses 0.5 m apart.  Every iteration draws its keyframe as the mapper
+    # does; with N ranks each rank takes its own draw of the same seeded sequence
+    cams = [camera(k) for k in range(n_kf)]
+    kf_p = keyframe_probabilities(n_kf, args.prob_view_last_keyframe)
+    n_draws = (args.warmup + 2 * args.steps + 4) * ips * world
+    draws = np.random.default_rng(0).choice(n_kf, size=n_draws, p=kf_p)
+    pick_rank = draws[rank::world] if n_kf > 1 else None
+    cam = cams[0] if n_kf > 1 else camera(rank)
 
     # ---- N > 1: which gradient exchange?  (un-timed calibration on throw-away models, same verdict on every rank)
     dp_mode, dp_cal = None, None
@@ -268,7 +326,7 @@ def main():
             for m in ("rs_ag", "allreduce"):
                 mdl, eng = fresh(dp_mode=m)
                 try:
-                    dt_m, _ = run(mdl, eng, [cam], 3, 10)
+                    dt_m, _ = run(mdl, eng, cams if n_kf > 1 else [cam], 3, 10, pick=pick_rank)
                     ok = 1.0
                 except Exception as e:          # (a collective the backend does not offer: the other scheme stays)
                     log(f"dp_mode {m} failed: {e}")
@@ -286,7 +344,8 @@ def main():
     timing = not args.no_timing
     # events around the dominant kernel only (2 per step, ~10 us): it is timed live inside the
     # timed region without the ~0.2 ms/step that 60 event records per step would add
-    dt, step = run(model, engine, [cam], args.warmup, args.steps,
+    n_iters = args.steps * ips
+    dt, step = run(model, engine, cams if n_kf > 1 else [cam], args.warmup * ips, n_iters, pick=pick_rank,
                    after_warmup=(lambda: lib.sls_timing_enable(3)) if timing else None)
     if engine is not None and status_read is False:
         assert not engine._read_status()["overflow"], "instance buffers overflowed during the timed region"
@@ -298,15 +357,15 @@ def main():
         lib.sls_timing_collect(tot, cnt)
         return {lib.sls_timing_name(s).decode(): (tot[s], int(cnt[s])) for s in range(ns) if cnt[s]}
 
-    log(f"headline: {dt / args.steps * 1e3:.4f} ms/step")
+    log(f"headline: {dt / args.steps * 1e3:.4f} ms/step = {dt / n_iters * 1e3:.4f} ms/iteration")
     kernels, live, comm = {}, {}, None
     if timing:
         live = collect()                     # render_bwd, measured inside the timed region
         lib.sls_timing_enable(1)             # every launch, in an extra un-timed pass of the same steps
         if engine is not None and world > 1:
             engine.comm_events = []
-        for i in range(args.steps):
-            step(args.warmup + args.steps + i)
+        for i in range(n_iters):
+            step(args.warmup * ips + n_iters + i)
         if engine is not None:
             engine.flush()
         barrier()
@@ -333,28 +392,34 @@ def main():
             dist.destroy_process_group()
         return
 
-    # workload statistics from one un-timed forward (R, R_eff, surfels the backward reaches)
+    # workload statistics from un-timed forwards of the model as the timed iterations left it (R, R_eff, surfels the
+    # backward reaches): one per keyframe of the window, averaged with the sampling probabilities
     from splat_loam_amd.rasterizer import GaussianRasterizationSettings, rasterize_forward
-    with torch.no_grad():
-        st = rasterize_forward(GaussianRasterizationSettings(H, W, 1.0, cam.world_view_transform,
-                                                             cam.projection_matrix, False, False),
-                               model.get_xyz, model.get_opacity, model.get_scaling, model.get_rotation)
-        R = st.R
-        cons = st.tile_consumed.long() & 0xFFFFFFFF
-        R_eff = int(cons.sum().item())
-        N_touched = 0
-        if R > 0:
-            start = st.ranges.view(-1, 2)[:, 0].long() & 0xFFFFFFFF
-            delta = torch.zeros((R + 1,), dtype=torch.int32, device=dev)
-            delta.index_add_(0, start, torch.ones_like(start, dtype=torch.int32))
-            delta.index_add_(0, start + cons, -torch.ones_like(start, dtype=torch.int32))
-            in_prefix = torch.cumsum(delta[:R], 0) > 0
-            N_touched = int(torch.unique(st.vals[:R][in_prefix]).numel())
+
+    def workload(c):
+        with torch.no_grad():
+            st = rasterize_forward(GaussianRasterizationSettings(H, W, 1.0, c.world_view_transform,
+                                                                 c.projection_matrix, False, False),
+                                   model.get_xyz, model.get_opacity, model.get_scaling, model.get_rotation)
+            cons = st.tile_consumed.long() & 0xFFFFFFFF
+            touched = 0
+            if st.R > 0:
+                start = st.ranges.view(-1, 2)[:, 0].long() & 0xFFFFFFFF
+                delta = torch.zeros((st.R + 1,), dtype=torch.int32, device=dev)
+                delta.index_add_(0, start, torch.ones_like(start, dtype=torch.int32))
+                delta.index_add_(0, start + cons, -torch.ones_like(start, dtype=torch.int32))
+                in_prefix = torch.cumsum(delta[:st.R], 0) > 0
+                touched = int(torch.unique(st.vals[:st.R][in_prefix]).numel())
+            return st.R, int(cons.sum().item()), touched
+    per_kf = [workload(c) for c in (cams if n_kf > 1 else [cam])]
+    wts = kf_p if n_kf > 1 else np.array([1.0])
+    R, R_eff, N_touched = (int(round(float(np.dot(wts, [w[k] for w in per_kf])))) for k in range(3))
     tw, th = _abi.tile_size()
     P = H * W
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * N / (dt / args.steps) / 1e6
+    ms_per_iter = dt / n_iters * 1e3
+    value = world * N * ips / (dt / args.steps) / 1e6
 
     roofline = None
     breakdown = {}
@@ -362,28 +427,42 @@ def main():
         for name, (ms, c) in kernels.items():
             avg_us = ms / c * 1e3
             b = algorithmic_bytes(name, N, R, R_eff, P, N_touched)
-            breakdown[name] = {"launches_per_step": c / args.steps, "avg_us": round(avg_us, 2),
-                               "us_per_step": round(ms / args.steps * 1e3, 2),
+            breakdown[name] = {"launches_per_iteration": round(c / n_iters, 3), "avg_us": round(avg_us, 2),
+                               "us_per_iteration": round(ms / n_iters * 1e3, 2),
                                "alg_bytes_per_launch": int(b),
                                "GBps": round(b / (avg_us * 1e-6) / 1e9, 1) if avg_us > 0 else None}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, c = kernels[dom]
         b = algorithmic_bytes(dom, N, R, R_eff, P, N_touched)
         ach = b / (ms / c * 1e-3) / 1e9
-        traffic, traffic_source = pmc_traffic(dom, N, H, W)
+        traffic, traffic_source, traffic_hash = pmc_traffic(dom, N, H, W)
         valu = pmc_valu(dom, N, H, W)
+        cal = valu_calibration()
         hbm_frac = ach / HBM_PEAK_GBS
-        # what limits the dominant kernel, from evidence: the fraction of the HBM roofline its algorithmic bytes
-        # reach (measured live) against the fraction of the SIMDs' VALU issue slots it keeps busy (SQ counters)
-        bound = "valu" if (valu and valu["valu_issue_busy"] > hbm_frac) else "hbm"
+        src_hash = kernel_source_hash()
+        # counters are REPLAYED from committed rocprofv3 passes (rocprofv3 cannot wrap the process it is called from):
+        # they describe this build only if the kernel sources hash to what the pass was measured on
+        stale = bool((traffic is not None and traffic_hash != src_hash) or
+                     (valu is not None and valu.get("kernel_source_hash") != src_hash))
+        # VALU side, calibrated: the raw reading SQ_ACTIVE_INST_VALU / SIMD quad-cycles is 1.6-1.8 —
+        # not 1.0 — when a SIMD issues independent v_fma_f32 back to back (tools/micro/valu_calib.hip: one wave64
+        # VALU instruction per ~2.3 clocks), so the kernel's reading is divided by that peak
+        valu_frac = None
+        if valu and cal:
+            valu_frac = round(valu["valu_issue_busy_quad"] / cal["peak_valu_issue_busy_quad"], 4)
+        bound = "valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm"
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(hbm_frac, 5), "hbm_frac": round(hbm_frac, 5),
-                    "valu_frac": valu["valu_issue_busy"] if valu else None,
-                    "traffic": traffic, "traffic_source": traffic_source,
+                    "valu_frac": valu_frac, "valu_calibration": cal,
+                    "traffic": traffic, "traffic_source": traffic_source, "stale": stale,
+                    "kernel_source_hash": src_hash,
                     "avg_launch_us": round(ms / c * 1e3, 2), "alg_bytes_per_launch": int(b), "valu": valu,
                     "note": "achieved/frac: algorithmic bytes / live HIP-event time of this run against the HBM peak "
-                            "(the contract's figure); bound: the tile kernels are limited by VALU issue, not by HBM "
-                            "(DESIGN.md section 4)"}
+                            "(the contract's figure).  valu_frac: the kernel's VALU counter reading relative to what "
+                            "the same counter shows at the measured peak issue rate of plain FP32 instructions; the "
+                            "step loops are made of half- and quarter-rate classes (DPP, v_cmp, packed, lane swaps, "
+                            "exp/rcp), weighted by their measured rates the issue port is ~0.75 busy (DESIGN.md section 4). "
+                            "stale: the replayed counters were measured on other kernel sources than this build's"}
         fb_ms = sum(kernels[k][0] / kernels[k][1] for k in ("render_fwd", "render_bwd") if k in kernels)
         if fb_ms > 0:
             fb_b = (algorithmic_bytes("render_fwd", N, R, R_eff, P, N_touched)
@@ -396,26 +475,26 @@ def main():
     log("per-kernel pass done")
     if world == 1 and engine is not None and not args.no_extras:
         extras = {}
+        # round 1/2's headline: ONE keyframe re-rendered every iteration (its depth order repaired each time)
+        m1, e1 = fresh()
+        d1, _ = run(m1, e1, [cams[0]], args.warmup * ips, n_iters)
+        extras["single_keyframe"] = {"ms_per_iteration": round(d1 / n_iters * 1e3, 4),
+                                     "Msplats_per_s": round(N / (d1 / n_iters) / 1e6, 1),
+                                     "repeated_iterations": dict(e1.stats)}
+        del m1, e1
         m2, e2 = fresh(full_sort=True)
-        d2, _ = run(m2, e2, [cam], args.warmup, args.steps)
-        extras["ms_per_step_full_sort"] = round(d2 / args.steps * 1e3, 4)
+        d2, _ = run(m2, e2, cams if n_kf > 1 else [cam], args.warmup * ips, n_iters, pick=pick_rank)
+        extras["ms_per_iteration_full_sort"] = round(d2 / n_iters * 1e3, 4)
         del m2, e2
         m3, e3 = fresh()
-        d3, _ = run(m3, e3, [cam], 200, 200)
-        extras["ms_per_step_steps_200_400"] = round(d3 / 200 * 1e3, 4)
-        extras["repeated_iterations_steps_0_400"] = dict(e3.stats)
+        d3, _ = run(m3, e3, cams if n_kf > 1 else [cam], 400, 400, pick=np.random.default_rng(1).choice(n_kf, size=800, p=kf_p) if n_kf > 1 else None)
+        extras["ms_per_iteration_400_800"] = round(d3 / 400 * 1e3, 4)
+        extras["repeated_iterations_0_800"] = dict(e3.stats)
         del m3, e3
-        # eight keyframes of the window, one drawn at random per iteration as slam/mapper.py:152-153 does
-        m4, e4 = fresh()
-        cams8 = [camera(k) for k in range(8)]
-        pick = np.random.default_rng(0).integers(0, 8, size=16 + 200)
-        d4, _ = run(m4, e4, cams8, 16, 200, pick=pick)
-        extras["ms_per_step_8_keyframes_sampled"] = round(d4 / 200 * 1e3, 4)
-        extras["repeated_iterations_8_keyframes"] = dict(e4.stats)
-        extras["note"] = ("same scene and size as the headline; full_sort: depth order sorted from scratch every "
-                          "iteration; steps_200_400: 200 timed iterations after 200 un-timed ones; 8_keyframes: 200 "
-                          "iterations, the keyframe drawn uniformly from 8 poses 0.5 m apart each iteration")
-        del m4, e4
+        extras["note"] = ("same scene, size and keyframe sampling as the headline unless said otherwise; single_keyframe: one "
+                          "keyframe re-rendered every iteration; full_sort: depth order sorted from scratch every "
+                          "iteration; 400_800: 400 timed iterations after 400 un-timed ones (the optimisation changes "
+                          "the workload as it proceeds)")
 
     cpu = None
     log("extras done")
@@ -427,15 +506,21 @@ def main():
         "metric": "fwd+bwd Msplats/s", "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU: render fwd + mapper loss + bwd + fused Adam"
+        "config": {"workload": f"{N} surfels, {H}x{W} spherical, 1 keyframe/GPU per iteration drawn from a window of "
+                               f"{n_kf} keyframes as Mapper.optimize does (sample_geometric, p={args.prob_view_last_keyframe}): "
+                               "render fwd + mapper loss + bwd + fused Adam"
                                + {"engine": " (one native sls_mapping_step per iteration)",
                                   "fused": " (torch autograd + HIP loss consumer)",
                                   "unfused": " (torch loss glue)"}[args.mode],
+                   "iterations_per_step": ips, "ms_per_iteration": round(ms_per_iter, 5),
+                   "step": f"one bench step = {ips} mapping iterations ({args.steps} steps = {n_iters} timed iterations)",
                    "N": N, "H": H, "W": W, "tile": [tw, th], "R": R, "R_eff": R_eff, "N_touched": N_touched,
+                   "keyframes": n_kf, "keyframe_probabilities": [round(float(x), 4) for x in kf_p],
                    "parallelism": f"keyframe-dp{world}",
                    "status_read": {True: "sync", False: "async", "lagged": "lagged-1"}[status_read]
                    if engine is not None else "torch",
-                   "depth_order": ("repaired from the previous iteration, verified exact"
+                   "depth_order": ("per keyframe: repaired from the keyframe's last order while it is at most 12 "
+                                   "iterations old (verified exact), else sorted from scratch"
                                    if (engine is not None and engine.reuse_depth_order and status_read is not False)
                                    else "sorted from scratch"),
                    "repeated_iterations": dict(engine.stats) if engine is not None else None},
@@ -451,22 +536,23 @@ def main():
 
 
 def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
-    """The CPU legs (rank 0, 1 GPU only; bounded to roughly 10-30 s of CPU work).  Primary = the baseline
-    BASELINE.json names: the pure-PyTorch tile rasterizer (oracle/torch_tiles.py), one WHOLE mapping iteration
-    (activations, render, render() post-processing + mapper loss in torch, autograd backward, torch.optim.Adam) on
-    a stated subset of the tiles of the same scene, extrapolated to the image by the tile count.
-    Also reported: the same at 50k surfels / 64x1024, and the C/OpenMP checker (rasterizer only, every core)."""
+    """The CPU legs (rank 0, 1 GPU only).  Primary = the baseline BASELINE.json names: the pure-PyTorch tile
+    rasterizer (oracle/torch_tiles.py), one WHOLE mapping iteration (activations, render, render() post-processing
+    + mapper loss in torch, autograd backward, torch.optim.Adam).
+      * thread count: swept over 32 / 64 / all host threads on a small tile subset, the fastest is used and reported;
+      * the headline workload (500k surfels, 64x2048): a stated subset of the tiles, extrapolated by the tile count
+        (SURVEY.md section 8d allows it for N = 500k);
+      * SURVEY.md section 8d's mandatory case, 50k surfels at 64x1024 with EVERY tile: one warm-up, then the median
+        of 5 whole iterations.
+    Also reported: the C/OpenMP checker (rasterizer forward + backward only, every core)."""
     from splat_loam_amd import synth
-    # torch's intra-op pool: the per-tile tensors are (entries x 256) — beyond a few dozen threads the fork/join
-    # cost of every small op outweighs the work, so the pool is capped and the count that was USED is reported
-    cores = min(os.cpu_count() or 1, 32)
-    out = {"value": None, "unit": "Msplats/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port", "sample": None}
+    host = os.cpu_count() or 1
+    out = {"value": None, "unit": "Msplats/s", "cores": None, "host_cores": host, "kind": "port", "sample": None}
     try:
         from oracle import torch_tiles as tt
         from splat_loam_amd.mapping import mapping_loss
         from splat_loam_amd.renderer import postprocess
         from splat_loam_amd.scene import Camera, SurfelModel
-        torch.set_num_threads(cores)
 
         def torch_iteration(sc, Hh, Ww, tiles):
             view, proj = synth.camera_matrices(sc["K"], poses[0])
@@ -483,6 +569,21 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
             model.optimizer.step()
             return time.perf_counter() - t0
 
+        sc2 = synth.make_scene(50_000, 64, 1024, seed=0)
+        T2 = ((1024 + tile[0] - 1) // tile[0]) * ((64 + tile[1] - 1) // tile[1])
+        # ---- thread sweep (the per-tile tensors are (entries x 256): a larger pool mostly adds fork/join cost)
+        sweep = {}
+        probe = sorted(set(int(i * T2 / 12) for i in range(12)))
+        for th in sorted(set(t for t in (32, 64, host) if t <= host)):
+            torch.set_num_threads(th)
+            torch_iteration(sc2, 64, 1024, probe[:2])                      # warm the pool
+            sweep[th] = round(torch_iteration(sc2, 64, 1024, probe), 3)
+        cores = min(sweep, key=sweep.get)
+        torch.set_num_threads(cores)
+        out["cores"] = cores
+        out["thread_sweep_s"] = {str(k): v for k, v in sweep.items()}
+        log(f"cpu baseline: thread sweep {sweep} -> {cores}")
+
         def timed_subset(sc, Hh, Ww, n_sc, budget_s):
             """iteration time extrapolated from as many evenly spaced tiles as fit the budget."""
             T = ((Ww + tile[0] - 1) // tile[0]) * ((Hh + tile[1] - 1) // tile[1])
@@ -498,14 +599,18 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
 
         v, how = timed_subset(scene, H, W, N, 4.0)
         out.update(value=round(v, 5), sample=f"pure-PyTorch tile rasterizer (oracle/torch_tiles.py, float32, {cores} torch "
-                   f"threads): one whole mapping iteration (render + loss + autograd backward + torch Adam) of the same "
-                   f"{N}-surfel {H}x{W} scene; {how}")
+                   f"threads, the fastest of {sorted(sweep)}): one whole mapping iteration (render + loss + autograd "
+                   f"backward + torch Adam) of the same {N}-surfel {H}x{W} scene; {how}")
         log("cpu baseline: torch 500k subset done")
-        sc2 = synth.make_scene(50_000, 64, 1024, seed=0)
-        v2, how2 = timed_subset(sc2, 64, 1024, 50_000, 4.0)
-        out["torch_50k_64x1024"] = {"value": round(v2, 5), "unit": "Msplats/s",
-                                    "sample": "the same iteration, 50k surfels at 64x1024; " + how2}
-        log("cpu baseline: torch 50k done")
+        # ---- 50k / 64x1024, every tile, warm-up + median of 5
+        torch_iteration(sc2, 64, 1024, None)
+        times = sorted(torch_iteration(sc2, 64, 1024, None) for _ in range(5))
+        med = times[2]
+        out["torch_50k_64x1024"] = {"value": round(50_000 / med / 1e6, 5), "unit": "Msplats/s", "cores": cores,
+                                    "seconds_median_of_5": round(med, 3), "seconds_all": [round(t, 3) for t in times],
+                                    "sample": "the same iteration, 50k surfels at 64x1024, EVERY tile: one warm-up, "
+                                              "then 5 whole iterations, median"}
+        log("cpu baseline: torch 50k (every tile, median of 5) done")
     except Exception as e:  # the baseline is a report, never a reason to lose the bench line
         out["sample"] = f"pure-PyTorch baseline failed: {e}"
     try:

@@ -61,6 +61,14 @@ typedef struct SlsCamera {
     float pad;
     float Rvw[9];           /* row-major: p_view = Rvw * p_world + tvw          */
     float tvw[3];
+    float pix_offset[2];    /* D1: pixel (c, r) has image coordinate (c + pix_offset[0], r + pix_offset[1]) in
+                             * K-space.  (0, 0) = the lineage convention `pixf = (float)pix` (default, set by
+                             * sls_camera_from_matrices); (-0.5, -0.5) = the convention of the reference's own
+                             * back-projection and projector (utils/graphic_utils.py:46-49,
+                             * scene/preprocessing.py:42-64).  Honoured by the pixel rays (sls_ray_tables), the
+                             * centre pixel and with it the tile rectangle, the low-pass term and every cull:
+                             * the rasterizer works with the principal point (cx - pix_offset[0],
+                             * cy - pix_offset[1]), each rounded once in float. */
 } SlsCamera;
 
 const char *sls_last_error(void);
@@ -79,11 +87,13 @@ int sls_camera_from_matrices(const float *view_host, const float *proj_host, int
                              float scale_modifier, SlsCamera *out);
 
 /* Host helper: per-column (cos az, sin az) and per-row (cos el, sin el) of the
- * pixel rays, evaluated in double and rounded once.  col_cs_host: 2*W floats,
- * row_cs_host: 2*H floats.  The caller uploads them (they depend on K only). */
+ * pixel rays at the camera's pix_offset, evaluated in double and rounded once.
+ * col_cs_host: 2*W floats, row_cs_host: 2*H floats.  The caller uploads them
+ * (they depend on K and pix_offset only). */
 int sls_ray_tables(const SlsCamera *cam, float *col_cs_host, float *row_cs_host);
-/* Same at image coordinate (c + col_offset, r + row_offset); the reference's
- * back-projection uses (-0.5, -0.5) (utils/graphic_utils.py:46-49). */
+/* Same at image coordinate (c + col_offset, r + row_offset) whatever cam->pix_offset
+ * says; the reference's back-projection uses (-0.5, -0.5) (utils/graphic_utils.py:46-49),
+ * which is what sls_consumer_fwd_bwd / sls_mapping_step expect as col_cs_half / row_cs_half. */
 int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, float *col_cs_host,
                       float *row_cs_host);
 

@@ -58,7 +58,7 @@ class Camera:
     """
 
     def __init__(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16),
-                 wrap=None, dtype=np.float32):
+                 wrap=None, dtype=np.float32, pix_offset=(0.0, 0.0)):
         V = np.asarray(viewmatrix, dtype=np.float64)
         Pm = np.asarray(projmatrix, dtype=np.float64)
         K = Pm[:3, :3].T
@@ -66,6 +66,12 @@ class Camera:
         self.H, self.W = int(H), int(W)
         self.tile = (int(tile[0]), int(tile[1]))
         self.fx, self.fy, self.cx, self.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+        # D1 as a parameter (SlsCamera.pix_offset): pixel (c, r) sits at image coordinate (c + ox, r + oy) — the
+        # rasterizer works with the principal point (cx - ox, cy - oy), ONE subtraction in the working precision
+        self.pix_offset = (float(pix_offset[0]), float(pix_offset[1]))
+        dt = np.dtype(dtype).type
+        self.cx = float(dt(self.cx) - dt(self.pix_offset[0]))
+        self.cy = float(dt(self.cy) - dt(self.pix_offset[1]))
         if wrap is None:
             wrap = should_wrap(self.fx, self.W, self.tile[0])
         self.wrap = int(bool(wrap))
@@ -103,8 +109,8 @@ class Oracle:
     def _r(self, a):
         return np.ascontiguousarray(a, dtype=self.dtype)
 
-    def camera(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16), wrap=None):
-        return Camera(H, W, viewmatrix, projmatrix, scale_modifier, tile, wrap, self.dtype)
+    def camera(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16), wrap=None, pix_offset=(0.0, 0.0)):
+        return Camera(H, W, viewmatrix, projmatrix, scale_modifier, tile, wrap, self.dtype, pix_offset)
 
     def ray_tables(self, cam: Camera):
         col = np.empty((cam.W, 2), self.dtype)

@@ -61,7 +61,10 @@ enum { FC_FX = 0, FC_FY, FC_CX, FC_CY, FC_MOD, FC_NEAR, FC_FAR, FC_R = 7, FC_T =
 int or_real_bytes(void) { return (int)sizeof(real); }
 
 /* ------------------------------------------------------------------ */
-/* Ray tables.  Pixel (c, r) has image coordinate (c, r) (D1):         */
+/* Ray tables.  Pixel (c, r) has image coordinate (c, r) (D1); with a    */
+/* pixel-centre offset (SlsCamera.pix_offset, oracle.py:Camera) the     */
+/* caller passes the principal point (cx - ox, cy - oy) in FC_CX/FC_CY, */
+/* which moves rays, centre pixel, rectangle and low-pass term alike:   */
 /*   az = (c - cx)/fx, el = (r - cy)/fy                                */
 /*   ray = (cos az cos el, sin az cos el, sin el)                      */
 /* utils/graphic_utils.py:46-59 (without its -0.5 offset, see D1).     */

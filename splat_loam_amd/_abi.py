@@ -22,6 +22,7 @@ class SlsCamera(C.Structure):
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("scale_modifier", C.c_float), ("near_cut", C.c_float), ("far_cut", C.c_float), ("pad", C.c_float),
         ("Rvw", C.c_float * 9), ("tvw", C.c_float * 3),
+        ("pix_offset", C.c_float * 2),
     ]
 
 

@@ -223,24 +223,34 @@ int sls_camera_from_matrices(const float *view, const float *proj, int H, int W,
     return SLS_OK;
 }
 
+// rays of pixel (c, r) at image coordinate (c + oc, r + orow) for a principal point (cx, cy)
+static void ray_tables_for(const SlsCamera *cam, double oc, double orow, double cx, double cy, float *col_cs, float *row_cs)
+{
+    for (int c = 0; c < cam->W; ++c) {
+        const double a = ((double)c + oc - cx) / (double)cam->fx;
+        col_cs[2 * c] = (float)cos(a);
+        col_cs[2 * c + 1] = (float)sin(a);
+    }
+    for (int r = 0; r < cam->H; ++r) {
+        const double e = ((double)r + orow - cy) / (double)cam->fy;
+        row_cs[2 * r] = (float)cos(e);
+        row_cs[2 * r + 1] = (float)sin(e);
+    }
+}
+
 int sls_ray_tables(const SlsCamera *cam, float *col_cs, float *row_cs)
 {
-    return sls_ray_tables_at(cam, 0.0f, 0.0f, col_cs, row_cs);
+    SLS_REQUIRE(cam && col_cs && row_cs, "null pointer");
+    // the rasterizer's own rays: the principal point the kernels use (make_devcam), rounded to float as there
+    const DevCam dc = make_devcam(*cam);
+    ray_tables_for(cam, 0.0, 0.0, (double)dc.cx, (double)dc.cy, col_cs, row_cs);
+    return SLS_OK;
 }
 
 int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, float *col_cs, float *row_cs)
 {
     SLS_REQUIRE(cam && col_cs && row_cs, "null pointer");
-    for (int c = 0; c < cam->W; ++c) {
-        const double a = ((double)c + (double)col_offset - (double)cam->cx) / (double)cam->fx;
-        col_cs[2 * c] = (float)cos(a);
-        col_cs[2 * c + 1] = (float)sin(a);
-    }
-    for (int r = 0; r < cam->H; ++r) {
-        const double e = ((double)r + (double)row_offset - (double)cam->cy) / (double)cam->fy;
-        row_cs[2 * r] = (float)cos(e);
-        row_cs[2 * r + 1] = (float)sin(e);
-    }
+    ray_tables_for(cam, (double)col_offset, (double)row_offset, (double)cam->cx, (double)cam->cy, col_cs, row_cs);
     return SLS_OK;
 }
 

@@ -96,7 +96,10 @@ inline DevCam make_devcam(const SlsCamera &c)
     d.H = c.H; d.W = c.W; d.wrap = c.wrap;
     d.GX = (c.W + kTileW - 1) / kTileW;
     d.GY = (c.H + kTileH - 1) / kTileH;
-    d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+    d.fx = c.fx; d.fy = c.fy;
+    // D1 as a parameter: pixel (c, r) sits at image coordinate (c + ox, r + oy), i.e. the kernels see the
+    // principal point (cx - ox, cy - oy) — one float subtraction, the same the checker makes
+    d.cx = c.cx - c.pix_offset[0]; d.cy = c.cy - c.pix_offset[1];
     d.mod = c.scale_modifier; d.near_c = c.near_cut; d.far_c = c.far_cut;
     for (int i = 0; i < 9; ++i) d.R[i] = c.Rvw[i];
     for (int i = 0; i < 3; ++i) d.t[i] = c.tvw[i];

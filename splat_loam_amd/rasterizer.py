@@ -31,6 +31,31 @@ class GaussianRasterizationSettings(NamedTuple):
     projmatrix: torch.Tensor   # (4,4), [:3,:3] = K^T            scene/cameras.py:47-50
     prefiltered: bool = False
     debug: bool = False
+    # extension (not a reference field; the tree builds the settings with the seven keywords above): D1 as a
+    # parameter.  Pixel (c, r) has image coordinate (c + ox, r + oy).  None -> the process default (pix_offset()):
+    # (0, 0), the lineage convention; (-0.5, -0.5) is the convention of the reference's own back-projection and
+    # projector (utils/graphic_utils.py:46-49), under which a rendered keyframe registers without the half-pixel bias
+    pix_offset: Optional[tuple] = None
+
+
+_PIX_OFFSET = None
+
+
+def pix_offset() -> tuple:
+    """Process default of D1's pixel-centre offset: set_pix_offset(), else SLS_PIX_OFFSET="ox,oy", else (0, 0)."""
+    global _PIX_OFFSET
+    if _PIX_OFFSET is None:
+        env = os.environ.get("SLS_PIX_OFFSET", "")
+        _PIX_OFFSET = tuple(float(v) for v in env.split(",")) if env else (0.0, 0.0)
+        if len(_PIX_OFFSET) != 2:
+            raise ValueError("SLS_PIX_OFFSET must be 'ox,oy'")
+    return _PIX_OFFSET
+
+
+def set_pix_offset(ox: float, oy: float) -> None:
+    """For a caller that cannot touch the settings (gaussian_renderer/__init__.py builds them itself)."""
+    global _PIX_OFFSET
+    _PIX_OFFSET = (float(ox), float(oy))
 
 
 # ---------------------------------------------------------------------------
@@ -49,7 +74,7 @@ _TABLE_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
 def _ray_tables(cam: _abi.SlsCamera, device: torch.device):
-    key = (cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, str(device))
+    key = (cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, cam.pix_offset[0], cam.pix_offset[1], str(device))
     hit = _TABLE_CACHE.get(key)
     if hit is not None:
         _TABLE_CACHE.move_to_end(key)
@@ -66,8 +91,10 @@ def _ray_tables(cam: _abi.SlsCamera, device: torch.device):
 
 def get_camera(settings: GaussianRasterizationSettings, device: torch.device) -> _CamEntry:
     v, p = settings.viewmatrix, settings.projmatrix
+    off = getattr(settings, "pix_offset", None)
+    off = pix_offset() if off is None else (float(off[0]), float(off[1]))
     key = (v.data_ptr(), v._version, p.data_ptr(), p._version, int(settings.image_height),
-           int(settings.image_width), float(settings.scale_modifier), str(device))
+           int(settings.image_width), float(settings.scale_modifier), off, str(device))
     hit = _CAM_CACHE.get(key)
     if hit is not None:
         _CAM_CACHE.move_to_end(key)
@@ -81,6 +108,7 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
     _abi.check(_abi.lib().sls_camera_from_matrices(vh.data_ptr(), ph.data_ptr(), int(settings.image_height),
                                                    int(settings.image_width), float(settings.scale_modifier),
                                                    C.byref(e.cam)), "sls_camera_from_matrices")
+    e.cam.pix_offset[0], e.cam.pix_offset[1] = off
     e.col_cs, e.row_cs = _ray_tables(e.cam, device)
     e.view_ref, e.proj_ref = v, p
     _CAM_CACHE[key] = e

@@ -96,3 +96,50 @@ def test_g5_mapper_optimize_trajectory():
         moved = np.abs(ref - init).max()
         assert moved > 0
         assert np.abs(got - ref).max() <= 2e-3 * moved + 1e-7, name
+
+
+def test_g6_slam_rules_against_the_reference():
+    """The rules that size the hot path's workload (splat_loam_amd/slam_rules.py) against the reference's own
+    functions: compute_depth_gradient (utils/graphic_utils.py:91-106), sample_geometric
+    (utils/sampling_utils.py:11-20; also the golden G3 cases) and Tracker.require_new_keyframe's truth table
+    (slam/tracker.py:61-84, evaluated by the reference's method when the fixture was made)."""
+    from splat_loam_amd import slam_rules as sr
+    g = np.load(os.path.join(GOLD, "g6_slam_rules.npz"))
+    dg = sr.compute_depth_gradient(torch.from_numpy(g["depth"]), torch.from_numpy(g["valid"])).numpy()
+    assert np.array_equal(dg, g["depth_gradient"])
+    g3 = np.load(os.path.join(GOLD, "g3_utils.npz"))
+    for key, (n, p) in {"geom_1_4": (1, 0.4), "geom_5_4": (5, 0.4), "geom_8_7": (8, 0.7)}.items():
+        assert np.allclose(sr.sample_geometric(n, p), g3[key], rtol=1e-12, atol=0)
+    assert np.allclose(sr.sample_geometric(8, 0.4), g["geom_8_4"], rtol=1e-12)
+    assert np.allclose(sr.keyframe_probabilities(2, 0.4), g["geom_2_4"], rtol=1e-12)
+    assert np.allclose(sr.keyframe_probabilities(4, None), 0.25) and np.allclose(sr.keyframe_probabilities(4, -1.0), 0.25)
+    for nfr, fit, dist, t_n, t_f, t_d, want in g["keyframe_rule"]:
+        T = np.eye(4); T[0, 3] = dist
+        got = sr.require_new_keyframe(int(nfr), fit, T, int(t_n), t_f, t_d)
+        assert got == bool(want), (nfr, fit, dist, t_n, t_f, t_d)
+
+
+def test_densify_selection_follows_the_mapper():
+    """slam/mapper.py:51-102 restated: candidates = valid & alpha <= threshold (| the depth-error quantile mask),
+    int(percentage * #candidates) of them drawn without replacement, weighted by the log-depth gradient."""
+    from splat_loam_amd import slam_rules as sr
+    g = np.load(os.path.join(GOLD, "g6_slam_rules.npz"))
+    depth, valid = torch.from_numpy(g["depth"]), torch.from_numpy(g["valid"])
+    rng = np.random.default_rng(0)
+    alpha = torch.from_numpy(rng.uniform(size=depth.shape).astype(np.float32))
+    cand = sr.densify_candidates(valid, alpha, depth * 1.1, depth, 0.5, -1.0)
+    assert np.array_equal(cand.numpy(), (alpha[0].numpy() <= 0.5) & (g["valid"][0] == 1))
+    first = sr.densify_candidates(valid, initialize_model=True)
+    assert np.array_equal(first.numpy(), g["valid"][0] == 1)
+    sd = depth.clone(); sd[0, 8, 20] = depth[0, 8, 20] + 30.0      # one pixel rendered far behind its measurement
+    valid2 = valid.clone(); valid2[0, 8, 20] = 1
+    cand_e = sr.densify_candidates(valid2, torch.ones_like(alpha), sd, depth, 0.5, 0.1)
+    assert bool(cand_e[8, 20]) and int(cand_e.sum()) == 1
+    gen = torch.Generator().manual_seed(1)
+    m = sr.densify_sample(cand, depth, valid, 0.15, generator=gen)
+    assert m is not None and int(m.sum()) == int(0.15 * int(cand.sum())) and not bool((m & ~cand).any())
+    w = sr.compute_depth_gradient(depth, valid)[0]
+    assert float(w[m].min()) > 0.0                                   # zero-gradient pixels are never drawn
+    assert sr.densify_sample(cand & False, depth, valid, 0.15) is None
+    keep = sr.prune_mask(torch.tensor([[0.05], [0.5]]), torch.tensor([[0.1, 0.1], [0.001, 0.001]]), 0.1, 0.01)
+    assert keep.tolist() == [True, True] and not sr.prune_mask(torch.tensor([[0.05]]), torch.tensor([[1.0, 1.0]])).any()

@@ -112,6 +112,28 @@ def _compare_backward(oracle32, st, t, ost, sc, name, seed=3):
     return worst
 
 
+@pytest.mark.parametrize("offset", [(-0.5, -0.5), (0.25, -0.125)])
+def test_pixel_centre_offset_parity(device, oracle32, offset):
+    """D1 as a parameter (SlsCamera.pix_offset): pixel (c, r) at image coordinate (c + ox, r + oy).  The reference's
+    own back-projection uses (-0.5, -0.5) (utils/graphic_utils.py:46-49).  Forward integers bit-exact, allmap and
+    gradients to the usual bar against the checker given the same offset — and the image really moves: rendered
+    with the offset, the surfels land where the un-offset render puts them half a pixel further."""
+    from splat_loam_amd import _abi
+    N, H, W = 6000, 64, 512
+    sc, view, proj = scene_and_camera(N, H, W, seed=23, range_lo=2.0, range_hi=25.0)
+    st, t = hip_forward(device, sc, view, proj, H, W, pix_offset=offset)
+    assert tuple(st.cam.cam.pix_offset) == offset
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size(), pix_offset=offset)
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    _compare_forward(oracle32, st, ost, cam, f"offset{offset}")
+    _compare_backward(oracle32, st, t, ost, sc, f"offset{offset}")
+    # the offset is not a no-op: centre pixels move by -offset
+    st0, _ = hip_forward(device, sc, view, proj, H, W, pix_offset=(0.0, 0.0))
+    vis = (st.radii > 0) & (st0.radii > 0)
+    d = (st.rec[:, 16:18] - st0.rec[:, 16:18])[vis].cpu().numpy()
+    assert np.abs(d[:, 0] + offset[0]).max() < 1e-3 and np.abs(d[:, 1] + offset[1]).max() < 1e-3
+
+
 CASES = [
     # name, N, H, W, kwargs
     ("small_wrap", 3000, 32, 256, {}),

@@ -122,6 +122,31 @@ def test_backprojected_surfel_lands_on_its_pixel(oracle32):
         assert abs(am[0, r, c] / am[1, r, c] - rho) < 1e-3 * rho
 
 
+def test_pixel_centre_offset_meets_the_reference_backprojection(oracle32):
+    """With pix_offset = (-0.5, -0.5) the rasterizer's pixel (c, r) is the direction the reference's own
+    back-projection gives that pixel (utils/graphic_utils.py:46-49: K^-1 [c - 0.5, r - 0.5, 1]): a surfel put there
+    renders CENTRED on (r, c) — equal alpha left and right — while the default D1 render of the same surfel is
+    lopsided by the half pixel DESIGN.md section 9 reports as a tracking bias."""
+    H, W = 16, 64
+    K = synth.spherical_K(H, W).astype(np.float64)
+    view, proj = synth.camera_matrices(K.astype(np.float32), None)
+    cam_h = oracle32.camera(H, W, view, proj, pix_offset=(-0.5, -0.5))
+    cam_0 = oracle32.camera(H, W, view, proj)
+    assert abs(cam_h.cx - (cam_0.cx + 0.5)) < 1e-6 and abs(cam_h.cy - (cam_0.cy + 0.5)) < 1e-6
+    for (c, r, rho) in ((20, 6, 6.0), (41, 9, 15.0)):
+        az, el = (c - 0.5 - K[0, 2]) / K[0, 0], (r - 0.5 - K[1, 2]) / K[1, 1]
+        d = np.array([np.cos(az) * np.cos(el), np.sin(az) * np.cos(el), np.sin(el)])
+        n = -d
+        tu = np.cross(n, [0.3, 0.1, 1.0]); tu /= np.linalg.norm(tu)
+        q = synth._quat_from_R(np.stack([tu, np.cross(n, tu), n], 1)[None])[0]
+        args = ((d * rho)[None], np.array([[0.04 * rho, 0.04 * rho]]), q[None], np.array([[0.9]]))
+        a_h = oracle32.forward(cam_h, *args)["allmap"][1]
+        a_0 = oracle32.forward(cam_0, *args)["allmap"][1]
+        assert np.unravel_index(a_h.argmax(), a_h.shape) == (r, c)
+        assert abs(a_h[r, c - 1] - a_h[r, c + 1]) < 2e-3 * a_h[r, c] and abs(a_h[r - 1, c] - a_h[r + 1, c]) < 2e-3 * a_h[r, c]
+        assert abs(a_0[r, c - 1] - a_0[r, c + 1]) > 0.02 * a_0[r, c]        # D1: shifted by half a pixel
+
+
 def test_sorted_list_invariants_and_seam(oracle32):
     N, H, W = 3000, 32, 256
     sc = synth.make_scene(N, H, W, seed=4)

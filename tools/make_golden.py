@@ -216,11 +216,44 @@ def g5():
     np.savez_compressed(os.path.join(OUT, "g5_mapper.npz"), **out)
 
 
+def g6():
+    """The SLAM rules that size the hot path's workload: compute_depth_gradient (utils/graphic_utils.py:91-106)
+    on a seeded range image with holes, sample_geometric for the bench's 8-keyframe window, and
+    Tracker.require_new_keyframe's truth table (slam/tracker.py:61-84) evaluated by the reference's own method
+    on a stand-in object carrying the three fields it reads."""
+    from utils import graphic_utils as gu
+    from utils import sampling_utils as su
+    rng = np.random.default_rng(6)
+    H, W = 12, 40
+    depth = rng.uniform(2.0, 40.0, size=(1, H, W)).astype(np.float32)
+    depth[0, 3:6, 10:14] = 0.0                                   # log(0) = -inf -> 0
+    valid = (rng.uniform(size=(1, H, W)) > 0.15)
+    valid[0, 3:6, 10:14] = False
+    out = {"depth": depth, "valid": valid.astype(np.uint8),
+           "depth_gradient": gu.compute_depth_gradient(torch.from_numpy(depth), torch.from_numpy(valid)).numpy(),
+           "geom_8_4": np.asarray(su.sample_geometric(list(range(8)), 0.4), dtype=np.float64),
+           "geom_2_4": np.asarray(su.sample_geometric(list(range(2)), 0.4), dtype=np.float64)}
+    from slam.tracker import Tracker
+    from types import SimpleNamespace
+    rows = []
+    for nfr, fit, dist in ((3, 0.9, 0.2), (12, 0.9, 0.2), (3, 0.2, 0.2), (3, 0.9, 6.0), (12, 0.1, 9.0)):
+        for thr in ((-1, -1.0, 1.0), (10, -1.0, -1.0), (-1, 0.3, 5.0), (10, 0.3, 5.0), (0, 0.0, 0.0)):
+            T = torch.eye(4); T[0, 3] = dist
+            fake = SimpleNamespace(
+                cfg=SimpleNamespace(tracking=SimpleNamespace(keyframe_threshold_nframes=thr[0],
+                                                             keyframe_threshold_fitness=thr[1],
+                                                             keyframe_threshold_distance=thr[2])),
+                num_frames_tracked=nfr, aligner=SimpleNamespace(fitness=lambda f=fit: f), keyframe_T_frame=T)
+            rows.append([nfr, fit, dist, thr[0], thr[1], thr[2], float(bool(Tracker.require_new_keyframe(fake)))])
+    out["keyframe_rule"] = np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g6_slam_rules.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6"]
     for name in which:
         globals()[name]()
         print("wrote", name)

@@ -38,17 +38,19 @@ enum Op {
     OP_DPP_CHAIN,      // v_mov_b32_dpp dependent chain (the quad transmittance chain)
     OP_BALLOT_BRANCH,  // v_cmp + s_and + s_cbranch (ballot -> uniform branch round trip)
     OP_STEP_MIX,       // the forward step's class mix (counts from the disassembly, see kMix below)
+    OP_CNDMASK_SGPR,   // v_cndmask_b32_e64 with an SGPR-pair mask (the form the tile kernels mostly use)
+    OP_CNDMASK_VCC_W,  // v_cmp writes vcc, v_cndmask reads it (pairs, as a select compiles)
     OP_COUNT
 };
 static const char *kOpName[OP_COUNT] = {
     "v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mov_b32_dpp", "v_add_f32_dpp",
     "v_permlane32_swap", "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b128", "v_fma_f32 chain", "v_exp_f32 chain",
-    "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix"
+    "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix", "v_cndmask_b32 sgpr", "v_cmp+v_cndmask"
 };
 // wave-instructions per loop iteration of each kernel (what the time is divided by)
-static const int kPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 8, 64, 64, 64, 8, 96 };
+static const int kPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 8, 64, 64, 64, 8, 96, 64, 64 };
 // VALU wave-instructions per loop iteration (for the SQ_INSTS_VALU cross-check)
-static const int kValuPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 8, 84 };
+static const int kValuPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 8, 84, 64, 64 };
 
 #define REP8(x) x x x x x x x x
 #define A8 "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
@@ -104,6 +106,15 @@ __global__ __launch_bounds__(1024) void calib_kernel(float *out, int iters, uint
         else if (OP == OP_CNDMASK) {
             REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
                               "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n" : A8 : "v"(m) : "vcc");)
+        }
+        else if (OP == OP_CNDMASK_SGPR) {
+            const uint64_t msk = 0x5555555555555555ull ^ (uint64_t)blockIdx.x;
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                              "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n" : A8 : "v"(m), "s"(msk));)
+        }
+        else if (OP == OP_CNDMASK_VCC_W) {
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                              "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n" : A8 : "v"(m) : "vcc");)
         }
         else if (OP == OP_CMP) {
             REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
@@ -190,8 +201,11 @@ static Result run(int waves_per_simd, float *d_out, uint64_t *d_clk, int cus)
     r.op = OP; r.waves = waves_per_simd; r.ms = ms;
     const double insts_per_simd = (double)iters * kPerIter[OP] * waves_per_simd;
     r.mhz = wall > 0 ? cyc / (wall * 10.0e-3) : 0.0;          // wall clock ticks at 100 MHz: 10 ns each
-    r.clk_per_inst = cyc / insts_per_simd;                     // shader clocks the SIMD spent per wave-instruction
-    r.ns_per_inst = (double)ms * 1e6 / insts_per_simd;
+    r.ns_per_inst = (double)ms * 1e6 / insts_per_simd;         // HIP-event time of the launch / instructions per SIMD
+    // clocks per wave-instruction per SIMD: the event time at the shader frequency the blocks measured themselves
+    // (a block's own clock span is NOT the launch's: with 16-wave workgroups the blocks of a launch do not all run
+    // side by side, so block clocks under-count; the frequency ratio inside a block is sound)
+    r.clk_per_inst = r.ns_per_inst * r.mhz * 1e-3;
     hipEventDestroy(e0); hipEventDestroy(e1);
     return r;
 }
@@ -227,6 +241,8 @@ int main(int argc, char **argv)
     sweep<OP_DPP_CHAIN>(all, d_out, d_clk, cus);
     sweep<OP_BALLOT_BRANCH>(all, d_out, d_clk, cus);
     sweep<OP_STEP_MIX>(all, d_out, d_clk, cus);
+    sweep<OP_CNDMASK_SGPR>(all, d_out, d_clk, cus);
+    sweep<OP_CNDMASK_VCC_W>(all, d_out, d_clk, cus);
     printf("%-22s %5s %9s %12s %12s %8s\n", "class", "w/SIMD", "ms", "ns/inst/SIMD", "clk/inst/SIMD", "MHz");
     for (const Result &r : all)
         printf("%-22s %5d %9.3f %12.3f %12.3f %8.0f\n", kOpName[r.op], r.waves, r.ms, r.ns_per_inst, r.clk_per_inst, r.mhz);

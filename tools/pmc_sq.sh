@@ -37,7 +37,11 @@ for line in open("gpurun_out/pmc_sq.txt"):
     m = re.match(r"(\S+(?:<[^>]*>)?)\s+(SQ_\w+)\s+(\d+)", line.strip())
     if m:
         rows.setdefault(m.group(1).split("<")[0], {})[m.group(2)] = int(m.group(3))
-out = {"note": "SQ counters per launch, tools/one_iter.py (first 4 iterations of the bench scene); SQ_*_CYCLES / ACTIVE / WAIT "
+import sys
+sys.path.insert(0, ".")
+from bench import kernel_source_hash
+out = {"kernel_source_hash": kernel_source_hash(),
+       "note": "SQ counters per launch, tools/one_iter.py (first 4 iterations of the bench scene); SQ_*_CYCLES / ACTIVE / WAIT "
                "count SIMD issue slots (4 clocks), SQ_BUSY_CYCLES is summed over the 32 shader engines", "kernels": {}}
 for k, v in rows.items():
     slots = v["SQ_BUSY_CYCLES"] / 32 * 1024 / 4      # issue slots of all SIMDs during the kernel

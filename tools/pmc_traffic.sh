@@ -30,7 +30,11 @@ adam = out["adam_kernel"]
 read_true, write_true = N * 10 * 16, N * 10 * 12
 f_corr = read_true / (adam["FETCH_SIZE_KiB_per_launch"] * 1024)
 w_corr = write_true / (adam["WRITE_SIZE_KiB_per_launch"] * 1024)
-res = {"calibration": {"kernel": "adam_kernel", "true_read_bytes": read_true, "true_write_bytes": write_true,
+import sys
+sys.path.insert(0, ".")
+from bench import kernel_source_hash
+res = {"kernel_source_hash": kernel_source_hash(),
+       "calibration": {"kernel": "adam_kernel", "true_read_bytes": read_true, "true_write_bytes": write_true,
                        "fetch_factor": f_corr, "write_factor": w_corr,
                        "note": "factor = known bytes / (counter KiB * 1024); the guide's gfx950 FETCH_SIZE correction is x2"},
        "kernels": {}}

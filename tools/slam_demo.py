@@ -16,7 +16,7 @@ import numpy as np, torch
 from test_aligner import room_scan, pose_of, pose_error
 from gsaligner import GSAligner, GSAlignerParams
 from simple_knn._C import distCUDA2
-from splat_loam_amd import synth
+from splat_loam_amd import slam_rules, synth
 from splat_loam_amd.engine import MappingEngine
 from splat_loam_amd.mapping import MappingConfig
 from splat_loam_amd.projector import DeviceProjector
@@ -44,6 +44,25 @@ def surfels_from_scan(depth, points_sensor, world_T_sensor, stride, smax, dev):
                                       torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
 
 
+def _with_pix_offset(fn):
+    """pix_offset=(ox, oy): run with that pixel-centre convention in the rasterizer (SlsCamera.pix_offset; D1 default
+    (0, 0), the reference's own back-projection convention (-0.5, -0.5)), restoring the process default after."""
+    import functools
+    from splat_loam_amd import rasterizer
+
+    @functools.wraps(fn)
+    def wrapped(*a, pix_offset=None, **kw):
+        old = rasterizer.pix_offset()
+        if pix_offset is not None:
+            rasterizer.set_pix_offset(*pix_offset)
+        try:
+            return fn(*a, **kw)
+        finally:
+            rasterizer.set_pix_offset(*old)
+    return wrapped
+
+
+@_with_pix_offset
 def run(H=64, W=1024, n_frames=6, n_iter=60, verbose=True, dev="cuda:0"):
     dev = torch.device(dev)
     K = synth.spherical_K(H, W).astype(np.float64)
@@ -115,17 +134,27 @@ def _new_surfels(points_world, normals_world, existing_xyz, smax, dev):
                                       torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
 
 
-def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True, dev="cuda:0", out_dir=None,
-                 first_stride=2, el_deg=None):
+@_with_pix_offset
+def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=True, dev="cuda:0", out_dir=None,
+                 first_stride=None, el_deg=None, densify_percentage=0.15, densify_threshold_opacity=0.5,
+                 densify_threshold_egeom=-1.0, prob_view_last_keyframe=0.4, keyframe_threshold_distance=0.9,
+                 keyframe_threshold_fitness=0.30, keyframe_threshold_nframes=-1, pruning_min_opacity=0.1,
+                 step=(0.25, 0.04, 1.2)):
     """Odometry + mapping over a sequence, the reference's per-frame loop with this repository's
-    components: every scan is registered against the latest keyframe as the MODEL renders it (tracker); every
-    `kf_every`-th frame becomes a keyframe at its ESTIMATED pose: densify where the model is transparent
-    (Mapper.densify), engine.remap, `n_iter` iterations over geometrically sampled keyframes (Mapper.optimize),
-    prune by opacity (Mapper.prune), engine.remap."""
+    components: every scan is registered against the latest keyframe as the MODEL renders it (tracker); a frame
+    becomes a keyframe — at its ESTIMATED pose — when Tracker.require_new_keyframe says so (slam/tracker.py:61-84:
+    distance / fitness / frame-count thresholds; `kf_every` overrides the rule with a fixed cadence); a keyframe is
+    densified as Mapper.densify does (slam/mapper.py:51-135: candidates = valid pixels the model renders with
+    alpha <= densify_threshold_opacity [+ the depth-error quantile mask], densify_percentage of them drawn with
+    probability proportional to the log-depth gradient; the first keyframe draws from every valid pixel;
+    `first_stride` replaces the draw of the FIRST keyframe by a regular column stride — a denser model than the
+    reference's rule builds, kept as a stress option), then engine.remap, `n_iter` iterations over keyframes
+    sampled as Mapper.optimize does (sample_geometric over the keyframe list), pruning (Mapper.prune), engine.remap.
+    step: (dx, dy, yaw_deg) of the generating trajectory per frame."""
     dev = torch.device(dev)
     rng = np.random.default_rng(0)
     K = (synth.spherical_K(H, W) if el_deg is None else synth.spherical_K(H, W, el_deg[0], el_deg[1])).astype(np.float64)
-    gt = [pose_of([0.25 * k, 0.04 * k, 0.0], yaw_deg=1.2 * k) for k in range(n_frames)]
+    gt = [pose_of([step[0] * k, step[1] * k, 0.0], yaw_deg=step[2] * k) for k in range(n_frames)]
     cfg = MappingConfig()
     proj = DeviceProjector(H, W, 0.5, 100.0, device=dev)
     Kd = torch.tensor(K.reshape(-1), dtype=torch.float32, device=dev)
@@ -139,17 +168,24 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
 
     def add_keyframe(model, eng, est_pose, depth, normals, valid, points, first):
         cam = Camera(K, depth[None], normals.permute(2, 0, 1), valid[None], est_pose, data_device=str(dev))
-        if first:
-            mask = valid.clone()
+        gen = torch.Generator(device=dev).manual_seed(len(kfs))
+        if first and first_stride:
+            mask = valid.clone().bool()
             if first_stride > 1:
                 keep_cols = torch.zeros(mask.shape[1], dtype=torch.bool, device=dev); keep_cols[::first_stride] = True
                 mask &= keep_cols[None, :]
         else:
-            with torch.no_grad():
-                alpha = render(cam, model, cfg.depth_ratio)["rend_alpha"][0]
-            mask = (alpha <= 0.5) & valid                       # densify_threshold_opacity
-            mask &= torch.rand(mask.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(len(kfs))) < 0.5
-        sel = mask.reshape(-1).cpu().numpy()
+            pkg = None
+            if not first:
+                with torch.no_grad():
+                    pkg = render(cam, model, cfg.depth_ratio)
+            cand = slam_rules.densify_candidates(cam.image_valid, None if first else pkg["rend_alpha"],
+                                                 None if first else pkg["surf_depth"], cam.image_depth,
+                                                 densify_threshold_opacity, densify_threshold_egeom, initialize_model=first)
+            mask = slam_rules.densify_sample(cand, cam.image_depth, cam.image_valid, densify_percentage, generator=gen)
+            if mask is None:
+                mask = torch.zeros_like(cand)
+        sel = mask.reshape(-1).cpu().numpy().astype(bool)
         n_new = int(sel.sum())
         if n_new >= 2:
             R, t = est_pose[:3, :3], est_pose[:3, 3]
@@ -164,11 +200,11 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
                     setattr(model, name, torch.nn.Parameter(torch.cat([getattr(model, name).detach(), getattr(new, name).detach()]).contiguous()))
                 eng.remap(None, appended=n_new)
         kfs.append(cam)
-        p = np.array([0.4 * 0.6 ** (len(kfs) - 1 - i) for i in range(len(kfs))]); p /= p.sum()   # sample_geometric
+        p = slam_rules.keyframe_probabilities(len(kfs), prob_view_last_keyframe)     # slam/mapper.py:142-149
         for it in range(n_iter):
             eng.step(kfs[rng.choice(len(kfs), p=p)], sync="lagged")
         eng.flush()
-        keep = model.get_opacity.detach().reshape(-1) >= 0.1         # pruning_min_opacity
+        keep = ~slam_rules.prune_mask(model.get_opacity.detach(), model.get_scaling.detach(), pruning_min_opacity, 0.0)
         if not bool(keep.all()):
             for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
                 setattr(model, name, torch.nn.Parameter(getattr(model, name).detach()[keep].contiguous()))
@@ -192,14 +228,20 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
     set_reference(kf_cam)
     kf_T_frame = torch.eye(4, device=dev)
     errs = [(0.0, 0.0)]
+    tracked = 0
     for k in range(1, n_frames):
         depth, normals, valid, points = frame(k)
         al.set_query(depth[None], points, kf_cam.projection_matrix)
         kf_T_frame, fitness, _ = al.align(kf_T_frame)
+        tracked += 1
         pose = kf_pose @ kf_T_frame.cpu().numpy().astype(np.float64)
         est.append(pose)
         errs.append(pose_error(pose, gt[k]))
-        if k % kf_every == 0:
+        new_kf = (k % kf_every == 0) if kf_every else slam_rules.require_new_keyframe(
+            tracked, float(fitness), kf_T_frame, keyframe_threshold_nframes, keyframe_threshold_fitness,
+            keyframe_threshold_distance)
+        if new_kf:
+            tracked = 0
             model, eng, kf_cam, n_new, n_pruned = add_keyframe(model, eng, pose, depth, normals, valid, points, first=False)
             kf_pose, kf_T_frame = pose, torch.eye(4, device=dev)
             set_reference(kf_cam)
@@ -226,7 +268,10 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=4, n_iter=60, verbose=True,
 
 
 if __name__ == "__main__":
+    off = None
+    if "--half-pixel" in sys.argv:
+        sys.argv.remove("--half-pixel"); off = (-0.5, -0.5)
     if len(sys.argv) > 1 and sys.argv[1] == "sequence":
-        run_sequence(*[int(x) for x in sys.argv[2:]])
+        run_sequence(*[int(x) for x in sys.argv[2:]], pix_offset=off)
     else:
-        run(*[int(x) for x in sys.argv[1:]])
+        run(*[int(x) for x in sys.argv[1:]], pix_offset=off)
