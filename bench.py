@@ -574,10 +574,17 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
         # ---- thread sweep (the per-tile tensors are (entries x 256): a larger pool mostly adds fork/join cost)
         sweep = {}
         probe = sorted(set(int(i * T2 / 12) for i in range(12)))
+        t_leg = time.perf_counter()
         for th in sorted(set(t for t in (32, 64, host) if t <= host)):
             torch.set_num_threads(th)
+            t_w = time.perf_counter()
             torch_iteration(sc2, 64, 1024, probe[:2])                      # warm the pool
+            if time.perf_counter() - t_w > 5.0 and sweep:                  # a pool this slow cannot win: skip its probe
+                sweep[th] = float("inf")
+                log(f"cpu baseline: {th} threads: warm-up alone took {time.perf_counter() - t_w:.1f} s, skipped")
+                continue
             sweep[th] = round(torch_iteration(sc2, 64, 1024, probe), 3)
+            log(f"cpu baseline: {th} threads: {sweep[th]} s for {len(probe)} tiles")
         cores = min(sweep, key=sweep.get)
         torch.set_num_threads(cores)
         out["cores"] = cores
@@ -603,8 +610,14 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
                    f"backward + torch Adam) of the same {N}-surfel {H}x{W} scene; {how}")
         log("cpu baseline: torch 500k subset done")
         # ---- 50k / 64x1024, every tile, warm-up + median of 5
+        t_w = time.perf_counter()
         torch_iteration(sc2, 64, 1024, None)
-        times = sorted(torch_iteration(sc2, 64, 1024, None) for _ in range(5))
+        log(f"cpu baseline: 50k warm-up iteration {time.perf_counter() - t_w:.1f} s (leg so far {time.perf_counter() - t_leg:.0f} s)")
+        times = []
+        for _ in range(5):
+            times.append(torch_iteration(sc2, 64, 1024, None))
+            log(f"cpu baseline: 50k iteration {len(times)}: {times[-1]:.2f} s")
+        times.sort()
         med = times[2]
         out["torch_50k_64x1024"] = {"value": round(50_000 / med / 1e6, 5), "unit": "Msplats/s", "cores": cores,
                                     "seconds_median_of_5": round(med, 3), "seconds_all": [round(t, 3) for t in times],

@@ -54,7 +54,9 @@ extern "C" {
 typedef struct SlsCamera {
     int32_t H, W;           /* image_height, image_width                        */
     int32_t wrap;           /* 1: azimuth wraps (360 deg image), D5             */
-    int32_t reserved;
+    int32_t reserved;       /* 0 (default): D10, the binning emits only the instances of a surfel's tile rectangle
+                             * whose tile the footprint can reach (include/sls_det_math.h: sls_tile_outside);
+                             * 1: every tile of the rectangle (the pre-D10 lists; tests, A/B runs) */
     float fx, fy, cx, cy;   /* K = projmatrix[:3,:3]^T : u = fx*az+cx, v = fy*el+cy */
     float scale_modifier;
     float near_cut, far_cut;
@@ -98,8 +100,14 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
                       float *row_cs_host);
 
 /* ---- forward, stage 1: preprocess + depth order + scan ---------------------
+ * col_cs / row_cs: the DEVICE copies of sls_ray_tables (the tile test of D10 takes its tile-centre directions
+ * from them; may be null with cam->reserved = 1).
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
- * tiles_touched: N uint32, depth: N floats (range of the centre, the sort key),
+ * tiles_touched: N uint32 = number of tile instances the surfel emits,
+ * tile_mask: N uint64 — bit k set: the k-th tile of the rectangle (row-major, the emission order) is emitted;
+ *   rectangles of fewer than 3 or more than 64 tiles are not tested and emit every tile (mask = all ones
+ *   below the tile count),
+ * depth: N floats (range of the centre, the sort key),
  * order: N uint32 = surfel index at each position of the (range, index) order (ALL surfels,
  *        culled ones included at their range; they have tiles_touched = 0 and emit nothing),
  * offsets: N uint32 = inclusive scan of tiles_touched[order[.]],
@@ -109,8 +117,8 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 size_t sls_stage1_scratch_bytes(int N);
 int sls_forward_stage1(const SlsCamera *cam, int N,
                        const float *means3D, const float *scales, const float *rotations,
-                       const float *opacities,
-                       float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles_touched,
+                       const float *opacities, const float *col_cs, const float *row_cs,
+                       float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles_touched, uint64_t *tile_mask,
                        float *depth, uint32_t *order, uint32_t *offsets, uint32_t *total_out,
                        void *scratch, size_t scratch_bytes, void *stream);
 
@@ -131,6 +139,7 @@ size_t sls_sort_scratch_bytes(uint64_t R);
 size_t sls_block_mask_bytes(uint64_t R, int H, int W);
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
                        const float *rec, const int32_t *rect, const uint32_t *tiles_touched,
+                       const uint64_t *tile_mask,
                        const float *depth, const uint32_t *order, const uint32_t *offsets,
                        const uint32_t *total_dev,
                        uint32_t *tile_keys, uint32_t *vals, uint32_t *tile_keys_tmp, uint32_t *vals_tmp,

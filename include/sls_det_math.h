@@ -44,6 +44,7 @@ typedef double sls_real;
 #define SLS_FMIN(a, b) fmin((a), (b))
 #define SLS_FLOOR(a) floor(a)
 #define SLS_CEIL(a) ceil(a)
+#define SLS_RINT(a) rint(a)
 #define SLS_R(x) x
 #else
 typedef float sls_real;
@@ -54,6 +55,7 @@ typedef float sls_real;
 #define SLS_FMIN(a, b) fminf((a), (b))
 #define SLS_FLOOR(a) floorf(a)
 #define SLS_CEIL(a) ceilf(a)
+#define SLS_RINT(a) rintf(a)
 #define SLS_R(x) x##f
 #endif
 
@@ -95,6 +97,118 @@ SLS_HD sls_real sls_atan2(sls_real y, sls_real x)
 SLS_HD sls_real sls_asin01(sls_real s)
 {
     return sls_atan2(s, SLS_SQRT(SLS_FMA(-s, s, SLS_R(1.0))));
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * D10: footprint test of a surfel against a whole TILE in the binning (which instances exist at all).
+ *
+ * A pixel ray d can only receive alpha >= 1/255 from a surfel's 3D branch if
+ *     G(d) = |(Hu.d, Hv.d)| + kc (n.d) <= 0      (rho3 <= kc^2 = 2 ln(255 o) and n.d < 0),
+ * and G is convex in d.  With the tile's rays written as d0 + x Dx + y Dy + r, |x|,|y| <= 1, |r| <= eps
+ * (second-order remainder of the sphere's parametrisation), G over the tile is bounded below by
+ *     G(d0) - |gradG.Dx| - |gradG.Dy| - eps |gradG|_1 ;
+ * if that is positive no pixel of the tile lies in the 3D footprint.  The low-pass (2D) branch reaches
+ * kc / sqrt 2 pixels from the centre pixel: tested as the distance to the tile's pixel box.  An instance
+ * (surfel, tile) of the surfel's tile rectangle is emitted iff the 3D footprint may reach the tile OR the
+ * disc does.  Everything is multiplied through by su sv |(a, b)| so that no division is needed, and only
+ * exactly-rounded operations in a fixed order are used (see the rules at the top of this file): the HIP
+ * kernel and the CPU checker reach the same verdict for every instance, so tiles_touched, the sorted lists
+ * and the tile ranges stay bit-exact.  Conservative by construction (margins: 0.1 % + 1e-3 on rho_max,
+ * 2e-4 relative on G, 0.05 px on the disc); tests/test_tile_cull.py checks on whole scenes that the
+ * rendered image does not change by a single bit when the test is switched off.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Upper bound of ln(x) for a finite x >= 1 (x = 255 o <= 255): x = 2^e m, m in [1,2),
+ * ln m = 2 atanh(z), z = (m-1)/(m+1) in [0,1/3): the series 2 (z + z^3/3 + z^5/5 + z^7/7) is a lower bound
+ * whose tail is < 1.4e-5; 3e-5 is added (tail + rounding). */
+SLS_HD sls_real sls_log_upper(sls_real x)
+{
+    int e = 0;
+    sls_real m = x;
+    /* exact scaling by powers of two (x <= 255 in practice: at most 8 rounds; capped for safety) */
+    for (int k = 0; k < 128 && m >= SLS_R(2.0); ++k) { m = m * SLS_R(0.5); ++e; }
+    const sls_real z = (m - SLS_R(1.0)) / (m + SLS_R(1.0));
+    const sls_real z2 = z * z;
+    sls_real p = SLS_R(0.14285714285714285);          /* 1/7 */
+    p = SLS_FMA(p, z2, SLS_R(0.2));
+    p = SLS_FMA(p, z2, SLS_R(0.33333333333333333));
+    p = SLS_FMA(p, z2, SLS_R(1.0));
+    const sls_real lnm = SLS_R(2.0) * (z * p);
+    return SLS_FMA((sls_real)e, SLS_R(0.69314718055994531), lnm) + SLS_R(3.0e-5);
+}
+
+/* Per-surfel inputs of the tile test (all from exactly reproducible quantities). */
+typedef struct SlsTileCullSurfel {
+    sls_real Pu[3], Pv[3];   /* sv (Tv x p), su (Tu x p): su sv times the record's Hu, Hv up to sign */
+    sls_real n[3], dc[3];    /* sensor-facing normal, unit centre direction p / |p| */
+    sls_real ks;             /* kc su sv */
+    sls_real rd;             /* reach of the low-pass disc in pixels: kc / sqrt 2 (+0.1 %, +0.05 px) */
+    sls_real cpx, cpy;       /* centre pixel */
+} SlsTileCullSurfel;
+
+/* Per-camera constants of the tile test (host: sls_tile_cull_consts / the checker's copy of it). */
+typedef struct SlsTileCullCam {
+    sls_real chx, shx, chy, shy;   /* cos / sin of half a pixel in azimuth (0.5 / fx) and elevation (0.5 / fy) */
+    sls_real kx, ky;               /* half extent of a tile in radians: (tile_w - 1) / 2 / fx, (tile_h - 1) / 2 / fy */
+    sls_real eps;                  /* bound of the second-order remainder + float32 slop */
+    sls_real hx, hy;               /* (tile_w - 1) / 2, (tile_h - 1) / 2 pixels */
+    sls_real wrapW, invW;          /* W and 1 / W in 360-degree mode, else 0 */
+} SlsTileCullCam;
+
+SLS_HD void sls_tile_cull_surfel(const sls_real *Tu, const sls_real *Tv, const sls_real *n, const sls_real *p,
+                                 sls_real rho, sls_real su, sls_real sv, sls_real opacity, sls_real cpx,
+                                 sls_real cpy, SlsTileCullSurfel *s)
+{
+    /* W = T x p with the fma form used for Hu / Hv */
+    const sls_real Wu0 = SLS_FMA(Tv[1], p[2], -(Tv[2] * p[1])), Wu1 = SLS_FMA(Tv[2], p[0], -(Tv[0] * p[2])),
+                   Wu2 = SLS_FMA(Tv[0], p[1], -(Tv[1] * p[0]));
+    const sls_real Wv0 = SLS_FMA(Tu[1], p[2], -(Tu[2] * p[1])), Wv1 = SLS_FMA(Tu[2], p[0], -(Tu[0] * p[2])),
+                   Wv2 = SLS_FMA(Tu[0], p[1], -(Tu[1] * p[0]));
+    s->Pu[0] = sv * Wu0; s->Pu[1] = sv * Wu1; s->Pu[2] = sv * Wu2;
+    s->Pv[0] = su * Wv0; s->Pv[1] = su * Wv1; s->Pv[2] = su * Wv2;
+    for (int k = 0; k < 3; ++k) { s->n[k] = n[k]; s->dc[k] = p[k] / rho; }
+    const sls_real lo = SLS_R(255.0) * opacity;
+    /* lo <= 1: no pixel can reach alpha >= 1/255 at all (alpha <= o): kc = 0 keeps the maths finite */
+    const sls_real rho_max = lo > SLS_R(1.0) ? SLS_R(2.0) * sls_log_upper(lo) * SLS_R(1.001) + SLS_R(1.0e-3) : SLS_R(0.0);
+    const sls_real kc = SLS_SQRT(rho_max) * SLS_R(1.0001);
+    s->ks = kc * (su * sv);
+    s->rd = kc * SLS_R(0.70781) + SLS_R(0.05);
+    s->cpx = cpx; s->cpy = cpy;
+}
+
+/* 1: the surfel cannot contribute to any pixel of the tile whose first pixel is (x0, y0); col_c / row_c:
+ * (cos, sin) of the pixel column min(x0 + (tile_w - 1) / 2, W - 1) rounded down / of the corresponding row, from
+ * the rasterizer's own ray tables (the tile centre lies half a pixel further). */
+SLS_HD int sls_tile_outside(const SlsTileCullCam *c, const SlsTileCullSurfel *s, sls_real x0, sls_real y0,
+                            sls_real col_cos, sls_real col_sin, sls_real row_cos, sls_real row_sin)
+{
+    /* tile-centre direction: the pixel's angles advanced by half a pixel */
+    const sls_real cc = col_cos * c->chx - col_sin * c->shx, sc = col_sin * c->chx + col_cos * c->shx;
+    const sls_real cr = row_cos * c->chy - row_sin * c->shy, sr = row_sin * c->chy + row_cos * c->shy;
+    const sls_real d0 = cc * cr, d1 = sc * cr, d2 = sr;
+    const sls_real Dx0 = -(c->kx * d1), Dx1 = c->kx * d0;
+    const sls_real Dy0 = -(c->ky * (cc * sr)), Dy1 = -(c->ky * (sc * sr)), Dy2 = c->ky * cr;
+    const sls_real l0 = d0 - s->dc[0], l1 = d1 - s->dc[1], l2 = d2 - s->dc[2];
+    const sls_real a = (s->Pu[0] * l0 + s->Pu[1] * l1) + s->Pu[2] * l2;
+    const sls_real b = (s->Pv[0] * l0 + s->Pv[1] * l1) + s->Pv[2] * l2;
+    const sls_real e = (s->n[0] * d0 + s->n[1] * d1) + s->n[2] * d2;
+    const sls_real n2 = a * a + b * b;
+    const sls_real kn = s->ks * SLS_SQRT(n2);
+    const sls_real g0 = (a * s->Pu[0] + b * s->Pv[0]) + kn * s->n[0];
+    const sls_real g1 = (a * s->Pu[1] + b * s->Pv[1]) + kn * s->n[1];
+    const sls_real g2 = (a * s->Pu[2] + b * s->Pv[2]) + kn * s->n[2];
+    const sls_real tx = g0 * Dx0 + g1 * Dx1;
+    const sls_real ty = (g0 * Dy0 + g1 * Dy1) + g2 * Dy2;
+    const sls_real reach = (SLS_FABS(tx) + SLS_FABS(ty)) + c->eps * ((SLS_FABS(g0) + SLS_FABS(g1)) + SLS_FABS(g2));
+    const int outside3d = ((n2 + kn * e) - reach) > SLS_R(2.0e-4) * (n2 + kn * SLS_FABS(e));
+    if (!outside3d) return 0;
+    /* low-pass disc against the tile's pixel box */
+    const sls_real dxr = (x0 + c->hx) - s->cpx;
+    const sls_real dxc = dxr - c->wrapW * SLS_RINT(dxr * c->invW);
+    const sls_real ex = SLS_FMAX(SLS_FABS(dxc) - c->hx, SLS_R(0.0));
+    const sls_real ey = SLS_FMAX(SLS_FABS((y0 + c->hy) - s->cpy) - c->hy, SLS_R(0.0));
+    return (ex * ex + ey * ey) > s->rd * s->rd;
 }
 
 #endif /* SLS_DET_MATH_H */

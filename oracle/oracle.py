@@ -58,7 +58,7 @@ class Camera:
     """
 
     def __init__(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16),
-                 wrap=None, dtype=np.float32, pix_offset=(0.0, 0.0)):
+                 wrap=None, dtype=np.float32, pix_offset=(0.0, 0.0), tile_cull=True):
         V = np.asarray(viewmatrix, dtype=np.float64)
         Pm = np.asarray(projmatrix, dtype=np.float64)
         K = Pm[:3, :3].T
@@ -76,7 +76,8 @@ class Camera:
             wrap = should_wrap(self.fx, self.W, self.tile[0])
         self.wrap = int(bool(wrap))
         self.dtype = np.dtype(dtype)
-        self.icam = np.array([self.H, self.W, self.tile[0], self.tile[1], self.wrap], dtype=np.int32)
+        self.tile_cull = bool(tile_cull)     # D10: the binning drops instances whose tile the footprint cannot reach
+        self.icam = np.array([self.H, self.W, self.tile[0], self.tile[1], self.wrap, int(self.tile_cull)], dtype=np.int32)
         Rvw = V[:3, :3].T
         tvw = V[3, :3]
         self.fcam = np.concatenate([
@@ -109,8 +110,9 @@ class Oracle:
     def _r(self, a):
         return np.ascontiguousarray(a, dtype=self.dtype)
 
-    def camera(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16), wrap=None, pix_offset=(0.0, 0.0)):
-        return Camera(H, W, viewmatrix, projmatrix, scale_modifier, tile, wrap, self.dtype, pix_offset)
+    def camera(self, H, W, viewmatrix, projmatrix, scale_modifier=1.0, tile=(16, 16), wrap=None, pix_offset=(0.0, 0.0),
+               tile_cull=True):
+        return Camera(H, W, viewmatrix, projmatrix, scale_modifier, tile, wrap, self.dtype, pix_offset, tile_cull)
 
     def ray_tables(self, cam: Camera):
         col = np.empty((cam.W, 2), self.dtype)
@@ -118,16 +120,18 @@ class Oracle:
         self.lib.or_ray_tables(_ptr(cam.icam), _ptr(cam.fcam), _ptr(col), _ptr(row))
         return col, row
 
-    def preprocess(self, cam: Camera, means, scales, rots, opac):
+    def preprocess(self, cam: Camera, means, scales, rots, opac, tables=None):
         means, scales, rots, opac = map(self._r, (means, scales, rots, opac))
         N = means.shape[0]
+        col, row = tables if tables is not None else self.ray_tables(cam)      # (D10 takes its tile directions from them)
         out = dict(
             rec=np.empty((N, REC_STRIDE), self.dtype), radii=np.empty(N, np.int32),
-            rect=np.empty((N, 4), np.int32), tiles=np.empty(N, np.uint32),
+            rect=np.empty((N, 4), np.int32), tiles=np.empty(N, np.uint32), tmask=np.empty(N, np.uint64),
             depth=np.empty(N, self.dtype))
         self.lib.or_preprocess(_ptr(cam.icam), _ptr(cam.fcam), C.c_int(N), _ptr(means), _ptr(scales),
-                               _ptr(rots), _ptr(opac.reshape(-1)), _ptr(out["rec"]), _ptr(out["radii"]),
-                               _ptr(out["rect"]), _ptr(out["tiles"]), _ptr(out["depth"]))
+                               _ptr(rots), _ptr(opac.reshape(-1)), _ptr(col), _ptr(row), _ptr(out["rec"]),
+                               _ptr(out["radii"]), _ptr(out["rect"]), _ptr(out["tiles"]), _ptr(out["tmask"]),
+                               _ptr(out["depth"]))
         return out
 
     def bin_sort(self, cam: Camera, pre):
@@ -137,7 +141,7 @@ class Oracle:
         out = dict(R=R, keys_unsorted=np.empty(R, np.uint64), vals_unsorted=np.empty(R, np.uint32),
                    keys=np.empty(R, np.uint64), vals=np.empty(R, np.uint32),
                    ranges=np.zeros((cam.T, 2), np.uint32))
-        self.lib.or_emit_sort(_ptr(cam.icam), C.c_int(N), _ptr(pre["rect"]), _ptr(pre["tiles"]),
+        self.lib.or_emit_sort(_ptr(cam.icam), C.c_int(N), _ptr(pre["rect"]), _ptr(pre["tiles"]), _ptr(pre["tmask"]),
                               _ptr(depth_bits), C.c_uint64(R), _ptr(out["keys_unsorted"]),
                               _ptr(out["vals_unsorted"]), _ptr(out["keys"]), _ptr(out["vals"]),
                               _ptr(out["ranges"]))
@@ -186,7 +190,7 @@ class Oracle:
         """Whole forward: returns a state dict with radii, allmap and everything
         the backward needs."""
         tables = self.ray_tables(cam)
-        pre = self.preprocess(cam, means, scales, rots, opac)
+        pre = self.preprocess(cam, means, scales, rots, opac, tables)
         binned = self.bin_sort(cam, pre)
         fwd = self.render_fwd(cam, tables, binned, pre["rec"], frag_tol)
         return dict(cam=cam, tables=tables, pre=pre, binned=binned, fwd=fwd,

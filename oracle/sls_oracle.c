@@ -55,7 +55,7 @@ typedef sls_real real;
 
 /* icam: H, W, tile_w, tile_h, wrap
  * fcam: fx, fy, cx, cy, scale_modifier, near, far, Rvw[9] (row-major), tvw[3] */
-enum { IC_H = 0, IC_W, IC_TW, IC_TH, IC_WRAP, IC_COUNT };
+enum { IC_H = 0, IC_W, IC_TW, IC_TH, IC_WRAP, IC_TILECULL, IC_COUNT };   /* IC_TILECULL: D10 on (1) / off (0) */
 enum { FC_FX = 0, FC_FY, FC_CX, FC_CY, FC_MOD, FC_NEAR, FC_FAR, FC_R = 7, FC_T = 16, FC_COUNT = 19 };
 
 int or_real_bytes(void) { return (int)sizeof(real); }
@@ -141,6 +141,26 @@ static inline void ball_extent(real rad, real rho, real rxy, real *theta, real *
     else *daz = sls_asin01(q);
 }
 
+/* D10 — per-camera constants of the tile-level footprint test (include/sls_det_math.h), in double and rounded
+ * once, exactly as the library's make_tile_cull_cam does (same expressions, same libm). */
+static SlsTileCullCam tile_cull_consts(const int32_t *ic, const real *fc)
+{
+    SlsTileCullCam c;
+    const double hx = 0.5 * (double)(ic[IC_TW] - 1), hy = 0.5 * (double)(ic[IC_TH] - 1);
+    const double ax = 0.5 / (double)fc[FC_FX], ay = 0.5 / (double)fc[FC_FY];
+    c.chx = (real)cos(ax); c.shx = (real)sin(ax);
+    c.chy = (real)cos(ay); c.shy = (real)sin(ay);
+    const double kx = hx / (double)fc[FC_FX], ky = hy / (double)fc[FC_FY];
+    c.kx = (real)kx; c.ky = (real)ky;
+    const double span = fabs(kx) + fabs(ky);
+    c.eps = (real)(0.5 * span * span * 1.01 + 4.0e-6);
+    c.hx = (real)hx; c.hy = (real)hy;
+    c.wrapW = ic[IC_WRAP] ? (real)ic[IC_W] : RC(0.0);
+    c.invW = ic[IC_WRAP] ? RC(1.0) / (real)ic[IC_W] : RC(0.0);
+    return c;
+}
+#define SLS_TILE_CULL_MIN 3   /* rectangles of 3 .. 64 tiles are tested */
+
 /* ------------------------------------------------------------------ */
 /* A1 preprocess (called inside                     */
 /* gaussian_renderer/__init__.py:40-47).                               */
@@ -149,8 +169,11 @@ static inline void ball_extent(real rad, real rho, real rxy, real *theta, real *
 /* ------------------------------------------------------------------ */
 void or_preprocess(const int32_t *ic, const real *fc, int N,
                    const real *means, const real *scales, const real *rots, const real *opac,
-                   real *rec, int32_t *radii, int32_t *rect, uint32_t *tiles, real *depth)
+                   const real *col_cs, const real *row_cs,
+                   real *rec, int32_t *radii, int32_t *rect, uint32_t *tiles, uint64_t *tmask, real *depth)
 {
+    const SlsTileCullCam tcc = tile_cull_consts(ic, fc);
+    const int tile_cull = ic[IC_TILECULL] && col_cs && row_cs;
     const int H = ic[IC_H], W = ic[IC_W], TW = ic[IC_TW], TH = ic[IC_TH], wrap = ic[IC_WRAP];
     const int GX = (W + TW - 1) / TW;
     const real fx = fc[FC_FX], fy = fc[FC_FY], cx = fc[FC_CX], cy = fc[FC_CY];
@@ -160,7 +183,7 @@ void or_preprocess(const int32_t *ic, const real *fc, int N,
     for (int i = 0; i < N; ++i) {
         real *rc = rec + (size_t)i * SLS_REC_STRIDE;
         for (int k = 0; k < SLS_REC_STRIDE; ++k) rc[k] = 0;
-        radii[i] = 0; tiles[i] = 0; depth[i] = 0;
+        radii[i] = 0; tiles[i] = 0; depth[i] = 0; tmask[i] = 0;
         rect[4 * i] = rect[4 * i + 1] = rect[4 * i + 2] = rect[4 * i + 3] = 0;
 
         const real *m = means + 3 * i;
@@ -220,7 +243,27 @@ void or_preprocess(const int32_t *ic, const real *fc, int N,
         const int tylo = ylo / TH, nrows = yhi / TH - tylo + 1;
 
         rect[4 * i] = txlo; rect[4 * i + 1] = ncols; rect[4 * i + 2] = tylo; rect[4 * i + 3] = nrows;
-        tiles[i] = (uint32_t)(ncols * nrows);
+        /* D10: which tiles of the rectangle (row-major, the emission order) the footprint can reach */
+        const int nrect = ncols * nrows;
+        uint64_t mask = nrect >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << nrect) - 1);
+        if (tile_cull && nrect >= SLS_TILE_CULL_MIN && nrect <= 64) {
+            SlsTileCullSurfel cs;
+            sls_tile_cull_surfel(Tu, Tv, n, p, rho, su, sv, opac[i], cpx, cpy, &cs);
+            for (int idx = 0; idx < nrect; ++idx) {
+                const int ky = idx / ncols, kx = idx - ky * ncols;
+                int txx = txlo + kx;
+                if (txx >= GX) txx -= GX;
+                const int x0 = txx * TW, y0 = (tylo + ky) * TH;
+                int ci = x0 + TW / 2 - 1, ri = y0 + TH / 2 - 1;
+                if (ci > W - 1) ci = W - 1;
+                if (ri > H - 1) ri = H - 1;
+                if (sls_tile_outside(&tcc, &cs, (real)x0, (real)y0, col_cs[2 * ci], col_cs[2 * ci + 1],
+                                     row_cs[2 * ri], row_cs[2 * ri + 1]))
+                    mask &= ~((uint64_t)1 << idx);
+            }
+        }
+        tmask[i] = mask;
+        tiles[i] = nrect <= 64 ? (uint32_t)__builtin_popcountll(mask) : (uint32_t)nrect;
         radii[i] = to_int_clamped(SLS_CEIL(SLS_FMAX(rx, ry)));
         depth[i] = rho;
 
@@ -262,7 +305,7 @@ static int kv_cmp(const void *a, const void *b)
 
 /* depth32: IEEE-754 binary32 bit patterns of the float depth (the f64
  * build rounds its depth to float first; the caller passes the bits). */
-void or_emit_sort(const int32_t *ic, int N, const int32_t *rect, const uint32_t *tiles,
+void or_emit_sort(const int32_t *ic, int N, const int32_t *rect, const uint32_t *tiles, const uint64_t *tmask,
                   const uint32_t *depth_bits, uint64_t R,
                   uint64_t *keys_unsorted, uint32_t *vals_unsorted,
                   uint64_t *keys, uint32_t *vals, uint32_t *ranges)
@@ -274,8 +317,10 @@ void or_emit_sort(const int32_t *ic, int N, const int32_t *rect, const uint32_t 
     for (int i = 0; i < N; ++i) {
         if (!tiles[i]) continue;
         const int txlo = rect[4 * i], ncols = rect[4 * i + 1], tylo = rect[4 * i + 2], nrows = rect[4 * i + 3];
+        int bit = 0;
         for (int y = 0; y < nrows; ++y)
-            for (int k = 0; k < ncols; ++k) {
+            for (int k = 0; k < ncols; ++k, ++bit) {
+                if (bit < 64 && !((tmask[i] >> bit) & 1)) continue;     /* D10: the footprint cannot reach this tile */
                 const int tx = (txlo + k) % GX;
                 const uint64_t tile = (uint64_t)(tylo + y) * GX + tx;
                 kv[off].k = (tile << 32) | depth_bits[i];

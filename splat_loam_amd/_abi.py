@@ -80,9 +80,9 @@ _PROTOS = {
     "sls_consumer_fwd_bwd": (C.c_int, [C.c_int, C.c_int] + [_VP] * 5 + [C.c_float] * 3 + [C.c_int, _VP, _VP, _VP,
                                                                                          C.c_size_t, _VP]),
     "sls_stage1_scratch_bytes": (C.c_size_t, [C.c_int]),
-    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 12 + [_VP, C.c_size_t, _VP]),
+    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 15 + [_VP, C.c_size_t, _VP]),
     "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),
-    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 11 +
+    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 12 +
                            [_VP, C.c_size_t, C.POINTER(C.c_int), _VP] + [_VP] * 8 + [_VP]),
     "sls_block_mask_bytes": (C.c_size_t, [C.c_uint64, C.c_int, C.c_int]),
     "sls_mapping_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),

@@ -10,6 +10,7 @@
 
 #include "../../include/sls_abi.h"
 #include "../../include/sls_spec.h"
+#include "../../include/sls_det_math.h"
 
 #ifndef SLS_TILE_W
 #define SLS_TILE_W 16
@@ -88,7 +89,28 @@ struct DevCam {
     float fx, fy, cx, cy, mod, near_c, far_c;
     float R[9];
     float t[3];
+    SlsTileCullCam tc;      // D10: constants of the tile-level footprint test in the binning (sls_det_math.h)
+    int tile_cull;          // 1: instances that cannot contribute are not emitted (default); 0: the whole rectangle
 };
+
+// Host: the per-camera constants of the tile test, in double and rounded once — the checker computes the same
+// expressions with the same libm (its own copy of this function).
+inline SlsTileCullCam make_tile_cull_cam(float fx, float fy, int W, int wrap)
+{
+    SlsTileCullCam c;
+    const double hx = 0.5 * (double)(kTileW - 1), hy = 0.5 * (double)(kTileH - 1);
+    const double ax = 0.5 / (double)fx, ay = 0.5 / (double)fy;
+    c.chx = (float)cos(ax); c.shx = (float)sin(ax);
+    c.chy = (float)cos(ay); c.shy = (float)sin(ay);
+    const double kx = hx / (double)fx, ky = hy / (double)fy;
+    c.kx = (float)kx; c.ky = (float)ky;
+    const double span = fabs(kx) + fabs(ky);
+    c.eps = (float)(0.5 * span * span * 1.01 + 4.0e-6);
+    c.hx = (float)hx; c.hy = (float)hy;
+    c.wrapW = wrap ? (float)W : 0.0f;
+    c.invW = wrap ? 1.0f / (float)W : 0.0f;
+    return c;
+}
 
 inline DevCam make_devcam(const SlsCamera &c)
 {
@@ -103,6 +125,8 @@ inline DevCam make_devcam(const SlsCamera &c)
     d.mod = c.scale_modifier; d.near_c = c.near_cut; d.far_c = c.far_cut;
     for (int i = 0; i < 9; ++i) d.R[i] = c.Rvw[i];
     for (int i = 0; i < 3; ++i) d.t[i] = c.tvw[i];
+    d.tc = make_tile_cull_cam(d.fx, d.fy, d.W, d.wrap);
+    d.tile_cull = c.reserved == 0 ? 1 : 0;     // SlsCamera.reserved = 1 switches the tile test off (tests, A/B runs)
     return d;
 }
 

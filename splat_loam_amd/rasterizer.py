@@ -109,6 +109,8 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
                                                    int(settings.image_width), float(settings.scale_modifier),
                                                    C.byref(e.cam)), "sls_camera_from_matrices")
     e.cam.pix_offset[0], e.cam.pix_offset[1] = off
+    if os.environ.get("SLS_NO_TILE_CULL", "0") == "1":      # A/B switch: D10 off, the binning emits whole rectangles
+        e.cam.reserved = 1
     e.col_cs, e.row_cs = _ray_tables(e.cam, device)
     e.view_ref, e.proj_ref = v, p
     _CAM_CACHE[key] = e
@@ -136,7 +138,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 class ForwardState:
     """Everything the backward (and the tests) need from one forward."""
-    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "depth", "order", "offsets", "keys", "vals",
+    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "tmask", "depth", "order", "offsets", "keys", "vals",
                  "ranges", "pix_state", "pix_contrib", "tile_consumed", "block_masks", "allmap")
 
 
@@ -171,6 +173,7 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.radii = torch.empty((N,), dtype=i32, device=dev)
     s.rect = torch.empty((N, 4), dtype=i32, device=dev)
     s.tiles = torch.empty((N,), dtype=u32, device=dev)
+    s.tmask = torch.empty((N,), dtype=torch.int64, device=dev)     # D10: which tiles of the rectangle are emitted
     s.depth = torch.empty((N,), dtype=f32, device=dev)
     s.order = torch.empty((N,), dtype=u32, device=dev)
     s.offsets = torch.empty((N,), dtype=u32, device=dev)
@@ -178,8 +181,9 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     sb = int(lib.sls_stage1_scratch_bytes(N))
     scratch1 = torch.empty((max(sb, 4),), dtype=torch.uint8, device=dev)
     _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
-                                      opacities.data_ptr(), s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
-                                      s.tiles.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(),
+                                      opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
+                                      s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
+                                      s.tiles.data_ptr(), s.tmask.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(),
                                       total.data_ptr(), scratch1.data_ptr(), sb, st), "sls_forward_stage1")
     dbg()
     R = int(total.item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
@@ -200,7 +204,7 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.block_masks = torch.empty((int(lib.sls_block_mask_bytes(R, H, W)) // 8,), dtype=torch.int64, device=dev)
     in_tmp = C.c_int(0)
     _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
-                                      s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
+                                      s.tmask.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
                                       keys_a.data_ptr(), vals_a.data_ptr(), keys_b.data_ptr(), vals_b.data_ptr(),
                                       sort_scratch.data_ptr(), ssb, C.byref(in_tmp),
                                       keys64.data_ptr() if want_keys else None, s.ranges.data_ptr(),

@@ -29,6 +29,8 @@ def _compare_forward(oracle32, st, ost, cam, name):
     assert np.array_equal(st.radii.cpu().numpy(), pre["radii"]), f"{name}: radii"
     assert np.array_equal(st.rect.cpu().numpy(), pre["rect"]), f"{name}: rect"
     assert np.array_equal(u32(st.tiles), pre["tiles"]), f"{name}: tiles_touched"
+    tested = (pre["rect"][:, 1] * pre["rect"][:, 3]) <= 64      # (beyond 64 tiles the mask carries no information)
+    assert np.array_equal(st.tmask.cpu().numpy().view(np.uint64)[tested], pre["tmask"][tested]), f"{name}: D10 tile masks"
     assert np.array_equal(u32(st.depth), pre["depth"].view(np.uint32)), f"{name}: depth key bits"
     assert st.R == ost["binned"]["R"], f"{name}: R"
     order = u32(st.order)

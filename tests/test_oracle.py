@@ -238,12 +238,17 @@ def test_pure_torch_tile_rasterizer_matches_checker(oracle32):
     N, H, W = 4000, 32, 256
     sc = synth.make_scene(N, H, W, seed=5, range_lo=2.0, range_hi=20.0)
     view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(2)[1])
+    # (the pure-torch rasterizer bins a surfel's whole tile rectangle; the checker's D10 test only removes
+    #  instances that contribute nothing, so the images agree either way — compared with D10 on — and the
+    #  instance count is the un-culled one)
     cam = oracle32.camera(H, W, view, proj)
     ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    R_rect = oracle32.bin_sort(oracle32.camera(H, W, view, proj, tile_cull=False), oracle32.preprocess(
+        oracle32.camera(H, W, view, proj, tile_cull=False), sc["means"], sc["scales"], sc["rots"], sc["opac"]))["R"]
     t = {k: torch.tensor(sc[k]).requires_grad_(True) for k in ("means", "scales", "rots", "opac")}
     stats = {}
     radii, am = tt.rasterize(tt.camera_dict(H, W, view, proj), t["means"], t["scales"], t["rots"], t["opac"], stats=stats)
-    assert stats["R"] == ost["binned"]["R"] and np.array_equal(radii.numpy(), ost["radii"])
+    assert stats["R"] == R_rect >= ost["binned"]["R"] and np.array_equal(radii.numpy(), ost["radii"])
     ok = ~ost["fwd"]["fragile"]
     for ch in range(7):
         ref = ost["allmap"][ch]
@@ -278,7 +283,7 @@ def test_integer_outputs_reproduced_with_independent_math(oracle32):
                                 (20000, 64, 512, 9, dict(range_lo=1.0, range_hi=8.0, scale_lo=0.05, scale_hi=0.5))):
         sc = synth.make_scene(N, H, W, seed=seed, **kw)
         view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(2)[1])
-        cam = oracle32.camera(H, W, view, proj)
+        cam = oracle32.camera(H, W, view, proj, tile_cull=False)      # rectangles: D10 has its own tests (test_tile_cull.py)
         pre = oracle32.preprocess(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
         b = oracle32.bin_sort(cam, pre)
         t = {k: torch.tensor(sc[k]) for k in ("means", "scales", "rots", "opac")}

@@ -40,17 +40,18 @@ enum Op {
     OP_STEP_MIX,       // the forward step's class mix (counts from the disassembly, see kMix below)
     OP_CNDMASK_SGPR,   // v_cndmask_b32_e64 with an SGPR-pair mask (the form the tile kernels mostly use)
     OP_CNDMASK_VCC_W,  // v_cmp writes vcc, v_cndmask reads it (pairs, as a select compiles)
+    OP_CNDMASK_VCC_S,  // s_and_b64 writes vcc (a combined condition), four v_cndmask_b32_e32 read it: as the backward step does
     OP_COUNT
 };
 static const char *kOpName[OP_COUNT] = {
     "v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mov_b32_dpp", "v_add_f32_dpp",
     "v_permlane32_swap", "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b128", "v_fma_f32 chain", "v_exp_f32 chain",
-    "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix", "v_cndmask_b32 sgpr", "v_cmp+v_cndmask"
+    "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix", "v_cndmask_b32 sgpr", "v_cmp+v_cndmask", "s_and vcc + 4 v_cndmask"
 };
 // wave-instructions per loop iteration of each kernel (what the time is divided by)
-static const int kPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 8, 64, 64, 64, 8, 96, 64, 64 };
+static const int kPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 8, 64, 64, 64, 8, 96, 64, 64, 80 };
 // VALU wave-instructions per loop iteration (for the SQ_INSTS_VALU cross-check)
-static const int kValuPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 8, 84, 64, 64 };
+static const int kValuPerIter[OP_COUNT] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 0, 64, 64, 64, 8, 84, 64, 64, 64 };
 
 #define REP8(x) x x x x x x x x
 #define A8 "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(1024) void calib_kernel(float *out, int iters, uint
         else if (OP == OP_CNDMASK_VCC_W) {
             REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
                               "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n" : A8 : "v"(m) : "vcc");)
+        }
+        else if (OP == OP_CNDMASK_VCC_S) {
+            const uint64_t m0 = 0x5555555555555555ull ^ (uint64_t)blockIdx.x, m1 = 0x3333333333333333ull ^ (uint64_t)i;
+            REP8(asm volatile("s_and_b64 vcc, %8, %9\n v_cndmask_b32 %0, %0, %10, vcc\n v_cndmask_b32 %1, %1, %10, vcc\n v_cndmask_b32 %2, %2, %10, vcc\n v_cndmask_b32 %3, %3, %10, vcc\n"
+                              "s_and_b64 vcc, %9, %8\n v_cndmask_b32 %4, %4, %10, vcc\n v_cndmask_b32 %5, %5, %10, vcc\n v_cndmask_b32 %6, %6, %10, vcc\n v_cndmask_b32 %7, %7, %10, vcc\n" : A8 : "s"(m0), "s"(m1), "v"(m) : "vcc");)
         }
         else if (OP == OP_CMP) {
             REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
@@ -243,6 +249,7 @@ int main(int argc, char **argv)
     sweep<OP_STEP_MIX>(all, d_out, d_clk, cus);
     sweep<OP_CNDMASK_SGPR>(all, d_out, d_clk, cus);
     sweep<OP_CNDMASK_VCC_W>(all, d_out, d_clk, cus);
+    sweep<OP_CNDMASK_VCC_S>(all, d_out, d_clk, cus);
     printf("%-22s %5s %9s %12s %12s %8s\n", "class", "w/SIMD", "ms", "ns/inst/SIMD", "clk/inst/SIMD", "MHz");
     for (const Result &r : all)
         printf("%-22s %5d %9.3f %12.3f %12.3f %8.0f\n", kOpName[r.op], r.waves, r.ms, r.ns_per_inst, r.clk_per_inst, r.mhz);

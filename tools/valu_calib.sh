@@ -19,7 +19,7 @@ plain = json.load(open("/tmp/valu_plain.json"))
 cus = plain["cus"]
 names = ["v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_mov_b32_dpp", "v_add_f32_dpp",
          "v_permlane32_swap", "v_cndmask_b32", "v_cmp_lt_f32", "ds_read_b128", "v_fma_f32 chain", "v_exp_f32 chain",
-         "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix", "v_cndmask_b32 sgpr", "v_cmp+v_cndmask"]
+         "v_mov_b32_dpp chain", "ballot+branch", "fwd step mix", "v_cndmask_b32 sgpr", "v_cmp+v_cndmask", "s_and vcc + 4 v_cndmask"]
 pmc = {}
 f = glob.glob("/tmp/valu_pmc/**/*counter_collection.csv", recursive=True)
 if f:
