@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         SlsTileCullSurfel *s_cull_w = reinterpret_cast<SlsTileCullSurfel *>(s_rect_w + 64);
         uint32_t *s_scan_w = reinterpret_cast<uint32_t *>(s_cull_w + 64);
         uint32_t *s_drop_w = s_scan_w + 64;                       // [64][2]
-        if (tested) { s_cull_w[lane] = cull; s_rect_w[lane] = my_rc; }
+        if (tested) s_cull_w[lane] = cull;
+        s_rect_w[lane] = tested ? my_rc : make_int4(0, 1, 0, 1);     // (every lane: lanes beyond the last pair read owner 0)
         uint32_t incl = tested ? my_tiles : 0u;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             if (tx >= cam.GX) tx -= cam.GX;
             const int ty = orc.z + ky;
             const int x0 = tx * kTileW, y0 = ty * kTileH;
-            const float2 cc = col_cs[min(x0 + kTileW / 2 - 1, cam.W - 1)], rr = row_cs[min(max(y0 + kTileH / 2 - 1, 0), cam.H - 1)];
+            const float2 cc = col_cs[min(max(x0 + kTileW / 2 - 1, 0), cam.W - 1)], rr = row_cs[min(max(y0 + kTileH / 2 - 1, 0), cam.H - 1)];
             const int out = sls_tile_outside(&cam.tc, &s_cull_w[owner], (float)x0, (float)y0, cc.x, cc.y, rr.x, rr.y);
             if (valid && out) atomicOr(&s_drop_w[2 * owner + (int)(idx >> 5)], 1u << (idx & 31u));
         }

@@ -249,7 +249,6 @@ int main(int argc, char **argv)
     sweep<OP_STEP_MIX>(all, d_out, d_clk, cus);
     sweep<OP_CNDMASK_SGPR>(all, d_out, d_clk, cus);
     sweep<OP_CNDMASK_VCC_W>(all, d_out, d_clk, cus);
-    sweep<OP_CNDMASK_VCC_S>(all, d_out, d_clk, cus);
     printf("%-22s %5s %9s %12s %12s %8s\n", "class", "w/SIMD", "ms", "ns/inst/SIMD", "clk/inst/SIMD", "MHz");
     for (const Result &r : all)
         printf("%-22s %5d %9.3f %12.3f %12.3f %8.0f\n", kOpName[r.op], r.waves, r.ms, r.ns_per_inst, r.clk_per_inst, r.mhz);
