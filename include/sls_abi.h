@@ -54,9 +54,10 @@ extern "C" {
 typedef struct SlsCamera {
     int32_t H, W;           /* image_height, image_width                        */
     int32_t wrap;           /* 1: azimuth wraps (360 deg image), D5             */
-    int32_t reserved;       /* 0 (default): D10, the binning emits only the instances of a surfel's tile rectangle
-                             * whose tile the footprint can reach (include/sls_det_math.h: sls_tile_outside);
-                             * 1: every tile of the rectangle (the pre-D10 lists; tests, A/B runs) */
+    int32_t tile_cull_min;  /* D10: the binning emits only the instances of a surfel's tile rectangle whose tile the
+                             * footprint can reach (include/sls_det_math.h: sls_tile_outside), for rectangles of at
+                             * least this many (and at most 64) tiles.  0: the default (SLS_TILE_CULL_MIN_DEFAULT, 6);
+                             * 1: test off, every tile of the rectangle (the pre-D10 lists); k >= 2: threshold k */
     float fx, fy, cx, cy;   /* K = projmatrix[:3,:3]^T : u = fx*az+cx, v = fy*el+cy */
     float scale_modifier;
     float near_cut, far_cut;
@@ -101,12 +102,12 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 
 /* ---- forward, stage 1: preprocess + depth order + scan ---------------------
  * col_cs / row_cs: the DEVICE copies of sls_ray_tables (the tile test of D10 takes its tile-centre directions
- * from them; may be null with cam->reserved = 1).
+ * from them; may be null with cam->tile_cull_min = 1).
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
  * tiles_touched: N uint32 = number of tile instances the surfel emits,
  * tile_mask: N uint64 — bit k set: the k-th tile of the rectangle (row-major, the emission order) is emitted;
- *   rectangles of fewer than 3 or more than 64 tiles are not tested and emit every tile (mask = all ones
- *   below the tile count),
+ *   rectangles of fewer than cam->tile_cull_min or more than 64 tiles are not tested and emit every tile (mask =
+ *   all ones below the tile count),
  * depth: N floats (range of the centre, the sort key),
  * order: N uint32 = surfel index at each position of the (range, index) order (ALL surfels,
  *        culled ones included at their range; they have tiles_touched = 0 and emit nothing),

@@ -23,6 +23,7 @@ REC_STRIDE = 20
 GREC_STRIDE = 16
 NEAR = float(np.float32(0.2))  # SLS_NEAR / SLS_FAR are float literals
 FAR = 100.0
+TILE_CULL_MIN_DEFAULT = 6   # SLS_TILE_CULL_MIN_DEFAULT (include/sls_spec.h)
 
 
 def build(force: bool = False) -> None:
@@ -76,8 +77,10 @@ class Camera:
             wrap = should_wrap(self.fx, self.W, self.tile[0])
         self.wrap = int(bool(wrap))
         self.dtype = np.dtype(dtype)
-        self.tile_cull = bool(tile_cull)     # D10: the binning drops instances whose tile the footprint cannot reach
-        self.icam = np.array([self.H, self.W, self.tile[0], self.tile[1], self.wrap, int(self.tile_cull)], dtype=np.int32)
+        # D10: the binning drops instances whose tile the footprint cannot reach, for rectangles of at least this many
+        # tiles (True: SLS_TILE_CULL_MIN_DEFAULT of include/sls_spec.h; False / 0: off)
+        self.tile_cull = TILE_CULL_MIN_DEFAULT if tile_cull is True else int(tile_cull or 0)
+        self.icam = np.array([self.H, self.W, self.tile[0], self.tile[1], self.wrap, self.tile_cull], dtype=np.int32)
         Rvw = V[:3, :3].T
         tvw = V[3, :3]
         self.fcam = np.concatenate([

@@ -55,7 +55,7 @@ typedef sls_real real;
 
 /* icam: H, W, tile_w, tile_h, wrap
  * fcam: fx, fy, cx, cy, scale_modifier, near, far, Rvw[9] (row-major), tvw[3] */
-enum { IC_H = 0, IC_W, IC_TW, IC_TH, IC_WRAP, IC_TILECULL, IC_COUNT };   /* IC_TILECULL: D10 on (1) / off (0) */
+enum { IC_H = 0, IC_W, IC_TW, IC_TH, IC_WRAP, IC_TILECULL, IC_COUNT };   /* IC_TILECULL: D10 threshold (tiles), 0 = off */
 enum { FC_FX = 0, FC_FY, FC_CX, FC_CY, FC_MOD, FC_NEAR, FC_FAR, FC_R = 7, FC_T = 16, FC_COUNT = 19 };
 
 int or_real_bytes(void) { return (int)sizeof(real); }
@@ -159,7 +159,6 @@ static SlsTileCullCam tile_cull_consts(const int32_t *ic, const real *fc)
     c.invW = ic[IC_WRAP] ? RC(1.0) / (real)ic[IC_W] : RC(0.0);
     return c;
 }
-#define SLS_TILE_CULL_MIN 3   /* rectangles of 3 .. 64 tiles are tested */
 
 /* ------------------------------------------------------------------ */
 /* A1 preprocess (called inside                     */
@@ -173,7 +172,7 @@ void or_preprocess(const int32_t *ic, const real *fc, int N,
                    real *rec, int32_t *radii, int32_t *rect, uint32_t *tiles, uint64_t *tmask, real *depth)
 {
     const SlsTileCullCam tcc = tile_cull_consts(ic, fc);
-    const int tile_cull = ic[IC_TILECULL] && col_cs && row_cs;
+    const int tile_cull = (col_cs && row_cs) ? ic[IC_TILECULL] : 0;   /* rectangles of tile_cull .. 64 tiles are tested */
     const int H = ic[IC_H], W = ic[IC_W], TW = ic[IC_TW], TH = ic[IC_TH], wrap = ic[IC_WRAP];
     const int GX = (W + TW - 1) / TW;
     const real fx = fc[FC_FX], fy = fc[FC_FY], cx = fc[FC_CX], cy = fc[FC_CY];
@@ -246,7 +245,7 @@ void or_preprocess(const int32_t *ic, const real *fc, int N,
         /* D10: which tiles of the rectangle (row-major, the emission order) the footprint can reach */
         const int nrect = ncols * nrows;
         uint64_t mask = nrect >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << nrect) - 1);
-        if (tile_cull && nrect >= SLS_TILE_CULL_MIN && nrect <= 64) {
+        if (tile_cull > 0 && nrect >= tile_cull && nrect <= 64) {
             SlsTileCullSurfel cs;
             sls_tile_cull_surfel(Tu, Tv, n, p, rho, su, sv, opac[i], cpx, cpy, &cs);
             for (int idx = 0; idx < nrect; ++idx) {

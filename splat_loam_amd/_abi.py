@@ -18,7 +18,7 @@ SLS_OK = 0
 
 class SlsCamera(C.Structure):
     _fields_ = [
-        ("H", C.c_int32), ("W", C.c_int32), ("wrap", C.c_int32), ("reserved", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("wrap", C.c_int32), ("tile_cull_min", C.c_int32),
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
         ("scale_modifier", C.c_float), ("near_cut", C.c_float), ("far_cut", C.c_float), ("pad", C.c_float),
         ("Rvw", C.c_float * 9), ("tvw", C.c_float * 3),

@@ -90,7 +90,8 @@ struct DevCam {
     float R[9];
     float t[3];
     SlsTileCullCam tc;      // D10: constants of the tile-level footprint test in the binning (sls_det_math.h)
-    int tile_cull;          // 1: instances that cannot contribute are not emitted (default); 0: the whole rectangle
+    int tile_cull;          // D10: rectangles of at least this many (and at most 64) tiles are tested, instances that
+                            // cannot contribute are not emitted; 0: off, the whole rectangle is emitted
 };
 
 // Host: the per-camera constants of the tile test, in double and rounded once — the checker computes the same
@@ -126,7 +127,8 @@ inline DevCam make_devcam(const SlsCamera &c)
     for (int i = 0; i < 9; ++i) d.R[i] = c.Rvw[i];
     for (int i = 0; i < 3; ++i) d.t[i] = c.tvw[i];
     d.tc = make_tile_cull_cam(d.fx, d.fy, d.W, d.wrap);
-    d.tile_cull = c.reserved == 0 ? 1 : 0;     // SlsCamera.reserved = 1 switches the tile test off (tests, A/B runs)
+    // SlsCamera.tile_cull_min: 0 = the default threshold, 1 = test off, k >= 2 = rectangles of k..64 tiles are tested
+    d.tile_cull = c.tile_cull_min == 0 ? SLS_TILE_CULL_MIN_DEFAULT : (c.tile_cull_min == 1 ? 0 : c.tile_cull_min);
     return d;
 }
 

@@ -14,7 +14,8 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr,
-                          const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr);
+                          const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr,
+                          int32_t *erec = nullptr);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
@@ -33,7 +34,8 @@ struct ScanHandoff {
     const uint64_t *resort_edges;
 };
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
-                    const int32_t *rect, const uint32_t *tiles, const uint64_t *tile_mask, const float *depth, const uint32_t *offsets,
+                    const int32_t *rect, const uint32_t *tiles, const uint64_t *tile_mask, const int32_t *erec,
+                    const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
                     uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff = nullptr,
@@ -62,7 +64,7 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
 // workspace of sls_mapping_step: one caller-owned buffer, carved here
 // ---------------------------------------------------------------------------
 struct MapWs {
-    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; float *depth; uint32_t *order; uint32_t *offsets;
+    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; int32_t *erec; float *depth; uint32_t *order; uint32_t *offsets;
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
@@ -87,6 +89,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.rect = (int32_t *)take(n * 16);
     w.tiles = (uint32_t *)take(n * 4);
     w.tmask = (uint64_t *)take(n * 8);
+    w.erec = (int32_t *)take(n * 16);
     w.depth = (float *)take(n * 4);
     w.order = (uint32_t *)take(n * 4);
     w.offsets = (uint32_t *)take(n * 4);
@@ -149,8 +152,8 @@ int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const 
     SLS_REQUIRE(means3D && scales && rotations && opacities && rec && radii && rect && tiles_touched && depth &&
                     order && offsets && scratch,
                 "null pointer");
-    SLS_REQUIRE(cam->reserved != 0 || (col_cs && row_cs && tile_mask),
-                "the tile-level footprint test (SlsCamera.reserved = 0) needs the ray tables and a tile_mask buffer");
+    SLS_REQUIRE(cam->tile_cull_min == 1 || (col_cs && row_cs && tile_mask),
+                "the tile-level footprint test (SlsCamera.tile_cull_min != 1) needs the ray tables and a tile_mask buffer");
     const DevCam dc = make_devcam(*cam);
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("stage1 scratch too small");
@@ -187,7 +190,7 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     hipStream_t st = (hipStream_t)stream;
     const DevCam dc = make_devcam(*cam);
     int rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched,
-                             cam->reserved == 0 ? tile_mask : nullptr, depth, offsets, tkeys, vals,
+                             cam->tile_cull_min != 1 ? tile_mask : nullptr, nullptr, depth, offsets, tkeys, vals,
                              tkeys_tmp, vals_tmp, sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges,
                              keys64_out, nullptr, st);
     if (rc) return rc;
@@ -318,14 +321,15 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask);
+                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec);
     if (rc) return rc;
     ScanHandoff handoff = { nullptr, 0, nullptr };   // the emission finishes the scan of tiles_touched
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff);
     if (rc) return rc;
     int in_tmp = 0;
-    rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr, w.depth,
+    rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
+                         (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
                          w.offsets, w.tkeys, w.vals,
                          w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
                          &status_dev->overflow, st, &handoff, &status_dev->R);

@@ -93,9 +93,7 @@ __device__ __forceinline__ void ball_extent(float rad, float rho, float rxy, flo
     }
 }
 
-// D10 applies to rectangles of at least this many tiles (a single tile always holds the centre pixel, and of the
-// instances the test removes on the bench scene 97 % belong to rectangles of 3 tiles or more)
-constexpr int kTileCullMin = 3;
+__device__ __forceinline__ uint32_t s_rect_cnt(const int4 rc) { return (uint32_t)(rc.y * rc.w); }
 
 struct SurfelGeom {
     float p[3], rho, rho2, rxy, rxy2;
@@ -184,12 +182,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     float4 *__restrict__ rec, int *__restrict__ radii, int4 *__restrict__ rect,
     uint32_t *__restrict__ tiles, float *__restrict__ depth, uint32_t *__restrict__ order_keys,
     uint32_t *__restrict__ order_vals, uint32_t *__restrict__ n_dev, const float2 *__restrict__ col_cs,
-    const float2 *__restrict__ row_cs, uint64_t *__restrict__ tile_mask)
+    const float2 *__restrict__ row_cs, uint64_t *__restrict__ tile_mask, int4 *__restrict__ erec)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint32_t my_tiles = 0;
     // D10 (sls_det_math.h): which tiles of the rectangle the footprint can reach — bit k = k-th tile in emission
-    // order (row-major).  Tested for rectangles of kTileCullMin .. 64 tiles; others keep the whole rectangle.
+    // order (row-major).  Tested for rectangles of cam.tile_cull .. 64 tiles; others keep the whole rectangle.
     uint64_t my_mask = 0;
     bool tested = false;
     SlsTileCullSurfel cull;
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 my_tiles = (uint32_t)(ncols * nrows);
                 my_rc = rc;
                 my_mask = my_tiles >= 64u ? ~0ull : ((1ull << my_tiles) - 1ull);
-                tested = cam.tile_cull && tile_mask && my_tiles >= (uint32_t)kTileCullMin && my_tiles <= 64u;
+                tested = cam.tile_cull > 0 && tile_mask && my_tiles >= (uint32_t)cam.tile_cull && my_tiles <= 64u;
                 if (tested) sls_tile_cull_surfel(g.Tu, g.Tv, g.n, g.p, g.rho, g.su, g.sv, o, cpx, cpy, &cull);
                 r_out = to_int_clamped(ceilf(fmaxf(rx, ry)));
                 dep = g.rho;
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     // ---- D10: the tile tests of a wave's surfels, dealt out evenly over its lanes (a surfel's rectangle has 1 to 18
     // tiles on the bench scene: lane-per-surfel loops would run at the pace of the largest rectangle of the wave)
     // One wave-private LDS slice serves the tile tests and, afterwards, the staging of the records.
-    constexpr int kCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 3 * sizeof(uint32_t));
+    constexpr int kCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
     constexpr int kSliceBytes = kCullBytes > 64 * kRec4 * 16 ? kCullBytes : 64 * kRec4 * 16;
     __shared__ __attribute__((aligned(16))) unsigned char s_slice[4][kSliceBytes];
     if (__ballot(tested)) {
@@ -326,6 +324,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         SlsTileCullSurfel *s_cull_w = reinterpret_cast<SlsTileCullSurfel *>(s_rect_w + 64);
         uint32_t *s_scan_w = reinterpret_cast<uint32_t *>(s_cull_w + 64);
         uint32_t *s_drop_w = s_scan_w + 64;                       // [64][2]
+        uint32_t *s_seg_w = s_drop_w + 128;                       // [64]: lane of the r-th tested surfel
+        uint32_t *s_ends_w = s_seg_w + 64;                        // [2]
         if (tested) s_cull_w[lane] = cull;
         s_rect_w[lane] = tested ? my_rc : make_int4(0, 1, 0, 1);     // (every lane: lanes beyond the last pair read owner 0)
         uint32_t incl = tested ? my_tiles : 0u;
@@ -336,20 +336,29 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         }
         s_scan_w[lane] = incl;
         s_drop_w[2 * lane] = 0u; s_drop_w[2 * lane + 1] = 0u;
+        {   // the tested lanes in lane order
+            const uint64_t tb = __ballot(tested);
+            if (tested) s_seg_w[__popcll(tb & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+            if (lane == 0) { s_ends_w[0] = 0u; s_ends_w[1] = 0u; }
+        }
+        int seg_base = 0;
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         __builtin_amdgcn_wave_barrier();
         for (uint32_t base = 0; base < total; base += 64u) {
             const uint32_t j = base + (uint32_t)lane;
             const bool valid = j < total;
-            // owner = first lane whose inclusive count exceeds j
-            int lo = 0, hi = 63;
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi) >> 1;
-                if (s_scan_w[mid] > j) hi = mid; else lo = mid + 1;
-            }
-            const int owner = valid ? lo : 0;
-            const uint32_t idx = valid ? j - (owner ? s_scan_w[owner - 1] : 0u) : 0u;
+            // owner = first lane whose inclusive count exceeds j = number of segment ends <= j.  The ends of the
+            // tested lanes are distinct (each has at least one pair): the ends that fall into this chunk as a 64-bit
+            // mask (one LDS atomic per tested lane), the ends before it as a running count
+            if (tested && incl > base && incl <= base + 64u) atomicOr(&s_ends_w[(incl - 1u - base) >> 5], 1u << ((incl - 1u - base) & 31u));
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t ends = ((uint64_t)s_ends_w[1] << 32) | (uint64_t)s_ends_w[0];    // bit p: a segment's LAST pair is base + p
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { s_ends_w[0] = 0u; s_ends_w[1] = 0u; }
+            const int seg = seg_base + (int)__popcll(ends & ((1ull << lane) - 1ull));           // segments that end before pair j
+            seg_base += (int)__popcll(ends);
+            const int owner = valid ? (int)s_seg_w[min(seg, 63)] : 0;
+            const uint32_t idx = valid ? j - (s_scan_w[owner] - s_rect_cnt(s_rect_w[owner])) : 0u;
             const int4 orc = s_rect_w[owner];
             const int ncols = max(orc.y, 1);
             const int ky = (int)idx / ncols, kx = (int)idx - ky * ncols;
@@ -372,6 +381,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     if (i < N) {
         tiles[i] = my_tiles;
         if (tile_mask) tile_mask[i] = my_mask;
+        // what the emission reads, in ONE 16-byte gather: the rectangle (16-bit fields) and the mask
+        if (erec) erec[i] = make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
     }
     {   // the 80-byte records leave through LDS so that every store instruction writes 1 KB of
         // consecutive addresses (a direct store would touch 40 cache lines per instruction)
@@ -602,7 +613,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear,
-                          const float *col_cs, const float *row_cs, uint64_t *tile_mask)
+                          const float *col_cs, const float *row_cs, uint64_t *tile_mask, int32_t *erec)
 {
     const int nb = (N + 255) / 256;
     RegArgs ra;
@@ -611,7 +622,8 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
                        (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, order_keys,
                        order_vals, n_dev, (const float2 *)col_cs, (const float2 *)row_cs,
-                       (col_cs && row_cs) ? tile_mask : nullptr);
+                       (col_cs && row_cs) ? tile_mask : nullptr,
+                       (cam.GX < 65536 && cam.GY < 65536) ? (int4 *)erec : nullptr);
     SLS_LAUNCH_CHECK("preprocess_fwd_kernel");
     return SLS_OK;
 }

@@ -643,6 +643,7 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
                                                          const int4 *__restrict__ rect,
                                                          const uint32_t *__restrict__ tiles,
                                                          const uint64_t *__restrict__ tile_mask,
+                                                         const int4 *__restrict__ erec,
                                                          const uint32_t *__restrict__ offsets, uint32_t cap,
                                                          uint32_t *__restrict__ tkeys, uint32_t *__restrict__ vals,
                                                          uint32_t *__restrict__ overflow, int pack_shift,
@@ -653,10 +654,20 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
     const int i = blockIdx.x * 256 + threadIdx.x;
     // ONE dependent round trip per surfel: the rectangle (all zeros for a culled surfel) and the mask of its tiles
     // that the footprint can reach (D10; null: the whole rectangle) give the tile count
+    // (erec: the same two things packed by preprocess into one 16-byte word)
     const uint32_t g = order[min(i, N - 1)];
-    const int4 rc = rect[g];
+    int4 rc;
+    uint64_t mask;
+    if (erec) {
+        const int4 e = erec[g];
+        rc = make_int4(e.x & 0xFFFF, e.y & 0xFFFF, (int)((uint32_t)e.x >> 16), (int)((uint32_t)e.y >> 16));
+        mask = ((uint64_t)(uint32_t)e.w << 32) | (uint64_t)(uint32_t)e.z;
+    } else {
+        rc = rect[g];
+        mask = (tile_mask && (uint32_t)(rc.y * rc.w) <= 64u) ? tile_mask[g] : ~0ull;
+    }
     const uint32_t nrect = (uint32_t)(rc.y * rc.w);
-    const uint64_t mask = (tile_mask && nrect <= 64u) ? tile_mask[g] : ~0ull;
+    if (nrect > 64u) mask = ~0ull;
     const uint32_t t = (i < N) ? (nrect <= 64u ? (uint32_t)__popcll(mask & (nrect >= 64u ? ~0ull : ((1ull << nrect) - 1ull))) : nrect) : 0u;
     uint32_t end;
     if (fused.block_sums) {
@@ -852,7 +863,8 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
 //   count_ptr: device R; cap: host-side capacity of the buffers (>= R, or the
 //   overflow flag is raised and the excess instances are dropped)
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
-                    const int32_t *rect, const uint32_t *tiles, const uint64_t *tile_mask, const float *depth, const uint32_t *offsets,
+                    const int32_t *rect, const uint32_t *tiles, const uint64_t *tile_mask, const int32_t *erec,
+                    const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
                     uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff, uint32_t *total_out)
@@ -878,7 +890,7 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
-                           (const int4 *)rect, tiles, tile_mask, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow,
+                           (const int4 *)rect, tiles, tile_mask, (const int4 *)erec, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow,
                            packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,
                            overflow);
     }

@@ -36,6 +36,8 @@ class GaussianRasterizationSettings(NamedTuple):
     # (0, 0), the lineage convention; (-0.5, -0.5) is the convention of the reference's own back-projection and
     # projector (utils/graphic_utils.py:46-49), under which a rendered keyframe registers without the half-pixel bias
     pix_offset: Optional[tuple] = None
+    # extension: threshold of D10's tile-level footprint test (SlsCamera.tile_cull_min: 0 default, 1 off, k >= 2)
+    tile_cull_min: Optional[int] = None
 
 
 _PIX_OFFSET = None
@@ -93,8 +95,11 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
     v, p = settings.viewmatrix, settings.projmatrix
     off = getattr(settings, "pix_offset", None)
     off = pix_offset() if off is None else (float(off[0]), float(off[1]))
+    tcm = getattr(settings, "tile_cull_min", None)
+    if tcm is None:        # A/B switches: SLS_NO_TILE_CULL=1 — D10 off (whole rectangles); SLS_TILE_CULL_MIN=k — threshold
+        tcm = 1 if os.environ.get("SLS_NO_TILE_CULL", "0") == "1" else int(os.environ.get("SLS_TILE_CULL_MIN", "0"))
     key = (v.data_ptr(), v._version, p.data_ptr(), p._version, int(settings.image_height),
-           int(settings.image_width), float(settings.scale_modifier), off, str(device))
+           int(settings.image_width), float(settings.scale_modifier), off, int(tcm), str(device))
     hit = _CAM_CACHE.get(key)
     if hit is not None:
         _CAM_CACHE.move_to_end(key)
@@ -109,8 +114,7 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
                                                    int(settings.image_width), float(settings.scale_modifier),
                                                    C.byref(e.cam)), "sls_camera_from_matrices")
     e.cam.pix_offset[0], e.cam.pix_offset[1] = off
-    if os.environ.get("SLS_NO_TILE_CULL", "0") == "1":      # A/B switch: D10 off, the binning emits whole rectangles
-        e.cam.reserved = 1
+    e.cam.tile_cull_min = int(tcm)
     e.col_cs, e.row_cs = _ray_tables(e.cam, device)
     e.view_ref, e.proj_ref = v, p
     _CAM_CACHE[key] = e

@@ -20,11 +20,11 @@ def scene_and_camera(N, H, W, seed=0, pose=None, hfov_deg=360.0, **kw):
     return sc, view, proj
 
 
-def hip_forward(device, sc, view, proj, H, W, scale_modifier=1.0, pix_offset=None):
+def hip_forward(device, sc, view, proj, H, W, scale_modifier=1.0, pix_offset=None, tile_cull_min=None):
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, scale_modifier=scale_modifier,
         viewmatrix=torch.tensor(view, device=device), projmatrix=torch.tensor(proj, device=device),
-        prefiltered=False, debug=True, pix_offset=pix_offset)
+        prefiltered=False, debug=True, pix_offset=pix_offset, tile_cull_min=tile_cull_min)
     t = {k: torch.tensor(sc[k], device=device) for k in ("means", "scales", "rots", "opac")}
     st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"], want_keys=True)
     torch.cuda.synchronize()

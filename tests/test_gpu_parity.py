@@ -114,6 +114,21 @@ def _compare_backward(oracle32, st, t, ost, sc, name, seed=3):
     return worst
 
 
+@pytest.mark.parametrize("kmin", [1, 2, 3])
+def test_tile_cull_thresholds_parity(device, oracle32, kmin):
+    """D10 at other thresholds than the default (SlsCamera.tile_cull_min: 1 = off, 2 and 3 = test nearly every / most
+    rectangles): tile masks, tiles_touched, the sorted lists and the image stay bit-exact / within the bar against the
+    checker at the same threshold, on a scene of large tilted footprints."""
+    from splat_loam_amd import _abi
+    N, H, W = 8000, 64, 1024
+    sc, view, proj = scene_and_camera(N, H, W, seed=29, range_lo=1.5, range_hi=12.0, scale_lo=0.01, scale_hi=0.6, max_tilt_deg=80.0)
+    st, t = hip_forward(device, sc, view, proj, H, W, tile_cull_min=kmin)
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size(), tile_cull=(0 if kmin == 1 else kmin))
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    _compare_forward(oracle32, st, ost, cam, f"tile_cull_min{kmin}")
+    _compare_backward(oracle32, st, t, ost, sc, f"tile_cull_min{kmin}")
+
+
 @pytest.mark.parametrize("offset", [(-0.5, -0.5), (0.25, -0.125)])
 def test_pixel_centre_offset_parity(device, oracle32, offset):
     """D1 as a parameter (SlsCamera.pix_offset): pixel (c, r) at image coordinate (c + ox, r + oy).  The reference's

@@ -34,7 +34,7 @@ def test_tile_cull_changes_no_pixel_and_no_gradient(oracle32, name, N, H, W, hfo
     sc, view, proj = _scene(N, H, W, hfov, pose_idx, kw)
     off = (-0.5, -0.5) if name == "half_pixel_offset" else (0.0, 0.0)
     args = (sc["means"], sc["scales"], sc["rots"], sc["opac"])
-    on = oracle32.forward(oracle32.camera(H, W, view, proj, pix_offset=off), *args)
+    on = oracle32.forward(oracle32.camera(H, W, view, proj, pix_offset=off, tile_cull=3), *args)
     no = oracle32.forward(oracle32.camera(H, W, view, proj, pix_offset=off, tile_cull=False), *args)
     R_on, R_no = on["binned"]["R"], no["binned"]["R"]
     assert R_on <= R_no and np.array_equal(on["pre"]["rect"], no["pre"]["rect"])
@@ -59,7 +59,7 @@ def test_dropped_tiles_hold_no_pixel_above_the_alpha_threshold(oracle32):
     spec and the raw inputs, never reaches 1/255 (a sample of the bench-like scene's drops)."""
     N, H, W = 60000, 64, 1024
     sc, view, proj = _scene(N, H, W, 360.0, None, {}, seed=9)
-    cam = oracle32.camera(H, W, view, proj)
+    cam = oracle32.camera(H, W, view, proj, tile_cull=3)
     pre = oracle32.preprocess(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
     rect, mask = pre["rect"], pre["tmask"]
     nrect = rect[:, 1] * rect[:, 3]
@@ -107,18 +107,20 @@ def test_dropped_tiles_hold_no_pixel_above_the_alpha_threshold(oracle32):
     assert checked >= 400
 
 
-def test_tile_cull_on_the_bench_scene():
-    """C3 (500k surfels, 64x2048): >= 9 % fewer instances, identical image."""
+@pytest.mark.parametrize("kmin", [3, 6])
+def test_tile_cull_on_the_bench_scene(kmin):
+    """C3 (500k surfels, 64x2048), identical image; rectangles of >= 3 tiles tested: 9.9 % fewer instances, 17.9 %
+    shorter consumed prefixes; >= 6 tiles (the default: a third of the tests): 6 % / 13.7 %."""
     o = Oracle(np.float32)
     N, H, W = 500_000, 64, 2048
     sc = synth.make_scene(N, H, W, seed=0)
     view, proj = synth.camera_matrices(sc["K"], None)
     args = (sc["means"], sc["scales"], sc["rots"], sc["opac"])
-    on = o.forward(o.camera(H, W, view, proj), *args, frag_tol=0.0)
+    on = o.forward(o.camera(H, W, view, proj, tile_cull=kmin), *args, frag_tol=0.0)
     no = o.forward(o.camera(H, W, view, proj, tile_cull=False), *args, frag_tol=0.0)
     assert np.array_equal(on["allmap"].view(np.uint32), no["allmap"].view(np.uint32))
     R_on, R_no = on["binned"]["R"], no["binned"]["R"]
     c_on, c_no = int(on["fwd"]["tile_consumed"].sum()), int(no["fwd"]["tile_consumed"].sum())
-    print(f"\n[C3] instances {R_no} -> {R_on} (-{100 * (1 - R_on / R_no):.1f} %), consumed prefixes {c_no} -> {c_on} "
+    print(f"\n[C3, rectangles of >= {kmin} tiles] instances {R_no} -> {R_on} (-{100 * (1 - R_on / R_no):.1f} %), consumed prefixes {c_no} -> {c_on} "
           f"(-{100 * (1 - c_on / c_no):.1f} %)")
-    assert R_on <= 0.905 * R_no and c_on <= 0.83 * c_no
+    assert (R_on <= 0.905 * R_no and c_on <= 0.83 * c_no) if kmin == 3 else (R_on <= 0.95 * R_no and c_on <= 0.875 * c_no)
