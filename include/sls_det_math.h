@@ -119,31 +119,39 @@ SLS_HD sls_real sls_asin01(sls_real s)
  * rendered image does not change by a single bit when the test is switched off.
  * ------------------------------------------------------------------------------------------------ */
 
-/* Upper bound of ln(x) for a finite x >= 1 (x = 255 o <= 255): x = 2^e m, m in [1,2),
- * ln m = 2 atanh(z), z = (m-1)/(m+1) in [0,1/3): the series 2 (z + z^3/3 + z^5/5 + z^7/7) is a lower bound
- * whose tail is < 1.4e-5; 3e-5 is added (tail + rounding). */
+/* Upper bound of ln(x) for a finite x >= 1 (x = 255 o <= 255): x = 2^e m, m in [1,2) straight from the bit pattern,
+ * ln m = t P(t), t = m - 1, P = degree-5 fit of ln(1+t)/t on [0,1] (float32 Horner evaluation within 6.1e-6 of ln m);
+ * 2e-5 is added.  No division, no loop: ~15 instructions. */
 SLS_HD sls_real sls_log_upper(sls_real x)
 {
+#ifdef SLS_REAL_IS_DOUBLE
     int e = 0;
     sls_real m = x;
-    /* exact scaling by powers of two (x <= 255 in practice: at most 8 rounds; capped for safety) */
-    for (int k = 0; k < 128 && m >= SLS_R(2.0); ++k) { m = m * SLS_R(0.5); ++e; }
-    const sls_real z = (m - SLS_R(1.0)) / (m + SLS_R(1.0));
-    const sls_real z2 = z * z;
-    sls_real p = SLS_R(0.14285714285714285);          /* 1/7 */
-    p = SLS_FMA(p, z2, SLS_R(0.2));
-    p = SLS_FMA(p, z2, SLS_R(0.33333333333333333));
-    p = SLS_FMA(p, z2, SLS_R(1.0));
-    const sls_real lnm = SLS_R(2.0) * (z * p);
-    return SLS_FMA((sls_real)e, SLS_R(0.69314718055994531), lnm) + SLS_R(3.0e-5);
+    for (int k = 0; k < 1100 && m >= SLS_R(2.0); ++k) { m = m * SLS_R(0.5); ++e; }
+#else
+    unsigned int bits;
+    __builtin_memcpy(&bits, &x, 4);
+    const int e = (int)(bits >> 23) - 127;
+    bits = (bits & 0x007FFFFFu) | 0x3F800000u;
+    sls_real m;
+    __builtin_memcpy(&m, &bits, 4);
+#endif
+    const sls_real t = m - SLS_R(1.0);
+    sls_real p = SLS_R(-0.02397957257926464);
+    p = SLS_FMA(p, t, SLS_R(0.10150004923343658));
+    p = SLS_FMA(p, t, SLS_R(-0.2102936953306198));
+    p = SLS_FMA(p, t, SLS_R(0.3252951502799988));
+    p = SLS_FMA(p, t, SLS_R(-0.49937260150909424));
+    p = SLS_FMA(p, t, SLS_R(0.9999918341636658));
+    return SLS_FMA((sls_real)e, SLS_R(0.69314718055994531), p * t) + SLS_R(2.0e-5);
 }
 
 /* Per-surfel inputs of the tile test (all from exactly reproducible quantities). */
 typedef struct SlsTileCullSurfel {
     sls_real Pu[3], Pv[3];   /* sv (Tv x p), su (Tu x p): su sv times the record's Hu, Hv up to sign */
     sls_real n[3], dc[3];    /* sensor-facing normal, unit centre direction p / |p| */
-    sls_real ks;             /* kc su sv */
-    sls_real rd;             /* reach of the low-pass disc in pixels: kc / sqrt 2 (+0.1 %, +0.05 px) */
+    sls_real K2;             /* (kc su sv)^2 with kc^2 = rho_max = 2 ln(255 o) (+ margins) */
+    sls_real rd2;            /* squared reach of the low-pass disc in pixels: >= (kc / sqrt 2 (+0.1 %) + 0.05)^2 */
     sls_real cpx, cpy;       /* centre pixel */
 } SlsTileCullSurfel;
 
@@ -156,8 +164,9 @@ typedef struct SlsTileCullCam {
     sls_real wrapW, invW;          /* W and 1 / W in 360-degree mode, else 0 */
 } SlsTileCullCam;
 
+/* dc: p / |p|, exactly rounded (the record's unit centre direction) */
 SLS_HD void sls_tile_cull_surfel(const sls_real *Tu, const sls_real *Tv, const sls_real *n, const sls_real *p,
-                                 sls_real rho, sls_real su, sls_real sv, sls_real opacity, sls_real cpx,
+                                 const sls_real *dc, sls_real su, sls_real sv, sls_real opacity, sls_real cpx,
                                  sls_real cpy, SlsTileCullSurfel *s)
 {
     /* W = T x p with the fma form used for Hu / Hv */
@@ -167,13 +176,16 @@ SLS_HD void sls_tile_cull_surfel(const sls_real *Tu, const sls_real *Tv, const s
                    Wv2 = SLS_FMA(Tu[0], p[1], -(Tu[1] * p[0]));
     s->Pu[0] = sv * Wu0; s->Pu[1] = sv * Wu1; s->Pu[2] = sv * Wu2;
     s->Pv[0] = su * Wv0; s->Pv[1] = su * Wv1; s->Pv[2] = su * Wv2;
-    for (int k = 0; k < 3; ++k) { s->n[k] = n[k]; s->dc[k] = p[k] / rho; }
+    for (int k = 0; k < 3; ++k) { s->n[k] = n[k]; s->dc[k] = dc[k]; }
     const sls_real lo = SLS_R(255.0) * opacity;
-    /* lo <= 1: no pixel can reach alpha >= 1/255 at all (alpha <= o): kc = 0 keeps the maths finite */
-    const sls_real rho_max = lo > SLS_R(1.0) ? SLS_R(2.0) * sls_log_upper(lo) * SLS_R(1.001) + SLS_R(1.0e-3) : SLS_R(0.0);
-    const sls_real kc = SLS_SQRT(rho_max) * SLS_R(1.0001);
-    s->ks = kc * (su * sv);
-    s->rd = kc * SLS_R(0.70781) + SLS_R(0.05);
+    /* lo <= 1: no pixel can reach alpha >= 1/255 at all (alpha <= o): rho_max = 0 keeps the maths finite.
+     * rho_max: 0.1 % + 1e-3 as the block-level cull's, times 1.0002 (its kc carries 1.0001) */
+    const sls_real rho_max = lo > SLS_R(1.0)
+        ? (SLS_R(2.0) * sls_log_upper(lo) * SLS_R(1.001) + SLS_R(1.0e-3)) * SLS_R(1.0002) : SLS_R(0.0);
+    const sls_real ss = su * sv;
+    s->K2 = rho_max * (ss * ss);
+    /* (c kc + 0.05)^2 with c = 0.70781 and kc <= (kc^2 + 1) / 2 */
+    s->rd2 = (SLS_R(0.5009949961) * rho_max + SLS_R(0.0353905) * (rho_max + SLS_R(1.0))) + SLS_R(0.0025);
     s->cpx = cpx; s->cpy = cpy;
 }
 
@@ -194,7 +206,7 @@ SLS_HD int sls_tile_outside(const SlsTileCullCam *c, const SlsTileCullSurfel *s,
     const sls_real b = (s->Pv[0] * l0 + s->Pv[1] * l1) + s->Pv[2] * l2;
     const sls_real e = (s->n[0] * d0 + s->n[1] * d1) + s->n[2] * d2;
     const sls_real n2 = a * a + b * b;
-    const sls_real kn = s->ks * SLS_SQRT(n2);
+    const sls_real kn = SLS_SQRT(s->K2 * n2);          /* kc su sv |(a, b)| */
     const sls_real g0 = (a * s->Pu[0] + b * s->Pv[0]) + kn * s->n[0];
     const sls_real g1 = (a * s->Pu[1] + b * s->Pv[1]) + kn * s->n[1];
     const sls_real g2 = (a * s->Pu[2] + b * s->Pv[2]) + kn * s->n[2];
@@ -208,7 +220,7 @@ SLS_HD int sls_tile_outside(const SlsTileCullCam *c, const SlsTileCullSurfel *s,
     const sls_real dxc = dxr - c->wrapW * SLS_RINT(dxr * c->invW);
     const sls_real ex = SLS_FMAX(SLS_FABS(dxc) - c->hx, SLS_R(0.0));
     const sls_real ey = SLS_FMAX(SLS_FABS((y0 + c->hy) - s->cpy) - c->hy, SLS_R(0.0));
-    return (ex * ex + ey * ey) > s->rd * s->rd;
+    return (ex * ex + ey * ey) > s->rd2;
 }
 
 #endif /* SLS_DET_MATH_H */

@@ -247,7 +247,8 @@ void or_preprocess(const int32_t *ic, const real *fc, int N,
         uint64_t mask = nrect >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << nrect) - 1);
         if (tile_cull > 0 && nrect >= tile_cull && nrect <= 64) {
             SlsTileCullSurfel cs;
-            sls_tile_cull_surfel(Tu, Tv, n, p, rho, su, sv, opac[i], cpx, cpy, &cs);
+            const real dcv[3] = { p[0] / rho, p[1] / rho, p[2] / rho };
+            sls_tile_cull_surfel(Tu, Tv, n, p, dcv, su, sv, opac[i], cpx, cpy, &cs);
             for (int idx = 0; idx < nrect; ++idx) {
                 const int ky = idx / ncols, kx = idx - ky * ncols;
                 int txx = txlo + kx;

@@ -250,9 +250,12 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 rc = make_int4(txlo, ncols, tylo, nrows);
                 my_tiles = (uint32_t)(ncols * nrows);
                 my_rc = rc;
+                // (correctly rounded: the tile kernels subtract this unit vector from the pixel's — a 1-ulp difference
+                //  here is 1e-4 of (d - dc) for a pixel next to the centre, and the checker rounds it this way)
+                const float dcv[3] = { g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho };
                 my_mask = my_tiles >= 64u ? ~0ull : ((1ull << my_tiles) - 1ull);
                 tested = cam.tile_cull > 0 && tile_mask && my_tiles >= (uint32_t)cam.tile_cull && my_tiles <= 64u;
-                if (tested) sls_tile_cull_surfel(g.Tu, g.Tv, g.n, g.p, g.rho, g.su, g.sv, o, cpx, cpy, &cull);
+                if (tested) sls_tile_cull_surfel(g.Tu, g.Tv, g.n, g.p, dcv, g.su, g.sv, o, cpx, cpy, &cull);
                 r_out = to_int_clamped(ceilf(fmaxf(rx, ry)));
                 dep = g.rho;
                 // Conservative support half-extents for the wave-level cull in the
@@ -295,9 +298,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
                 q0 = make_float4(g.Hu[0], g.Hu[1], g.Hu[2], g.sig * g.c);
                 q1 = make_float4(g.Hv[0], g.Hv[1], g.Hv[2], g.rho);
                 q2 = make_float4(g.n[0], g.n[1], g.n[2], o);
-                // (correctly rounded: the tile kernels subtract this unit vector from the pixel's — a 1-ulp difference
-                //  here is 1e-4 of (d - dc) for a pixel next to the centre, and the checker rounds it this way)
-                q3 = make_float4(g.p[0] / g.rho, g.p[1] / g.rho, g.p[2] / g.rho, kc);
+                q3 = make_float4(dcv[0], dcv[1], dcv[2], kc);
                 q4 = make_float4(cpx, cpy, ex, ey);
             }
         }
