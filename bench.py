@@ -175,10 +175,11 @@ def main():
     ap.add_argument("--full-sort", action="store_true",
                     help="engine mode: sort the depth order from scratch every iteration instead of repairing the "
                          "previous iteration's order (windowed re-sort + exactness check, DESIGN.md section 4)")
-    ap.add_argument("--dp-mode", choices=("auto", "rs_ag", "allreduce"), default=os.environ.get("SLS_DP_MODE", "auto"),
+    ap.add_argument("--dp-mode", choices=("auto", "rs_ag", "allreduce", "sparse"), default=os.environ.get("SLS_DP_MODE", "auto"),
                     help="N > 1: gradient exchange.  rs_ag: reduce-scatter -> Adam on the rank's 1/N -> all-gather of "
-                         "the parameters; allreduce: one all-reduce -> Adam everywhere; auto: time both for a few "
-                         "un-timed iterations and take the faster one")
+                         "the parameters; allreduce: one all-reduce -> Adam everywhere; sparse: only the touched set "
+                         "(bitmap OR + the union's rows SUM); auto: time all three for a few un-timed iterations and "
+                         "take the fastest")
     ap.add_argument("--iters-per-step", type=int, default=10,
                     help="mapping iterations inside ONE bench step (the driver's --steps 20 then times 200 iterations: "
                          "20 alone are 5 ms of GPU time, too few for a stable figure); ms_per_step is the time of a "
@@ -323,7 +324,7 @@ def main():
         dp_mode = args.dp_mode
         if dp_mode == "auto":
             dp_cal = {}
-            for m in ("rs_ag", "allreduce"):
+            for m in ("rs_ag", "allreduce", "sparse"):
                 mdl, eng = fresh(dp_mode=m)
                 try:
                     dt_m, _ = run(mdl, eng, cams if n_kf > 1 else [cam], 3, 10, pick=pick_rank)
@@ -380,10 +381,12 @@ def main():
                 return sum(e[a].elapsed_time(e[b]) for e in ev) / len(ev) * 1e3
             ex, ad, ag = avg(0, 1), avg(1, 2), avg(2, 3)
             sharded = engine._dp is not None
-            comm = {"mode": "rs_ag" if sharded else "allreduce",
+            comm = {"mode": "sparse" if engine._sx is not None else ("rs_ag" if sharded else "allreduce"),
                     ("reduce_scatter_us" if sharded else "all_reduce_us"): round(ex, 1),
                     "adam_us": round(ad, 1), "all_gather_us": round(ag, 1) if sharded else 0.0,
-                    "exchange_us": round(ex + ag, 1), "bytes_per_rank": 40 * N,
+                    "exchange_us": round(ex + ag, 1), "bytes_per_rank": int(engine.exchanged_bytes),
+                    "dense_bytes_per_rank": 40 * N,
+                    "union_rows": (engine.last or {}).get("exchange_count") if engine._sx is not None else None,
                     "note": "HIP events on the compute stream around each collective / the Adam kernel, un-timed "
                             "extra pass of the same steps (rank 0)"}
 

@@ -249,14 +249,21 @@ typedef struct SlsMappingConfig {
                               * gradients from run to run, about one extra tile-backward per iteration.  0: float
                               * atomics, whose order — and so the last bits of the sums — changes between runs */
     int32_t pad0;
+    uint64_t *grad_bitmap;   /* optional DEVICE buffer of sls_grad_bitmap_words(N) uint64 (apply_adam = 0, flat `grads`):
+                              * bit i of word i / 64 is set iff surfel i has a non-zero gradient in this iteration
+                              * (the keyframe reached it, or the scale regulariser pushes on it); the two words behind
+                              * the bitmap receive the void flags (non-zero: bit 0 resp. any other bit of
+                              * status.overflow) — OR-reduced over the ranks they are the group's verdict
+                              * (sls_grad_compact / sls_adam_step_sparse) */
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
-    uint32_t overflow;    /* bit 0: R > R_capacity; bit 1: depth-order repair failed (reuse_depth_order).
+    uint32_t overflow;    /* bit 0: R > R_capacity; bit 1: depth-order repair failed (reuse_depth_order); bit 2: the
+                           * sparse exchange's compact buffer was too small (sls_grad_compact).
                            * Non-zero: results of this iteration are void, Adam was skipped */
     float loss_sums[4];   /* sums of the three pixel terms, pixel-loss total */
     float loss_reg;       /* scale regulariser */
-    uint32_t pad;
+    uint32_t exchange_count;  /* sparse exchange only: number of surfels in the union of the ranks' touched sets */
 } SlsMappingStatus;
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity);
 /* The same for ONE configuration: without cfg->deterministic the two fixed-point accumulators (192 B per
@@ -362,6 +369,28 @@ int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double b
                           double eps, int64_t step, const float *void_flags_dev,
                           struct SlsMappingStatus *status_dev, struct SlsMappingStatus *status_mirror,
                           void *stream);
+
+/* ---- keyframe-parallel exchange of the touched set only -----------------------
+ * A keyframe reaches ~10 % of a local model's surfels; only they (and the few the scale regulariser pushes on)
+ * carry a non-zero gradient.  Instead of all-reducing the dense 40 B x N bucket:
+ *   sls_mapping_step(apply_adam = 0, cfg->grad_bitmap = B)      B: sls_grad_bitmap_words(N) uint64
+ *   all-reduce(B, bitwise OR)                                    N / 8 bytes: the union of the touched sets + verdict
+ *   sls_grad_compact(N, B, grads, compact, capacity, prefix, status)
+ *        compact[slot][10] = the gradient of the slot-th surfel of the union, [xyz 3 | opacity | scaling 2 |
+ *        rotation 4]; status->exchange_count = K = size of the union; K > capacity sets bit 2 of
+ *        status->overflow (void: repeat with more room); status->overflow = the group's verdict
+ *   all-reduce(compact[0 .. 10 * K_send), SUM)                   K_send <= capacity chosen by the host
+ *   sls_adam_step_sparse(...)                                    Adam on every surfel, gradient from its slot or 0;
+ *        skipped when the iteration is void; copies the status block to status_mirror (HOST-visible) if given.
+ * word_prefix: DEVICE scratch of (N + 63) / 64 uint32. */
+size_t sls_grad_bitmap_words(int N);
+int sls_grad_compact(int N, const uint64_t *union_bitmap, const float *grads_flat, float *compact, uint32_t capacity,
+                     uint32_t *word_prefix, struct SlsMappingStatus *status_dev, void *stream);
+int sls_adam_step_sparse(int N, float *xyz, float *opacity_raw, float *scaling_raw, float *rotation_raw,
+                         const uint64_t *union_bitmap, const uint32_t *word_prefix, const float *compact_reduced,
+                         float *exp_avg, float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling,
+                         float lr_rotation, double beta1, double beta2, double eps, int64_t step,
+                         struct SlsMappingStatus *status_dev, struct SlsMappingStatus *status_mirror, void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------
  * out[i] = mean of squared distances from point i to its 3 nearest other

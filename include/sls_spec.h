@@ -17,9 +17,11 @@
 #define SLS_RMIN_PX 2.1213203435596424f
 #define SLS_FILTER_INV_SQUARE 2.0f
 /* D10: the binning tests a surfel's tile rectangle tile by tile (include/sls_det_math.h) when it has at least this
- * many tiles (and at most 64).  On the bench scene rectangles of >= 6 tiles are 11 % of the surfels, 31 % of the
- * instances and 93 % of what the test removes from the consumed list prefixes. */
-#define SLS_TILE_CULL_MIN_DEFAULT 6
+ * many tiles (and at most 64).  On the bench scene rectangles of >= 3 tiles are 28 % of the surfels, 57 % of the
+ * instances and 97 % of what the test removes; measured on MI355X (profiles/r03e): threshold 3 -> 0.2676 ms per
+ * iteration, 6 -> 0.2688, off -> 0.2701 (the tests cost the VALU-bound preprocess kernel 6.9 / 5.4 us, the shorter
+ * lists give the tile kernels 8.1 / 6.0 us back). */
+#define SLS_TILE_CULL_MIN_DEFAULT 3
 /* blending thresholds */
 #define SLS_ALPHA_MAX 0.99f
 #define SLS_ALPHA_MIN (1.0f / 255.0f)

@@ -38,6 +38,7 @@ class SlsMappingConfig(C.Structure):
         ("void_flags_out", C.c_void_p),
         ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
         ("deterministic", C.c_int32), ("pad0", C.c_int32),
+        ("grad_bitmap", C.c_void_p),
     ]
 
 
@@ -54,7 +55,7 @@ class SlsAlignerResult(C.Structure):
 
 class SlsMappingStatus(C.Structure):
     _fields_ = [("R", C.c_uint32), ("overflow", C.c_uint32), ("loss_sums", C.c_float * 4),
-                ("loss_reg", C.c_float), ("pad", C.c_uint32)]
+                ("loss_reg", C.c_float), ("exchange_count", C.c_uint32)]
 
 
 class SlsAdamGroup(C.Structure):
@@ -98,6 +99,9 @@ _PROTOS = {
                                         C.c_int64, _VP, _VP]),
     "sls_adam_step_reduced": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP, _VP, _VP]),
+    "sls_grad_bitmap_words": (C.c_size_t, [C.c_int]),
+    "sls_grad_compact": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
+    "sls_adam_step_sparse": (C.c_int, [C.c_int] + [_VP] * 9 + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, _VP, _VP, _VP]),
     "sls_projector_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sls_projector_prepare": (C.c_int, [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "sls_projector_intrinsics": (C.c_int, [C.c_int, _VP, C.c_int, C.c_int, C.c_float, _VP, _VP, C.c_size_t, _VP]),

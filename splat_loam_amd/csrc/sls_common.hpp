@@ -298,6 +298,8 @@ struct AdamFuse {
     const uint32_t *det_max;
     const long long *det_acc;
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
+    uint64_t *grad_bitmap;                // optional (sparse exchange): bit per surfel with a non-zero gradient + 2 verdict words
+    int grad_bitmap_words;                // (N + 63) / 64
 };
 
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8

@@ -1,0 +1,192 @@
+// sls_exchange.hip — keyframe-parallel exchange of the TOUCHED SET only.
+//
+// A keyframe's pixels reach ~10 % of the surfels of a local model; only those (plus the few whose scale the
+// regulariser pushes on) have a non-zero gradient.  The dense exchange moves 40 B x N per rank and iteration all
+// the same.  Here:
+//   1. preprocess_bwd leaves, next to the flat gradient bucket, a BITMAP of the surfels with a non-zero gradient
+//      (one ballot per wave: N / 8 bytes) followed by two verdict words (non-zero: this rank voids the iteration);
+//   2. the bitmaps are OR-reduced over the ranks (one tiny collective, integer: exact);
+//   3. sls_grad_compact packs the 10 gradient values of every surfel of the UNION, in surfel order, into
+//      compact[slot][10] — the same slots on every rank, because the union bitmap is the same;
+//   4. the first K_send slots are SUM-reduced (K_send is a host-side capacity; K itself stays on the device:
+//      K > K_send sets bit 2 of status.overflow, the iteration is void and repeated with more room — the protocol
+//      of the instance buffers);
+//   5. sls_adam_step_sparse applies torch.optim.Adam to EVERY surfel (moments decay where the gradient is zero),
+//      reading the gradient from its slot or taking zero.
+// Every rank ends with bit-identical parameters: the collective's result is identical everywhere and the update
+// is a pure function of it.  Results equal the dense all-reduce path's to the bit (same operands per element).
+#include <string.h>
+
+#include "sls_common.hpp"
+
+namespace sls {
+
+constexpr uint32_t kExchangeTooSmall = 4u;      // bit 2 of SlsMappingStatus.overflow
+
+// exclusive prefix of popcount(bitmap[w]) over the words; ONE workgroup (N / 64 words: 7.8 k at 500 k surfels).
+// Also publishes the union's size and the group's verdict.
+__global__ __launch_bounds__(1024) void exchange_prefix_kernel(int nwords, const uint64_t *__restrict__ bitmap,
+                                                               uint32_t *__restrict__ word_prefix, uint32_t capacity,
+                                                               uint32_t *__restrict__ status_block)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < nwords; base += 1024) {
+        const int w = base + (int)threadIdx.x;
+        const uint32_t c = w < nwords ? (uint32_t)__popcll(bitmap[w]) : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int k = 0; k < wave; ++k) pre += s_wave[k];
+        if (w < nwords) word_prefix[w] = pre + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t K = s_carry;
+        const uint32_t void_bits = (bitmap[nwords] ? 1u : 0u) | (bitmap[nwords + 1] ? 2u : 0u);   // the group's verdict
+        status_block[7] = K;                                          // SlsMappingStatus.exchange_count
+        status_block[1] = void_bits | (K > capacity ? kExchangeTooSmall : 0u);
+    }
+}
+
+// thread per surfel: the surfels of the union copy their 10 gradient values into their slot
+__global__ __launch_bounds__(256) void exchange_compact_kernel(int N, const uint64_t *__restrict__ bitmap,
+                                                               const uint32_t *__restrict__ word_prefix,
+                                                               const float *__restrict__ grads, float *__restrict__ compact,
+                                                               uint32_t capacity)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint64_t word = bitmap[i >> 6];
+    const int b = i & 63;
+    if (!((word >> b) & 1ull)) return;
+    const uint32_t slot = word_prefix[i >> 6] + (uint32_t)__popcll(word & ((1ull << b) - 1ull));
+    if (slot >= capacity) return;
+    const size_t n = (size_t)N;
+    float *o = compact + (size_t)slot * 10;
+    o[0] = grads[3 * (size_t)i]; o[1] = grads[3 * (size_t)i + 1]; o[2] = grads[3 * (size_t)i + 2];
+    o[3] = grads[3 * n + i];
+    o[4] = grads[4 * n + 2 * (size_t)i]; o[5] = grads[4 * n + 2 * (size_t)i + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[6 + k] = grads[6 * n + 4 * (size_t)i + k];
+}
+
+struct SparseAdamArgs {
+    float *xyz, *opacity, *scaling, *rotation;
+    float *exp_avg, *exp_avg_sq;          // flat buckets [xyz 3N | opacity N | scaling 2N | rotation 4N]
+    float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
+    AdamCoef c;
+};
+
+// torch.optim.Adam on every surfel; the gradient comes from the reduced compact buffer (union surfels) or is zero.
+// Skipped as a whole when the group voided the iteration; the last kernel of the iteration: mirrors the status.
+__global__ __launch_bounds__(256) void exchange_adam_kernel(int N, SparseAdamArgs a, const uint64_t *__restrict__ bitmap,
+                                                            const uint32_t *__restrict__ word_prefix,
+                                                            const float *__restrict__ compact,
+                                                            const uint32_t *__restrict__ status_block,
+                                                            uint32_t *__restrict__ status_mirror)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && status_mirror) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(status_block[k], status_mirror + k);
+    }
+    if (status_block[1] != 0u) return;        // void: the verdict of the group or an exchange buffer too small
+    if (i >= N) return;
+    float g[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) g[k] = 0.0f;
+    const uint64_t word = bitmap[i >> 6];
+    const int b = i & 63;
+    if ((word >> b) & 1ull) {
+        const uint32_t slot = word_prefix[i >> 6] + (uint32_t)__popcll(word & ((1ull << b) - 1ull));
+        const float *s = compact + (size_t)slot * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g[k] = s[k];
+    }
+    const size_t n = (size_t)N, ix = 3 * (size_t)i, io = 3 * n + i, is = 4 * n + 2 * (size_t)i, ir = 6 * n + 4 * (size_t)i;
+    float *M = a.exp_avg, *V = a.exp_avg_sq;
+    const float ibc1 = __builtin_amdgcn_rcpf(a.c.bc1);
+    const float st_x = a.lr_xyz * ibc1, st_o = a.lr_opacity * ibc1, st_s = a.lr_scaling * ibc1, st_r = a.lr_rotation * ibc1;
+    float p, m, v;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p = a.xyz[ix + k]; m = M[ix + k]; v = V[ix + k];
+        adam_one(p, g[k], m, v, st_x, a.c);
+        a.xyz[ix + k] = p; M[ix + k] = m; V[ix + k] = v;
+    }
+    p = a.opacity[i]; m = M[io]; v = V[io];
+    adam_one(p, g[3], m, v, st_o, a.c);
+    a.opacity[i] = p; M[io] = m; V[io] = v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        p = a.scaling[2 * (size_t)i + k]; m = M[is + k]; v = V[is + k];
+        adam_one(p, g[4 + k], m, v, st_s, a.c);
+        a.scaling[2 * (size_t)i + k] = p; M[is + k] = m; V[is + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p = a.rotation[4 * (size_t)i + k]; m = M[ir + k]; v = V[ir + k];
+        adam_one(p, g[6 + k], m, v, st_r, a.c);
+        a.rotation[4 * (size_t)i + k] = p; M[ir + k] = m; V[ir + k] = v;
+    }
+}
+
+}  // namespace sls
+
+using namespace sls;
+
+extern "C" {
+
+size_t sls_grad_bitmap_words(int N) { return N > 0 ? (size_t)((N + 63) / 64) + 2 : 2; }
+
+int sls_grad_compact(int N, const uint64_t *union_bitmap, const float *grads_flat, float *compact, uint32_t capacity,
+                     uint32_t *word_prefix, SlsMappingStatus *status_dev, void *stream)
+{
+    SLS_REQUIRE(N > 0 && union_bitmap && grads_flat && compact && word_prefix && status_dev, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nwords = (N + 63) / 64;
+    hipLaunchKernelGGL(exchange_prefix_kernel, dim3(1), dim3(1024), 0, st, nwords, union_bitmap, word_prefix, capacity,
+                       (uint32_t *)status_dev);
+    SLS_LAUNCH_CHECK("exchange_prefix_kernel");
+    hipLaunchKernelGGL(exchange_compact_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, union_bitmap,
+                       (const uint32_t *)word_prefix, grads_flat, compact, capacity);
+    SLS_LAUNCH_CHECK("exchange_compact_kernel");
+    return SLS_OK;
+}
+
+int sls_adam_step_sparse(int N, float *xyz, float *opacity, float *scaling, float *rotation,
+                         const uint64_t *union_bitmap, const uint32_t *word_prefix, const float *compact_reduced,
+                         float *exp_avg, float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling,
+                         float lr_rotation, double beta1, double beta2, double eps, int64_t step,
+                         SlsMappingStatus *status_dev, SlsMappingStatus *status_mirror, void *stream)
+{
+    SLS_REQUIRE(N > 0 && xyz && opacity && scaling && rotation && union_bitmap && word_prefix && compact_reduced &&
+                    exp_avg && exp_avg_sq && status_dev,
+                "bad argument");
+    SLS_REQUIRE(step >= 1, "step is 1-based");
+    SparseAdamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xyz = xyz; a.opacity = opacity; a.scaling = scaling; a.rotation = rotation;
+    a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
+    a.lr_xyz = lr_xyz; a.lr_opacity = lr_opacity; a.lr_scaling = lr_scaling; a.lr_rotation = lr_rotation;
+    a.c = make_adam_coef(beta1, beta2, eps, step);
+    ScopedTimer tm(T_ADAM, (hipStream_t)stream);
+    hipLaunchKernelGGL(exchange_adam_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, a, union_bitmap,
+                       word_prefix, compact_reduced, (const uint32_t *)status_dev, (uint32_t *)status_mirror);
+    SLS_LAUNCH_CHECK("exchange_adam_kernel");
+    return SLS_OK;
+}
+
+}  // extern "C"

@@ -379,6 +379,11 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.void_flags = cfg->void_flags_out;
     fuse.void_count = 1; fuse.void_stride = 0;
     if (det) { fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc; }
+    if (cfg->grad_bitmap) {
+        SLS_REQUIRE(!cfg->apply_adam && !cfg->grad_chunk, "the gradient bitmap belongs to apply_adam = 0 with the flat bucket");
+        fuse.grad_bitmap = cfg->grad_bitmap;
+        fuse.grad_bitmap_words = (N + 63) / 64;
+    }
     if (cfg->grad_chunk) {
         SLS_REQUIRE(!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
                         (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&

@@ -444,6 +444,11 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);
         }
+        if (af.grad_bitmap) {   // sparse exchange: this rank's verdict behind the bitmap (OR-reduced with the bitmap)
+            const uint32_t bits = af.status_src[1];
+            af.grad_bitmap[af.grad_bitmap_words] = (bits & 1u) ? 1ull : 0ull;
+            af.grad_bitmap[af.grad_bitmap_words + 1] = (bits & ~1u) ? 1ull : 0ull;
+        }
     }
     if (i >= N) return;
     float dm[3] = { 0, 0, 0 };
@@ -542,6 +547,12 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         const float dd = dq.x * q.x + dq.y * q.y + dq.z * q.z + dq.w * q.w;
         dq.x = (dq.x - dd * q.x) * inv; dq.y = (dq.y - dd * q.y) * inv;
         dq.z = (dq.z - dd * q.z) * inv; dq.w = (dq.w - dd * q.w) * inv;
+    }
+    if (af.grad_bitmap) {   // which surfels have anything to exchange (one 64-bit word per wave)
+        const bool nz = dm[0] != 0.0f || dm[1] != 0.0f || dm[2] != 0.0f || dop != 0.0f || ds.x != 0.0f || ds.y != 0.0f ||
+                        dq.x != 0.0f || dq.y != 0.0f || dq.z != 0.0f || dq.w != 0.0f;
+        const uint64_t bal = __ballot(nz);
+        if ((threadIdx.x & 63) == 0) af.grad_bitmap[i >> 6] = bal;
     }
     if (af.gchunk) {
         // reduce-scatter layout: flat element e of [xyz 3N | opacity N | scaling 2N | rotation 4N] lives at

@@ -19,7 +19,14 @@ with the same replicated model.  Two exchange schemes (`dp_mode`):
       parameters — the bytes of one all-reduce, the optimiser pass divided by G,
       replicas identical by construction;
   "allreduce": the flat 10*N bucket (+2 void words) is all-reduced in one RCCL
-      collective and every rank applies the same guarded Adam update.
+      collective and every rank applies the same guarded Adam update;
+  "sparse": only the TOUCHED set travels (a keyframe reaches ~10 % of the surfels):
+      the ranks' gradient bitmaps are OR-reduced (N/8 bytes), the union's 40-byte
+      gradient rows are packed in surfel order (sls_grad_compact) and SUM-reduced,
+      sls_adam_step_sparse updates every surfel from its slot or with a zero
+      gradient.  The collective's size is a host-side capacity that follows the
+      union's measured size; a union larger than it voids the iteration on every
+      rank (bit 2 of the status word) and it is repeated with more room.
 """
 from __future__ import annotations
 
@@ -130,7 +137,7 @@ class MappingEngine:
         self.max_order_age = 4
         self.max_order_age_extra = 12     # up to this age an order is still repaired, with one more round
         self.max_cached_orders = 64
-        self.stats = {"repeated_too_small": 0, "repeated_resort": 0}
+        self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
         # keyframe-parallel exchange (set up at the first sharded step)
         self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
@@ -138,6 +145,8 @@ class MappingEngine:
         self._dp_agreed, self._dp_use_rs = None, False    # (G, rank) the scheme was agreed for; the agreed verdict
         from .rasterizer import deterministic_mode
         self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
+        self._sx = None                   # sparse exchange: dict(bitmap, prefix, compact, cap, send) once set up
+        self.exchanged_bytes = 0          # bytes this rank handed to collectives in the last keyframe-parallel step
         self.exchange_at_world_1 = False  # take the keyframe-parallel path (collectives + separate Adam) in a 1-rank group too
         self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
 
@@ -183,6 +192,8 @@ class MappingEngine:
         if self._dp is not None and not apply_adam:
             c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
         c.deterministic = 1 if self.deterministic else 0
+        if self._sx is not None and not apply_adam:
+            c.grad_bitmap = self._sx["bitmap"].data_ptr()
         return c
 
     def _order_entry(self, camera):
@@ -249,6 +260,10 @@ class MappingEngine:
             torch.cuda.current_stream(self.dev).cuda_stream),
             "sls_mapping_step")
 
+    @staticmethod
+    def _void_reason(st):
+        return "repeated_too_small" if st["too_small"] else ("repeated_resort" if st["resort_failed"] else "repeated_exchange")
+
     def _sharded(self, group):
         """Keyframe-parallel path?  World size > 1 — or 1 with `exchange_at_world_1` (the collectives then move
         a rank's data onto itself: how the RCCL path is exercised on a one-GPU box)."""
@@ -257,7 +272,15 @@ class MappingEngine:
         return dist.get_world_size(group) > 1 or self.exchange_at_world_1
 
     def _read_status(self):
-        return self._parse_status(self.status.cpu())   # the one sync of the iteration
+        return self._note(self._parse_status(self.status.cpu()))   # the one sync of the iteration
+
+    def _note(self, st):
+        """Host-side bookkeeping driven by a status every rank sees identically: the sparse exchange's collective
+        size follows the measured size of the union of the touched sets (25 % + 1024 slots of head room; a union
+        that outgrows it voids one iteration, which is repeated with the new size)."""
+        if self._sx is not None and (not st["overflow"] or st["exchange_too_small"]):
+            self._sx["send"] = int(min(self.N, int(st["exchange_count"] * 1.25) + 1024))
+        return st
 
     @staticmethod
     def _parse_status(h):
@@ -265,7 +288,9 @@ class MappingEngine:
         f = h.view(torch.float32)
         # "overflow": the iteration is void (Adam was skipped) and must be repeated; bit 0 = the
         # instance buffers were too small, bit 1 = the repaired depth order was not exact
-        return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2), "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
+        return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
+                "exchange_too_small": bool(flags & 4), "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
+                "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
     @torch.no_grad()
@@ -313,8 +338,9 @@ class MappingEngine:
                 return st
             # repeat the iteration (parameters were not touched): with the full sort, and with more
             # room if the instance buffers were too small
-            self._forget_order(camera, failed_repair=st["resort_failed"])
-            self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
+            if st["too_small"] or st["resort_failed"]:
+                self._forget_order(camera, failed_repair=st["resort_failed"])
+            self.stats[self._void_reason(st)] += 1
             if st["too_small"]:
                 need = st["R"]
                 if sharded:
@@ -356,7 +382,7 @@ class MappingEngine:
     def _lag_collect(self, prev, redo_current):
         pslot, pcam = prev
         self._lag_ev[pslot].synchronize()
-        st = self._parse_status(self._lag_host[pslot].clone())
+        st = self._note(self._parse_status(self._lag_host[pslot].clone()))
         if not st["overflow"]:
             self.last = st
             self._lag_ready.append(st)
@@ -365,15 +391,16 @@ class MappingEngine:
         # device, and so did the one enqueued after it (same capacity).  Drain, grow, redo.
         cur, self._lag_pending = self._lag_pending, None
         torch.cuda.current_stream(self.dev).synchronize()
-        cur_st = self._parse_status(self._lag_dev[cur[0]].cpu()) if cur is not None else None
+        cur_st = self._note(self._parse_status(self._lag_dev[cur[0]].cpu())) if cur is not None else None
         cur_void = cur_st is not None and cur_st["overflow"]
         # both in-flight iterations are taken off the step count; the one that did run is put back after the
         # redo below, so that the repeated iteration uses the Adam step number it was meant to have
         self.t -= 2 if cur is not None else 1
-        self._forget_order(pcam, failed_repair=st["resort_failed"])     # repeat with the full sort
-        if cur_void:
+        if st["too_small"] or st["resort_failed"]:
+            self._forget_order(pcam, failed_repair=st["resort_failed"])     # repeat with the full sort
+        if cur_void and (cur_st["too_small"] or cur_st["resort_failed"]):
             self._forget_order(cur[1], failed_repair=cur_st["resort_failed"])
-        self.stats["repeated_too_small" if st["too_small"] else "repeated_resort"] += 1
+        self.stats[self._void_reason(st)] += 1
         if st["too_small"] or (cur_void and cur_st["too_small"]):
             need = max(st["R"], cur_st["R"] if cur_void else 0, self.capacity)
             self.capacity = int(need * self.capacity_factor) + 1024
@@ -410,13 +437,22 @@ class MappingEngine:
         """First sharded step: lay the gradient bucket out for the reduce-scatter, move the four parameter tensors
         into ONE flat buffer (they stay torch Parameters: their storage becomes a view of it) and keep only this
         rank's 1/G of the Adam moments."""
-        if self.dp_mode not in ("rs_ag", "allreduce"):
-            raise ValueError(f"dp_mode must be 'rs_ag' or 'allreduce', not {self.dp_mode!r}")
+        if self.dp_mode not in ("rs_ag", "allreduce", "sparse"):
+            raise ValueError(f"dp_mode must be 'rs_ag', 'allreduce' or 'sparse', not {self.dp_mode!r}")
         G, rank, N = dist.get_world_size(group), dist.get_rank(group), self.N
         if self._dp is not None:
             if self._dp["G"] != G or self._dp["rank"] != rank:
                 raise RuntimeError("the process group changed under an engine whose optimiser state is sharded "
                                    f"({self._dp['G']} ranks -> {G}): build a new engine (or remap(reset_state=True))")
+            return
+        if self.dp_mode == "sparse":
+            if self._sx is None:
+                lib = _abi.lib()
+                nw = int(lib.sls_grad_bitmap_words(N))
+                self._sx = {"bitmap": torch.zeros((nw,), dtype=torch.int64, device=self.dev),
+                            "prefix": torch.zeros((nw,), dtype=torch.int32, device=self.dev),
+                            "compact": torch.zeros((10 * N,), dtype=torch.float32, device=self.dev),
+                            "send": N}          # slots handed to the SUM collective: all of them until the union's size is known
             return
         if self._dp_agreed != (G, rank):
             # every rank must run the SAME collective sequence: agree on the scheme once (MIN over ranks of
@@ -449,13 +485,35 @@ class MappingEngine:
         if self.comm_events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-        if self._dp is None:
+        if self._sx is not None:
+            # touched set only: OR of the bitmaps -> pack the union's rows -> SUM of the first `send` slots -> Adam
+            lib, sx, N = _abi.lib(), self._sx, self.N
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            dist.all_reduce(sx["bitmap"], op=dist.ReduceOp.BOR, group=group)
+            send = int(sx["send"])
+            _abi.check(lib.sls_grad_compact(N, sx["bitmap"].data_ptr(), self.grads.data_ptr(), sx["compact"].data_ptr(),
+                                            send, sx["prefix"].data_ptr(), status.data_ptr(), st), "sls_grad_compact")
+            dist.all_reduce(sx["compact"][:10 * send], op=dist.ReduceOp.SUM, group=group)
+            if ev:
+                ev[1].record()
+            xyz, scaling, rotation, opacity = self._params()
+            _abi.check(lib.sls_adam_step_sparse(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
+                                                rotation.data_ptr(), sx["bitmap"].data_ptr(), sx["prefix"].data_ptr(),
+                                                sx["compact"].data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2],
+                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1,
+                                                status.data_ptr(), mirror, st), "sls_adam_step_sparse")
+            if ev:
+                ev[2].record(); ev[3].record()
+            self.exchanged_bytes = 8 * int(sx["bitmap"].numel()) + 40 * send
+        elif self._dp is None:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
             if ev:
                 ev[1].record()
             self._adam_reduced(status, mirror)
             if ev:
                 ev[2].record(); ev[3].record()
+            self.exchanged_bytes = 4 * int(self.grads.numel())
         else:
             d = self._dp
             dist.reduce_scatter_tensor(d["gshard"], self.grads, op=dist.ReduceOp.SUM, group=group)
@@ -475,6 +533,7 @@ class MappingEngine:
                 dist.all_gather_into_tensor(d["flat"], mine.clone(), group=group)
             if ev:
                 ev[3].record()
+            self.exchanged_bytes = 4 * int(self.grads.numel()) + 4 * C        # reduce-scatter input + the gathered shard
         if ev:
             self.comm_events.append(ev)
 
@@ -557,6 +616,7 @@ class MappingEngine:
             self.exp_avg = carry_bucket(self.exp_avg, keep, n_new)
             self.exp_avg_sq = carry_bucket(self.exp_avg_sq, keep, n_new)
         self._dp_agreed = None
+        self._sx = None
         self._dp = None                               # re-sharded at the next keyframe-parallel step
         self.N = n_new
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)

@@ -85,8 +85,33 @@ def flat_grad_allreduce(model, group=None, average: bool = False) -> None:
         off += n
 
 
+def flat_grad_allreduce_sparse(model, group=None, average: bool = False) -> int:
+    """The same sum with only the TOUCHED set on the wire (the layout MappingEngine's dp_mode "sparse" moves with
+    sls_grad_compact / sls_adam_step_sparse, here in torch): a surfel takes part iff any of its 10 gradient
+    values is non-zero on some rank — the bitmaps are combined with a MAX all-reduce (N bytes here, N/8 in the native
+    path), the union's rows [xyz 3 | opacity | scaling 2 | rotation 4] are packed in surfel order, SUM-reduced and
+    scattered back.  Bit-identical to flat_grad_allreduce (same operands per element).  Returns the rows sent."""
+    params = [model._xyz, model._opacity, model._scaling, model._rotation]
+    rows = torch.cat([p.grad.reshape(p.grad.shape[0], -1) for p in params], dim=1)          # (N, 10)
+    touched = (rows != 0).any(dim=1).to(torch.uint8)
+    dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
+    idx = touched.nonzero().reshape(-1)
+    compact = rows[idx].contiguous()
+    dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        compact /= dist.get_world_size(group)
+    rows.zero_()
+    rows[idx] = compact
+    off = 0
+    for p in params:
+        w = p.grad.reshape(p.grad.shape[0], -1).shape[1]
+        p.grad.copy_(rows[:, off:off + w].reshape(p.grad.shape))
+        off += w
+    return int(idx.numel())
+
+
 def optimize_step_sharded(model, my_camera, cfg: MappingConfig, group=None, average: bool = False,
-                          **render_kw) -> torch.Tensor:
+                          sparse: bool = False, **render_kw) -> torch.Tensor:
     """Keyframe-parallel iteration: every rank renders ITS keyframe against the
     replicated model, gradients are summed over ranks, every rank applies the
     same Adam step (replicas stay bit-identical because the all-reduce result
@@ -99,7 +124,7 @@ def optimize_step_sharded(model, my_camera, cfg: MappingConfig, group=None, aver
     loss = mapping_loss(pkg, my_camera, model, local_cfg)
     loss.backward()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        flat_grad_allreduce(model, group, average)
+        (flat_grad_allreduce_sparse if sparse else flat_grad_allreduce)(model, group, average)
     with torch.no_grad():
         model.optimizer.step()
     return loss.detach()

@@ -142,3 +142,40 @@ def test_dp_layout_helpers():
                 cover.append((a, b))
                 assert lr == (1.0 if b <= 3 * n else 2.0 if b <= 4 * n else 3.0 if b <= 6 * n else 4.0)
         assert cover[0][0] == 0 and cover[-1][1] == 10 * n and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+
+
+def _worker_sparse(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    out = {}
+    for sparse in (False, True):
+        cams, model, R = _setup(rank)
+        for _ in range(2):
+            optimize_step_sharded(model, cams[rank], MappingConfig(), sparse=sparse, rasterizer_cls=R)
+        tag = "s" if sparse else "d"
+        for k in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            out[tag + k] = getattr(model, k).detach().numpy()
+            out[tag + "g" + k] = getattr(model, k).grad.numpy().copy()
+    # how much of the model the two keyframes reach together
+    from splat_loam_amd.mapping import flat_grad_allreduce_sparse
+    cams, model, R = _setup(rank)
+    model.optimizer.zero_grad(set_to_none=True)
+    mapping_loss(render(cams[rank], model, 0.0, rasterizer_cls=R), cams[rank], model, MappingConfig()).backward()
+    out["rows_sent"] = flat_grad_allreduce_sparse(model)
+    np.savez(os.path.join(out_dir, f"sparse{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_touched_set_exchange_equals_the_dense_all_reduce(tmp_path):
+    """dp_mode "sparse" at the torch level (mapping.flat_grad_allreduce_sparse; 2 ranks, gloo, CPU): OR of the touched
+    bitmaps, the union's rows packed in surfel order, SUM, scatter — gradients and the parameters after two Adam steps
+    equal the dense all-reduce's bit for bit on both ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_sparse, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "sparse0.npz"), np.load(tmp_path / "sparse1.npz")
+    for k in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        for pre in ("", "g"):
+            assert np.array_equal(r0["s" + pre + k], r0["d" + pre + k]), f"sparse != dense: {pre}{k}"
+            assert np.array_equal(r0["s" + pre + k], r1["s" + pre + k]), f"replicas diverged: {pre}{k}"
+    assert 0 < int(r0["rows_sent"]) == int(r1["rows_sent"]) <= N      # (this small scene is reached almost entirely)

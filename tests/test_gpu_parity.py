@@ -792,7 +792,15 @@ def _engine_rank(rank, world, port, out_dir, mode="sync", dp_mode="rs_ag"):
         return
 
     def reduced():
-        # the summed gradient as this rank holds it: the whole bucket (all-reduce) or its own chunk (reduce-scatter)
+        # the summed gradient as this rank holds it: the whole bucket (all-reduce), its own chunk (reduce-scatter) or
+        # the union's rows scattered back into the flat layout (sparse)
+        if eng._sx is not None:
+            sx, n = eng._sx, eng.N
+            bits = np.unpackbits(sx["bitmap"][:-2].cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+            rows = np.zeros((n, 10), np.float32)
+            k = int(bits.sum())
+            rows[bits] = sx["compact"][:10 * k].cpu().numpy().reshape(k, 10)
+            return np.concatenate([rows[:, 0:3].reshape(-1), rows[:, 3], rows[:, 4:6].reshape(-1), rows[:, 6:10].reshape(-1)]), 0
         if eng._dp is None:
             return eng.grads[:-2].cpu().numpy(), 0
         d = eng._dp
@@ -803,7 +811,8 @@ def _engine_rank(rank, world, port, out_dir, mode="sync", dp_mode="rs_ag"):
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), xyz=model._xyz.detach().cpu().numpy(),
              rot=model._rotation.detach().cpu().numpy(), sc=model._scaling.detach().cpu().numpy(),
              op=model._opacity.detach().cpu().numpy(), g1=g1, lo=lo, R=st["R"], t=eng.t,
-             sharded_state=int(eng._dp is not None), state_len=int(eng.exp_avg.numel()))
+             sharded_state=int(eng._dp is not None), state_len=int(eng.exp_avg.numel()),
+             rows=st["exchange_count"], xbytes=eng.exchanged_bytes)
     dist.destroy_process_group()
 
 
@@ -820,7 +829,7 @@ def test_engine_keyframe_parallel_lagged_two_ranks(device, tmp_path):
         assert np.array_equal(r0[k], r1[k]), f"replicas diverged: {k}"
 
 
-@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce"])
+@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce", "sparse"])
 def test_engine_keyframe_parallel_two_ranks(device, tmp_path, dp_mode):
     """Keyframe-parallel engine with 2 ranks (gloo, one GPU), both exchange schemes (reduce-scatter -> Adam on the
     rank's half -> all-gather of the parameters / one all-reduce -> Adam everywhere): the reduced gradient equals
@@ -842,6 +851,11 @@ def test_engine_keyframe_parallel_two_ranks(device, tmp_path, dp_mode):
         assert int(r0["sharded_state"]) == 1 and int(r0["state_len"]) < 10 * 5000, "optimiser state is sharded"
         assert int(r0["lo"]) == 0 and int(r1["lo"]) == len(r0["g1"])
         reduced = np.concatenate([r0["g1"], r1["g1"]])
+    elif dp_mode == "sparse":
+        # the reduced rows of the union, scattered back to the flat bucket layout by the worker
+        assert np.array_equal(r0["g1"], r1["g1"]) and 0 < int(r0["rows"]) < 5000
+        assert int(r0["xbytes"]) < 40 * 5000, "fewer bytes than the dense bucket"
+        reduced = r0["g1"]
     else:
         assert np.array_equal(r0["g1"], r1["g1"])
         reduced = r0["g1"]
@@ -901,7 +915,7 @@ def _engine_rccl_rank(rank, port, out_dir, dp_mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce"])
+@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce", "sparse"])
 def test_engine_exchange_through_rccl_world_1(device, tmp_path, dp_mode):
     """The keyframe-parallel exchange executed by RCCL itself (backend "nccl", one rank, one GPU): reduce_scatter_tensor
     -> Adam on the shard -> all_gather_into_tensor in place (rs_ag), or all_reduce -> Adam (allreduce).  With one

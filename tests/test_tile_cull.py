@@ -110,7 +110,7 @@ def test_dropped_tiles_hold_no_pixel_above_the_alpha_threshold(oracle32):
 @pytest.mark.parametrize("kmin", [3, 6])
 def test_tile_cull_on_the_bench_scene(kmin):
     """C3 (500k surfels, 64x2048), identical image; rectangles of >= 3 tiles tested: 9.9 % fewer instances, 17.9 %
-    shorter consumed prefixes; >= 6 tiles (the default: a third of the tests): 6 % / 13.7 %."""
+    shorter consumed prefixes (the default); >= 6 tiles (a third of the tests): 6 % / 13.7 %."""
     o = Oracle(np.float32)
     N, H, W = 500_000, 64, 2048
     sc = synth.make_scene(N, H, W, seed=0)
