@@ -374,8 +374,9 @@ int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double b
  * A keyframe reaches ~10 % of a local model's surfels; only they (and the few the scale regulariser pushes on)
  * carry a non-zero gradient.  Instead of all-reducing the dense 40 B x N bucket:
  *   sls_mapping_step(apply_adam = 0, cfg->grad_bitmap = B)      B: sls_grad_bitmap_words(N) uint64
- *   all-reduce(B, bitwise OR)                                    N / 8 bytes: the union of the touched sets + verdict
- *   sls_grad_compact(N, B, grads, compact, capacity, prefix, status)
+ *   all-gather(B) -> G bitmaps                                   G x N / 8 bytes (RCCL has no bitwise-OR reduction)
+ *   sls_grad_compact(N, bitmaps, G, U, grads, compact, capacity, prefix, status)
+ *        U (sls_grad_bitmap_words(N) uint64, out) = OR of the G bitmaps: the union of the touched sets + the verdict;
  *        compact[slot][10] = the gradient of the slot-th surfel of the union, [xyz 3 | opacity | scaling 2 |
  *        rotation 4]; status->exchange_count = K = size of the union; K > capacity sets bit 2 of
  *        status->overflow (void: repeat with more room); status->overflow = the group's verdict
@@ -384,8 +385,9 @@ int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double b
  *        skipped when the iteration is void; copies the status block to status_mirror (HOST-visible) if given.
  * word_prefix: DEVICE scratch of (N + 63) / 64 uint32. */
 size_t sls_grad_bitmap_words(int N);
-int sls_grad_compact(int N, const uint64_t *union_bitmap, const float *grads_flat, float *compact, uint32_t capacity,
-                     uint32_t *word_prefix, struct SlsMappingStatus *status_dev, void *stream);
+int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *union_bitmap, const float *grads_flat,
+                     float *compact, uint32_t capacity, uint32_t *word_prefix, struct SlsMappingStatus *status_dev,
+                     void *stream);
 int sls_adam_step_sparse(int N, float *xyz, float *opacity_raw, float *scaling_raw, float *rotation_raw,
                          const uint64_t *union_bitmap, const uint32_t *word_prefix, const float *compact_reduced,
                          float *exp_avg, float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling,

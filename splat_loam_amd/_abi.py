@@ -100,7 +100,7 @@ _PROTOS = {
     "sls_adam_step_reduced": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP, _VP, _VP]),
     "sls_grad_bitmap_words": (C.c_size_t, [C.c_int]),
-    "sls_grad_compact": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
+    "sls_grad_compact": (C.c_int, [C.c_int, _VP, C.c_int, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
     "sls_adam_step_sparse": (C.c_int, [C.c_int] + [_VP] * 9 + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, _VP, _VP, _VP]),
     "sls_projector_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sls_projector_prepare": (C.c_int, [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),

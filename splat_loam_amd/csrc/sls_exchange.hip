@@ -5,7 +5,8 @@
 // the same.  Here:
 //   1. preprocess_bwd leaves, next to the flat gradient bucket, a BITMAP of the surfels with a non-zero gradient
 //      (one ballot per wave: N / 8 bytes) followed by two verdict words (non-zero: this rank voids the iteration);
-//   2. the bitmaps are OR-reduced over the ranks (one tiny collective, integer: exact);
+//   2. the bitmaps are all-gathered (G x N / 8 bytes; RCCL offers no bitwise-OR reduction) and OR-ed here,
+//      inside sls_grad_compact's first kernel;
 //   3. sls_grad_compact packs the 10 gradient values of every surfel of the UNION, in surfel order, into
 //      compact[slot][10] — the same slots on every rank, because the union bitmap is the same;
 //   4. the first K_send slots are SUM-reduced (K_send is a host-side capacity; K itself stays on the device:
@@ -25,10 +26,12 @@ constexpr uint32_t kExchangeTooSmall = 4u;      // bit 2 of SlsMappingStatus.ove
 
 // exclusive prefix of popcount(bitmap[w]) over the words; ONE workgroup (N / 64 words: 7.8 k at 500 k surfels).
 // Also publishes the union's size and the group's verdict.
-__global__ __launch_bounds__(1024) void exchange_prefix_kernel(int nwords, const uint64_t *__restrict__ bitmap,
+__global__ __launch_bounds__(1024) void exchange_prefix_kernel(int nwords, const uint64_t *__restrict__ maps, int n_maps,
+                                                               uint64_t *__restrict__ bitmap,
                                                                uint32_t *__restrict__ word_prefix, uint32_t capacity,
                                                                uint32_t *__restrict__ status_block)
 {
+    // maps: n_maps bitmaps of nwords + 2 words each (the ranks' all-gathered bitmaps); bitmap: their OR (out)
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,7 +39,12 @@ __global__ __launch_bounds__(1024) void exchange_prefix_kernel(int nwords, const
     __syncthreads();
     for (int base = 0; base < nwords; base += 1024) {
         const int w = base + (int)threadIdx.x;
-        const uint32_t c = w < nwords ? (uint32_t)__popcll(bitmap[w]) : 0u;
+        uint64_t word = 0ull;
+        if (w < nwords) {
+            for (int m = 0; m < n_maps; ++m) word |= maps[(size_t)m * (size_t)(nwords + 2) + (size_t)w];
+            bitmap[w] = word;
+        }
+        const uint32_t c = (uint32_t)__popcll(word);
         uint32_t incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -54,7 +62,13 @@ __global__ __launch_bounds__(1024) void exchange_prefix_kernel(int nwords, const
     }
     if (threadIdx.x == 0) {
         const uint32_t K = s_carry;
-        const uint32_t void_bits = (bitmap[nwords] ? 1u : 0u) | (bitmap[nwords + 1] ? 2u : 0u);   // the group's verdict
+        uint64_t v0 = 0ull, v1 = 0ull;
+        for (int m = 0; m < n_maps; ++m) {
+            v0 |= maps[(size_t)m * (size_t)(nwords + 2) + (size_t)nwords];
+            v1 |= maps[(size_t)m * (size_t)(nwords + 2) + (size_t)nwords + 1];
+        }
+        bitmap[nwords] = v0; bitmap[nwords + 1] = v1;
+        const uint32_t void_bits = (v0 ? 1u : 0u) | (v1 ? 2u : 0u);   // the group's verdict
         status_block[7] = K;                                          // SlsMappingStatus.exchange_count
         status_block[1] = void_bits | (K > capacity ? kExchangeTooSmall : 0u);
     }
@@ -151,16 +165,17 @@ extern "C" {
 
 size_t sls_grad_bitmap_words(int N) { return N > 0 ? (size_t)((N + 63) / 64) + 2 : 2; }
 
-int sls_grad_compact(int N, const uint64_t *union_bitmap, const float *grads_flat, float *compact, uint32_t capacity,
-                     uint32_t *word_prefix, SlsMappingStatus *status_dev, void *stream)
+int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *union_bitmap, const float *grads_flat,
+                     float *compact, uint32_t capacity, uint32_t *word_prefix, SlsMappingStatus *status_dev, void *stream)
 {
-    SLS_REQUIRE(N > 0 && union_bitmap && grads_flat && compact && word_prefix && status_dev, "bad argument");
+    SLS_REQUIRE(N > 0 && bitmaps && n_bitmaps >= 1 && union_bitmap && grads_flat && compact && word_prefix && status_dev,
+                "bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int nwords = (N + 63) / 64;
-    hipLaunchKernelGGL(exchange_prefix_kernel, dim3(1), dim3(1024), 0, st, nwords, union_bitmap, word_prefix, capacity,
-                       (uint32_t *)status_dev);
+    hipLaunchKernelGGL(exchange_prefix_kernel, dim3(1), dim3(1024), 0, st, nwords, bitmaps, n_bitmaps, union_bitmap,
+                       word_prefix, capacity, (uint32_t *)status_dev);
     SLS_LAUNCH_CHECK("exchange_prefix_kernel");
-    hipLaunchKernelGGL(exchange_compact_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, union_bitmap,
+    hipLaunchKernelGGL(exchange_compact_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (const uint64_t *)union_bitmap,
                        (const uint32_t *)word_prefix, grads_flat, compact, capacity);
     SLS_LAUNCH_CHECK("exchange_compact_kernel");
     return SLS_OK;

@@ -3,6 +3,7 @@
 // sls_mapping_step, which enqueues one WHOLE mapping iteration
 // (slam/mapper.py:150-204: render -> loss -> backward -> Adam) on a stream with
 // no device->host sync and no torch op in between.
+#include <stdlib.h>
 #include <string.h>
 
 #include "sls_consumer_dev.hpp"
@@ -15,7 +16,9 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr,
                           const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr,
-                          int32_t *erec = nullptr);
+                          int32_t *erec = nullptr, const uint32_t *resort_prev_order = nullptr,
+                          uint64_t *resort_comp = nullptr);
+uint64_t *resort_comp_buffer(int N, void *scratch);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
 int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int N, const float *means,
@@ -27,7 +30,7 @@ size_t order_scratch_bytes(int N);
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
                             hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr,
-                            struct ScanHandoff *handoff = nullptr);
+                            struct ScanHandoff *handoff = nullptr, bool window_sort_done = false);
 struct ScanHandoff {
     const uint32_t *block_sums;
     int resort_windows;
@@ -319,13 +322,20 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     // keyframe of a window can repair ITS order when the mapper samples keyframes at random)
     uint32_t *order = cfg->depth_order ? cfg->depth_order : w.order;
     depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
+    // Repairing the previous order: its first step (sorting windows of the old order by the new keys) rides in the
+    // preprocess launch — it needs nothing the preprocess produces (SLS_NO_MERGED_SORT=1: two launches, for A/B runs)
+    static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
+    const bool merged_sort = cfg->reuse_depth_order >= 1 && !no_merge;
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec);
+                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
+                                   merged_sort ? order : nullptr,
+                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr);
     if (rc) return rc;
     ScanHandoff handoff = { nullptr, 0, nullptr };   // the emission finishes the scan of tiles_touched
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
-                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff);
+                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
+                                 merged_sort);
     if (rc) return rc;
     int in_tmp = 0;
     rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,

@@ -9,6 +9,7 @@
 // is reproducible bit for bit by a CPU checker.
 #include <cstring>
 #include "sls_common.hpp"
+#include "sls_resort.hpp"
 
 namespace sls {
 
@@ -174,17 +175,29 @@ __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q
 }
 
 // ---------------------------------------------------------------------------
-// A1 forward preprocess.  One thread per surfel; 256-thread blocks.
+// A1 forward preprocess.  One thread per surfel; blocks of WAVES waves, the block's first surfel is `first`.
+// s_mem: WAVES wave-private slices of kPreSliceBytes (tile tests, then the staging of the records).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void preprocess_fwd_kernel(
-    DevCam cam, RegArgs ra, int N, const float *__restrict__ means, const float2 *__restrict__ scales,
-    const float4 *__restrict__ rots, const float *__restrict__ opac,
-    float4 *__restrict__ rec, int *__restrict__ radii, int4 *__restrict__ rect,
-    uint32_t *__restrict__ tiles, float *__restrict__ depth, uint32_t *__restrict__ order_keys,
-    uint32_t *__restrict__ order_vals, uint32_t *__restrict__ n_dev, const float2 *__restrict__ col_cs,
-    const float2 *__restrict__ row_cs, uint64_t *__restrict__ tile_mask, int4 *__restrict__ erec)
+struct PreFwdArgs {
+    const float *means; const float2 *scales; const float4 *rots; const float *opac;
+    float4 *rec; int *radii; int4 *rect; uint32_t *tiles; float *depth; uint32_t *order_keys, *order_vals, *n_dev;
+    const float2 *col_cs, *row_cs; uint64_t *tile_mask; int4 *erec;
+};
+constexpr int kPreCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
+constexpr int kPreSliceBytes = kPreCullBytes > 64 * kRec4 * 16 ? kPreCullBytes : 64 * kRec4 * 16;
+
+template <int WAVES>
+__device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const RegArgs &ra, int N, const PreFwdArgs &pa,
+                                                    int first, unsigned char *s_mem, float *s_part)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float *__restrict__ means = pa.means; const float2 *__restrict__ scales = pa.scales;
+    const float4 *__restrict__ rots = pa.rots; const float *__restrict__ opac = pa.opac;
+    float4 *__restrict__ rec = pa.rec; int *__restrict__ radii = pa.radii; int4 *__restrict__ rect = pa.rect;
+    uint32_t *__restrict__ tiles = pa.tiles; float *__restrict__ depth = pa.depth;
+    uint32_t *__restrict__ order_keys = pa.order_keys, *__restrict__ order_vals = pa.order_vals, *__restrict__ n_dev = pa.n_dev;
+    const float2 *__restrict__ col_cs = pa.col_cs, *__restrict__ row_cs = pa.row_cs;
+    uint64_t *__restrict__ tile_mask = pa.tile_mask; int4 *__restrict__ erec = pa.erec;
+    const int i = first + (int)threadIdx.x;
     uint32_t my_tiles = 0;
     // D10 (sls_det_math.h): which tiles of the rectangle the footprint can reach — bit k = k-th tile in emission
     // order (row-major).  Tested for rectangles of cam.tile_cull .. 64 tiles; others keep the whole rectangle.
@@ -310,18 +323,15 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
             // emit nothing): a surfel that flips between visible and culled then keeps its place in
             // the order, which keeps the order repairable from one iteration to the next.
             order_keys[i] = depth_order_key(g.rho);
-            order_vals[i] = (uint32_t)i;
+            if (order_vals) order_vals[i] = (uint32_t)i;
         }
     }
     // ---- D10: the tile tests of a wave's surfels, dealt out evenly over its lanes (a surfel's rectangle has 1 to 18
     // tiles on the bench scene: lane-per-surfel loops would run at the pace of the largest rectangle of the wave)
     // One wave-private LDS slice serves the tile tests and, afterwards, the staging of the records.
-    constexpr int kCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
-    constexpr int kSliceBytes = kCullBytes > 64 * kRec4 * 16 ? kCullBytes : 64 * kRec4 * 16;
-    __shared__ __attribute__((aligned(16))) unsigned char s_slice[4][kSliceBytes];
     if (__ballot(tested)) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int4 *s_rect_w = reinterpret_cast<int4 *>(s_slice[wave]);
+        int4 *s_rect_w = reinterpret_cast<int4 *>(s_mem + (size_t)wave * kPreSliceBytes);
         SlsTileCullSurfel *s_cull_w = reinterpret_cast<SlsTileCullSurfel *>(s_rect_w + 64);
         uint32_t *s_scan_w = reinterpret_cast<uint32_t *>(s_cull_w + 64);
         uint32_t *s_drop_w = s_scan_w + 64;                       // [64][2]
@@ -388,11 +398,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
     {   // the 80-byte records leave through LDS so that every store instruction writes 1 KB of
         // consecutive addresses (a direct store would touch 40 cache lines per instruction)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float4 *t = reinterpret_cast<float4 *>(s_slice[wave]);
+        float4 *t = reinterpret_cast<float4 *>(s_mem + (size_t)wave * kPreSliceBytes);
         t[lane * kRec4 + 0] = q0; t[lane * kRec4 + 1] = q1; t[lane * kRec4 + 2] = q2;
         t[lane * kRec4 + 3] = q3; t[lane * kRec4 + 4] = q4;
         __builtin_amdgcn_wave_barrier();
-        const size_t base = ((size_t)blockIdx.x * 256 + (size_t)wave * 64) * kRec4, end = (size_t)N * kRec4;
+        const size_t base = ((size_t)first + (size_t)wave * 64) * kRec4, end = (size_t)N * kRec4;
 #pragma unroll
         for (int k = 0; k < kRec4; ++k) {
             const size_t idx = base + (size_t)(k * 64 + lane);
@@ -400,17 +410,52 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(
         }
     }
     if (ra.pen != 0.0f && ra.reg_out) {   // block reduction of the regulariser, one atomic per block
-        __shared__ float s_part[4];
         float v = my_reg;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+            float tot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) tot += s_part[k];
             if (tot != 0.0f) atomicAdd(ra.reg_out, tot);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_kernel(DevCam cam, RegArgs ra, int N, PreFwdArgs pa)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[4 * kPreSliceBytes];
+    __shared__ float s_part[4];
+    preprocess_fwd_body<4>(cam, ra, N, pa, (int)blockIdx.x * 256, s_mem, s_part);
+}
+
+// The same in ONE launch with step A of the depth-order repair (sls_resort.hpp): the first `n_windows` workgroups
+// sort windows of the previous order by the NEW depth keys — which they compute themselves from the centres, with
+// the arithmetic of surfel_geom<true> — the others preprocess 512 surfels each.  The window sort is a chain of
+// latencies (gathers, LDS stages), the preprocess is VALU bound: side by side they cost little more than the
+// longer of the two, and the iteration has one dependent launch less.
+__global__ __launch_bounds__(512) void preprocess_fwd_resort_kernel(DevCam cam, RegArgs ra, int N, PreFwdArgs pa, int n_windows,
+                                                                    const uint32_t *__restrict__ prev_order,
+                                                                    uint64_t *__restrict__ comp)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[8 * kPreSliceBytes];
+    __shared__ float s_part[8];
+    static_assert(8 * kPreSliceBytes >= (int)(kResortThreads * sizeof(ulonglong2)), "the window sort's pairs fit the slices");
+    if ((int)blockIdx.x < n_windows) {
+        const float *__restrict__ means = pa.means;
+        resort_sort_window((int)blockIdx.x, N, prev_order, [&](uint32_t g) {
+            const float m0 = means[3 * (size_t)g], m1 = means[3 * (size_t)g + 1], m2 = means[3 * (size_t)g + 2];
+            float p[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = fmaf(cam.R[3 * k], m0, fmaf(cam.R[3 * k + 1], m1, fmaf(cam.R[3 * k + 2], m2, cam.t[k])));
+            const float rho2 = fmaf(p[2], p[2], fmaf(p[0], p[0], p[1] * p[1]));
+            return depth_order_key(sqrtf(rho2));
+        }, comp, reinterpret_cast<ulonglong2 *>(s_mem));
+        return;
+    }
+    preprocess_fwd_body<8>(cam, ra, N, pa, ((int)blockIdx.x - n_windows) * 512, s_mem, s_part);
 }
 
 // ---------------------------------------------------------------------------
@@ -625,17 +670,29 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           const float *means, const float *scales, const float *rots, const float *opac, float *rec,
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear,
-                          const float *col_cs, const float *row_cs, uint64_t *tile_mask, int32_t *erec)
+                          const float *col_cs, const float *row_cs, uint64_t *tile_mask, int32_t *erec,
+                          const uint32_t *resort_prev_order, uint64_t *resort_comp)
 {
-    const int nb = (N + 255) / 256;
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out; ra.status_clear = status_clear;
+    PreFwdArgs pa;
+    pa.means = means; pa.scales = (const float2 *)scales; pa.rots = (const float4 *)rots; pa.opac = opac;
+    pa.rec = (float4 *)rec; pa.radii = radii; pa.rect = (int4 *)rect; pa.tiles = tiles; pa.depth = depth;
+    pa.order_keys = order_keys; pa.order_vals = order_vals; pa.n_dev = n_dev;
+    pa.col_cs = (const float2 *)col_cs; pa.row_cs = (const float2 *)row_cs;
+    pa.tile_mask = (col_cs && row_cs) ? tile_mask : nullptr;
+    pa.erec = (cam.GX < 65536 && cam.GY < 65536) ? (int4 *)erec : nullptr;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, N, means, (const float2 *)scales,
-                       (const float4 *)rots, opac, (float4 *)rec, radii, (int4 *)rect, tiles, depth, order_keys,
-                       order_vals, n_dev, (const float2 *)col_cs, (const float2 *)row_cs,
-                       (col_cs && row_cs) ? tile_mask : nullptr,
-                       (cam.GX < 65536 && cam.GY < 65536) ? (int4 *)erec : nullptr);
+    if (resort_prev_order && resort_comp) {
+        // merged with the repair's window sort (which overwrites the sort's identity permutation: not written here)
+        pa.order_vals = nullptr;
+        const int nw = (N + kResortWindow - 1) / kResortWindow, nb = (N + 511) / 512;
+        hipLaunchKernelGGL(preprocess_fwd_resort_kernel, dim3(nw + nb), dim3(512), 0, st, cam, ra, N, pa, nw, resort_prev_order,
+                           resort_comp);
+        SLS_LAUNCH_CHECK("preprocess_fwd_resort_kernel");
+        return SLS_OK;
+    }
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cam, ra, N, pa);
     SLS_LAUNCH_CHECK("preprocess_fwd_kernel");
     return SLS_OK;
 }

@@ -29,6 +29,7 @@
 //     a host-side capacity, so a whole iteration can be enqueued without a
 //     device->host sync (sls_mapping_step).
 #include "sls_common.hpp"
+#include "sls_resort.hpp"
 
 namespace sls {
 
@@ -384,123 +385,12 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
 //      the Adam update is skipped on the device and the caller repeats the
 //      iteration with the full radix sort (same protocol as a capacity overflow).
 // ---------------------------------------------------------------------------
-constexpr int kResortWindow = 1024;
-constexpr uint32_t kResortFailed = 2u;            // bit in SlsMappingStatus.overflow
-
-// The bitonic network of a window, from width K0 up to the full window, on elements held in REGISTERS:
-// thread t of the 512 owns elements 2t and 2t+1 of the window.
-//   * partner distance 1: inside the thread;
-//   * distances 2 .. 64 (thread ^ 1 .. 32): inside the wave — DPP (quad_perm, row_shl/shr:4, row_ror:8) for
-//     thread distances 1, 2, 4, 8, ds_bpermute for 16 and 32: no LDS storage, no barrier;
-//   * distances 128, 256, 512 (thread ^ 64, 128, 256): the only stages that go through LDS (one 128-bit write and
-//     one 128-bit read of the partner thread's pair, two workgroup barriers): 6 of the 55 stages of a sort, 3 of
-//     the 10 of a merge.
-// (The same network with every stage of distance >= 2 in LDS — 45 round trips with bank conflicts on the 64-bit
-//  elements — took 16.5 + 7.8 us per repair on C1 against what this one takes)
-// Branch-free compare-exchange throughout; all elements are distinct (the surfel index is part of the key).
-constexpr int kResortThreads = 512;
-static_assert(kResortWindow == 2 * kResortThreads, "one pair of elements per thread");
-
-template <int M>
-__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
-{
-    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane distance inside a wave");
-    if (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-    if (M == 4) {
-        int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);                    // row_shl:4 -> banks 0, 2
-        a = __builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);                        // row_shr:4 -> banks 1, 3
-        return (uint32_t)a;
-    }
-    if (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
-    return (uint32_t)__shfl_xor((int)v, M, 64);                                                    // ds_bpermute_b32
-}
-template <int M>
-__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v)
-{
-    return ((uint64_t)lane_xor_u32<M>((uint32_t)(v >> 32)) << 32) | lane_xor_u32<M>((uint32_t)v);
-}
-// e <- min(e, p) if keep_min else max(e, p)
-__device__ __forceinline__ void keep64(uint64_t &e, uint64_t p, bool keep_min)
-{
-    e = ((p < e) == keep_min) ? p : e;
-}
-// one stage with the partner thread at distance M (element distance 2M) of the width-k step
-template <int M>
-__device__ __forceinline__ void bitonic_stage(uint64_t &e0, uint64_t &e1, bool asc, ulonglong2 *s_pairs)
-{
-    const int t = threadIdx.x;
-    const bool keep_min = ((t & M) == 0) == asc;
-    uint64_t p0, p1;
-    if constexpr (M >= 64) {
-        s_pairs[t] = make_ulonglong2(e0, e1);
-        __syncthreads();
-        const ulonglong2 pp = s_pairs[t ^ M];
-        p0 = pp.x; p1 = pp.y;
-        __syncthreads();
-    } else {
-        p0 = lane_xor_u64<M>(e0); p1 = lane_xor_u64<M>(e1);
-    }
-    keep64(e0, p0, keep_min);
-    keep64(e1, p1, keep_min);
-}
-template <int K>
-__device__ __forceinline__ void bitonic_width(uint64_t &e0, uint64_t &e1, ulonglong2 *s_pairs)
-{
-    // direction of the width-K blocks (the last width sorts ascending throughout)
-    const bool asc = (K == kResortWindow) || ((2 * (int)threadIdx.x) & K) == 0;
-    if constexpr (K >= 1024) bitonic_stage<256>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 512) bitonic_stage<128>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 256) bitonic_stage<64>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 128) bitonic_stage<32>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 64) bitonic_stage<16>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 32) bitonic_stage<8>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 16) bitonic_stage<4>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 8) bitonic_stage<2>(e0, e1, asc, s_pairs);
-    if constexpr (K >= 4) bitonic_stage<1>(e0, e1, asc, s_pairs);
-    // distance 1: the two elements of the thread
-    const bool sw = (e0 > e1) == asc;
-    const uint64_t lo = sw ? e1 : e0, hi = sw ? e0 : e1;
-    e0 = lo; e1 = hi;
-}
-// full sort (K0 = 2) or merge of a bitonic window (K0 = kResortWindow)
-template <int K0>
-__device__ __forceinline__ void bitonic_pairs(uint64_t &e0, uint64_t &e1, ulonglong2 *s_pairs)
-{
-    if constexpr (K0 <= 2) bitonic_width<2>(e0, e1, s_pairs);
-    if constexpr (K0 <= 4) bitonic_width<4>(e0, e1, s_pairs);
-    if constexpr (K0 <= 8) bitonic_width<8>(e0, e1, s_pairs);
-    if constexpr (K0 <= 16) bitonic_width<16>(e0, e1, s_pairs);
-    if constexpr (K0 <= 32) bitonic_width<32>(e0, e1, s_pairs);
-    if constexpr (K0 <= 64) bitonic_width<64>(e0, e1, s_pairs);
-    if constexpr (K0 <= 128) bitonic_width<128>(e0, e1, s_pairs);
-    if constexpr (K0 <= 256) bitonic_width<256>(e0, e1, s_pairs);
-    if constexpr (K0 <= 512) bitonic_width<512>(e0, e1, s_pairs);
-    bitonic_width<1024>(e0, e1, s_pairs);
-}
-// window position of element q (0, 1) of thread t when the window is loaded as a bitonic sequence: the second
-// half back to front (ascending + descending)
-__device__ __forceinline__ int bitonic_src(int o)
-{
-    return o < kResortWindow / 2 ? o : (kResortWindow + kResortWindow / 2 - 1 - o);
-}
-
 __global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, const uint32_t *__restrict__ prev_order,
                                                                      const uint32_t *__restrict__ keys_by_surfel,
                                                                      uint64_t *__restrict__ comp)
 {
     __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
-    const int pos0 = blockIdx.x * kResortWindow + 2 * (int)threadIdx.x;
-    // (unconditional loads at clamped addresses, all of a level before the next: two dependent round trips
-    //  instead of one branch + full wait per element)
-    const uint32_t g0 = min(prev_order[min(pos0, N - 1)], (uint32_t)(N - 1));        // (memory-safe whatever the caller kept)
-    const uint32_t g1 = min(prev_order[min(pos0 + 1, N - 1)], (uint32_t)(N - 1));
-    const uint32_t k0 = keys_by_surfel[g0], k1 = keys_by_surfel[g1];
-    uint64_t e0 = pos0 < N ? (((uint64_t)k0 << 32) | g0) : ~0ull;                    // padding behind the end sorts last
-    uint64_t e1 = pos0 + 1 < N ? (((uint64_t)k1 << 32) | g1) : ~0ull;
-    bitonic_pairs<2>(e0, e1, s_pairs);
-    if (pos0 < N) comp[pos0] = e0;
-    if (pos0 + 1 < N) comp[pos0 + 1] = e1;
+    resort_sort_window((int)blockIdx.x, N, prev_order, [&](uint32_t g) { return keys_by_surfel[g]; }, comp, s_pairs);
 }
 
 // Second repair round, first half (reuse_depth_order = 2): after one round the array is sorted inside every
@@ -777,9 +667,18 @@ void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **k
 // reuse_order != 0: `order` holds the permutation of the previous iteration (same surfels, same
 // keyframe) and the keys were written by preprocess (keys_prefilled): temporal re-sort, failure is
 // reported in *fail_flag (see above).
+// where the repair keeps its (key, surfel) pairs: N u64 over the sort's two temporary arrays
+uint64_t *resort_comp_buffer(int N, void *scratch)
+{
+    uint32_t *keys_tmp = (uint32_t *)scratch + N;
+    return (uint64_t *)(((uintptr_t)keys_tmp + 7) & ~(uintptr_t)7);
+}
+
+// window_sort_done: step A of the repair (resort_sort) already ran — merged into the preprocess launch
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st, int reuse_order, uint32_t *fail_flag, ScanHandoff *handoff)
+                            hipStream_t st, int reuse_order, uint32_t *fail_flag, ScanHandoff *handoff,
+                            bool window_sort_done)
 {
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
@@ -803,14 +702,16 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
     const uint64_t *resort_edges = nullptr;
     if (reuse_order && keys_prefilled && fail_flag) {
         // comp: N u64 over the two temporary arrays (8-byte aligned), edges in the sort's count table
-        uint64_t *comp = (uint64_t *)(((uintptr_t)keys_tmp + 7) & ~(uintptr_t)7);
+        uint64_t *comp = resort_comp_buffer(N, scratch);
         uint64_t *edges = (uint64_t *)(((uintptr_t)sort_scratch + 7) & ~(uintptr_t)7);
         const int nA = (N + kResortWindow - 1) / kResortWindow;
         const int nB = (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow;   // windows that hold a real element
         ScopedTimer tm(T_RESORT, st);
-        hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
-                           (const uint32_t *)keys, comp);
-        SLS_LAUNCH_CHECK("resort_sort_kernel");
+        if (!window_sort_done) {
+            hipLaunchKernelGGL(resort_sort_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
+                               (const uint32_t *)keys, comp);
+            SLS_LAUNCH_CHECK("resort_sort_kernel");
+        }
         hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order, edges,
                            tiles, block_sums);
         SLS_LAUNCH_CHECK("resort_merge_kernel");

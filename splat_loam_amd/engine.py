@@ -193,7 +193,7 @@ class MappingEngine:
             c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
         c.deterministic = 1 if self.deterministic else 0
         if self._sx is not None and not apply_adam:
-            c.grad_bitmap = self._sx["bitmap"].data_ptr()
+            c.grad_bitmap = self._sx["mine"].data_ptr()
         return c
 
     def _order_entry(self, camera):
@@ -276,10 +276,12 @@ class MappingEngine:
 
     def _note(self, st):
         """Host-side bookkeeping driven by a status every rank sees identically: the sparse exchange's collective
-        size follows the measured size of the union of the touched sets (25 % + 1024 slots of head room; a union
-        that outgrows it voids one iteration, which is repeated with the new size)."""
+        size follows the measured size of the union of the touched sets: up at once (50 % + 4096 slots of head room
+        — keyframes of a window reach sets of different size, and an iteration voided by a union that outgrew the
+        collective costs more than a few hundred KB on the wire), down by 3 % per iteration."""
         if self._sx is not None and (not st["overflow"] or st["exchange_too_small"]):
-            self._sx["send"] = int(min(self.N, int(st["exchange_count"] * 1.25) + 1024))
+            want = int(st["exchange_count"] * 1.5) + 4096
+            self._sx["send"] = int(min(self.N, max(want, int(self._sx["send"] * 0.97))))
         return st
 
     @staticmethod
@@ -449,7 +451,9 @@ class MappingEngine:
             if self._sx is None:
                 lib = _abi.lib()
                 nw = int(lib.sls_grad_bitmap_words(N))
-                self._sx = {"bitmap": torch.zeros((nw,), dtype=torch.int64, device=self.dev),
+                self._sx = {"bitmap": torch.zeros((nw,), dtype=torch.int64, device=self.dev),       # the union (after the OR)
+                            "mine": torch.zeros((nw,), dtype=torch.int64, device=self.dev),         # this rank's bitmap
+                            "all": torch.zeros((G * nw,), dtype=torch.int64, device=self.dev),      # every rank's
                             "prefix": torch.zeros((nw,), dtype=torch.int32, device=self.dev),
                             "compact": torch.zeros((10 * N,), dtype=torch.float32, device=self.dev),
                             "send": N}          # slots handed to the SUM collective: all of them until the union's size is known
@@ -489,10 +493,13 @@ class MappingEngine:
             # touched set only: OR of the bitmaps -> pack the union's rows -> SUM of the first `send` slots -> Adam
             lib, sx, N = _abi.lib(), self._sx, self.N
             st = torch.cuda.current_stream(self.dev).cuda_stream
-            dist.all_reduce(sx["bitmap"], op=dist.ReduceOp.BOR, group=group)
+            # (RCCL offers no bitwise-OR reduction: the bitmaps are gathered, the library ORs them)
+            dist.all_gather_into_tensor(sx["all"], sx["mine"], group=group)
+            G = int(sx["all"].numel() // sx["mine"].numel())
             send = int(sx["send"])
-            _abi.check(lib.sls_grad_compact(N, sx["bitmap"].data_ptr(), self.grads.data_ptr(), sx["compact"].data_ptr(),
-                                            send, sx["prefix"].data_ptr(), status.data_ptr(), st), "sls_grad_compact")
+            _abi.check(lib.sls_grad_compact(N, sx["all"].data_ptr(), G, sx["bitmap"].data_ptr(), self.grads.data_ptr(),
+                                            sx["compact"].data_ptr(), send, sx["prefix"].data_ptr(), status.data_ptr(), st),
+                       "sls_grad_compact")
             dist.all_reduce(sx["compact"][:10 * send], op=dist.ReduceOp.SUM, group=group)
             if ev:
                 ev[1].record()
@@ -505,7 +512,7 @@ class MappingEngine:
                                                 status.data_ptr(), mirror, st), "sls_adam_step_sparse")
             if ev:
                 ev[2].record(); ev[3].record()
-            self.exchanged_bytes = 8 * int(sx["bitmap"].numel()) + 40 * send
+            self.exchanged_bytes = 8 * int(sx["mine"].numel()) + 40 * send
         elif self._dp is None:
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
             if ev:
