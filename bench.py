@@ -542,7 +542,9 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
     """The CPU legs (rank 0, 1 GPU only).  Primary = the baseline BASELINE.json names: the pure-PyTorch tile
     rasterizer (oracle/torch_tiles.py), one WHOLE mapping iteration (activations, render, render() post-processing
     + mapper loss in torch, autograd backward, torch.optim.Adam).
-      * thread count: swept over 32 / 64 / all host threads on a small tile subset, the fastest is used and reported;
+      * thread count: swept over 16 / 32 / 64 (and all host threads when there are at most 96: with 256 the pool's
+        warm-up alone took 144 s, profiles/r03c_bench_cpu_thread_sweep.err) on a small tile subset, the fastest is
+        used and reported;
       * the headline workload (500k surfels, 64x2048): a stated subset of the tiles, extrapolated by the tile count
         (SURVEY.md section 8d allows it for N = 500k);
       * SURVEY.md section 8d's mandatory case, 50k surfels at 64x1024 with EVERY tile: one warm-up, then the median
@@ -578,7 +580,10 @@ def cpu_baselines(scene, poses, depth, valid, cfg, N, H, W, tile):
         sweep = {}
         probe = sorted(set(int(i * T2 / 12) for i in range(12)))
         t_leg = time.perf_counter()
-        for th in sorted(set(t for t in (32, 64, host) if t <= host)):
+        # every host thread was tried once (profiles/r03c_bench_cpu_thread_sweep.err: 256 threads need 144 s for the
+        # two warm-up tiles alone, 32 threads 0.31 s for 12 tiles, 64 threads 0.69 s): pools beyond 96 threads are
+        # not probed again in the default run, which has to finish within minutes
+        for th in sorted(set(t for t in (16, 32, 64, host) if t <= host and t <= 96)):
             torch.set_num_threads(th)
             t_w = time.perf_counter()
             torch_iteration(sc2, 64, 1024, probe[:2])                      # warm the pool

@@ -132,6 +132,13 @@ inline DevCam make_devcam(const SlsCamera &c)
     return d;
 }
 
+// Ballot / all over the wave straight from the condition's lane mask.  HIP's __ballot() goes through an integer
+// compare of the zero-extended predicate: where the predicate is the result of scalar mask logic the compiler
+// materialises it as 0/1 in a VGPR and compares again — two half-rate VALU instructions per ballot in the tile
+// kernels' step loops (v_cndmask_b32 + v_cmp_ne_u32, ~4 clocks each on gfx950: profiles/r03a_valu_calibration.json).
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // One DPP move: returns src permuted by CTRL; lanes whose row is masked off

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     v2f N01 = mk2(0.0f, 0.0f);
     uint32_t medc = 0, last = 0, cons = 0;
     bool done = !inside;
-    bool wave_done = __all(done);
+    bool wave_done = wave_all(done);
     uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0, st_slots = 0, st_geom = 0;   // diagnostics only
 
     // footprint test against the whole block (sls_tile.hpp): rays of the block = d0 + x Dx + y Dy
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     SLS_PHASE_DECL();
     for (int r = 0; r < nr && !wave_done; ++r) {
         float bcx, bcy, bhx, bhy;
-        if (!block_active_box<BW, BH>(__ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        if (!block_active_box<BW, BH>(wave_ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
         SLS_PHASE_RESET();
         SLS_TRACE_ROUND();
-        SLS_TRACE_ACTIVE(__ballot(!done));
+        SLS_TRACE_ACTIVE(wave_ballot(!done));
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                        disc_reaches(c3, c4, bcx, bcy, bhx, bhy, wrapW, invW);
             }
         }
-        const uint64_t mask = __ballot(pass);
+        const uint64_t mask = wave_ballot(pass);
         const int npass = __builtin_popcountll(mask);
         if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
         __builtin_amdgcn_wave_barrier();
@@ -242,15 +242,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
             const bool live = valid && !done && !e.skip;
             if (DBG) {
-                const uint64_t lb = __ballot(live);
+                const uint64_t lb = wave_ballot(live);
                 st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(lb);
-                const uint64_t gb = __ballot(valid && inside && !e.skip);      // ignoring finished pixels
+                const uint64_t gb = wave_ballot(valid && inside && !e.skip);      // ignoring finished pixels
                 for (int q = 0; q < 4; ++q) {
                     st_slots += (lb & (0x1111111111111111ull << q)) ? 1u : 0u;
                     st_geom += (gb & (0x1111111111111111ull << q)) ? 1u : 0u;
                 }
             }
-            if (!__ballot(live)) continue;
+            if (!wave_ballot(live)) continue;
             SLS_TRACE_STEP();
             // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k
             const float f = live ? 1.0f - e.alpha : 1.0f;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
             sh = dppq<kQuadShr1>(I); E = slot >= 2 ? sh : E; I = E * f;
             sh = dppq<kQuadShr1>(I); E = slot >= 3 ? sh : E; I = E * f;
             const bool term = live && (I < SLS_T_MIN);
-            const uint64_t tb = __ballot(term);
+            const uint64_t tb = wave_ballot(term);
             // the transmittance behind the four entries (a finished pixel has f = 1 in every slot: Tr stays)
             const float I3 = dppq<0xFF>(I);
             bool upd = live;
@@ -295,12 +295,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                 med = is_med ? dep : med;
                 medc = is_med ? contributor : medc;
             }
-            if (tb && __all(done)) { wave_done = true; break; }
+            if (tb && wave_all(done)) { wave_done = true; break; }
         }
         SLS_PHASE(2);
         if (blk_mask) {
             __builtin_amdgcn_wave_barrier();
-            const uint64_t rmask = __ballot(s_flag[lane] != 0u);
+            const uint64_t rmask = wave_ballot(s_flag[lane] != 0u);
             if (lane == 0) blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)] = rmask;
             if (rmask) { bwd_rounds = (uint32_t)(r + 1); bwd_steps += (uint32_t)(__builtin_popcountll(rmask) + 3) / 4u; }
         }
@@ -454,6 +454,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         uint32_t next_idx = vals[range.x + (uint32_t)min((nr - 1) * 64 + lane, tmax - 1)];   // surfel of entry (r*64 + lane)
         if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, nr - 2, tmax) }
         float Tr = Tf, S = 0.0f;   // replicated over the quad
+        // the round's contribution mask is requested one round ahead: a load whose result the whole round waits for
+        uint64_t next_mask = use_mask ? blk_mask[block_mask_index(range.x, tile, nr - 1, kPerTile, sub)] : 0ull;
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
             SLS_TRACE_ROUND();
@@ -468,15 +470,16 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             const uint32_t c_lo = (uint32_t)(r * 64 + 1);
             uint64_t mask;
             if (use_mask) {
-                mask = blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)];
+                mask = next_mask;
+                if (r > 0) next_mask = blk_mask[block_mask_index(range.x, tile, r - 1, kPerTile, sub)];
                 if (cnt < 64) mask &= (1ull << cnt) - 1ull;
             } else {
                 float bcx, bcy, bhx, bhy;
-                if (!block_active_box<BW, BH>(__ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
+                if (!block_active_box<BW, BH>(wave_ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
                 __builtin_amdgcn_wave_barrier();
                 bool pass = false;
                 if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
-                mask = __ballot(pass);
+                mask = wave_ballot(pass);
             }
             if (mask == 0) continue;
             const bool pass = (mask >> lane) & 1ull;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 Eval e;
                 eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
                 const bool act = valid && inside && (contributor <= last) && !e.skip;
-                if (!__ballot(act)) continue;
+                if (!wave_ballot(act)) continue;
                 SLS_TRACE_STEP();
                 const float om = act ? 1.0f - e.alpha : 1.0f;
                 const float rom = __builtin_amdgcn_rcpf(om);
