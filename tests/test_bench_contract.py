@@ -24,14 +24,22 @@ def test_latest_bench_line_has_the_contract_fields():
     assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
     assert d["dtype"] == "f32" and d["data"] == "synthetic"
     assert isinstance(d["config"], dict) and "workload" in d["config"] and "model" not in d["config"]
-    # value and ms_per_step describe the same measurement: n_gpus * N surfels per step
-    n = d["config"]["N"]
-    assert abs(d["value"] - d["n_gpus"] * n / (d["ms_per_step"] * 1e-3) * 1e-6) <= 2e-3 * d["value"]
+    # value and ms_per_step describe the same measurement: n_gpus * N surfels per mapping iteration, a bench step
+    # being `iterations_per_step` iterations (the driver's --steps 20 then times 200 iterations)
+    n, ips = d["config"]["N"], d["config"].get("iterations_per_step", 1)
+    assert abs(d["value"] - d["n_gpus"] * n * ips / (d["ms_per_step"] * 1e-3) * 1e-6) <= 2e-3 * d["value"]
+    if ips > 1:
+        assert abs(d["config"]["ms_per_iteration"] * ips - d["ms_per_step"]) <= 2e-3 * d["ms_per_step"]
+        assert d["config"]["keyframes"] >= 1 and "Mapper.optimize" in d["config"]["workload"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, f"roofline.{k} missing"
     assert r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    if "valu_calibration" in r and r.get("valu_frac") is not None:
+        # calibrated: the kernel's VALU counter reading relative to the same counter at the measured
+        # peak issue rate of plain FP32 instructions — a fraction, not the raw 0.95 "busy" figure
+        assert 0.0 < r["valu_frac"] < 1.0 and r["valu_calibration"]["peak_valu_issue_busy_quad"] > 1.0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, f"cpu_baseline.{k} missing"
@@ -43,3 +51,26 @@ def test_profiles_of_the_latest_round_are_committed():
     tag = os.path.basename(path).split("_")[0]
     for suffix in ("bench_kernel_stats.csv", "pmc_traffic.json", "pmc_sq.json"):
         assert os.path.exists(os.path.join(ROOT, "profiles", f"{tag}_{suffix}")), f"profiles/{tag}_{suffix} missing"
+
+
+def test_replayed_counters_belong_to_this_build():
+    """`roofline.traffic` / `roofline.valu` are replayed from committed rocprofv3 --pmc passes (rocprofv3 cannot wrap
+    the process it is called from).  The passes record the hash of the kernel sources they were measured on
+    (bench.kernel_source_hash); the NEWEST committed passes must carry the hash of the sources in the tree — change a
+    kernel without re-profiling and this fails (and bench.py prints "stale": true)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench
+    finally:
+        sys.argv = argv
+    now = bench.kernel_source_hash()
+    for pattern in ("*pmc_traffic.json", "*pmc_sq.json"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        assert files, pattern
+        got = json.load(open(files[-1])).get("kernel_source_hash")
+        assert got == now, (f"{os.path.basename(files[-1])} was measured on kernel sources {got}, the tree has {now}: "
+                            "re-run tools/profile_round.sh on the GPU box and commit its outputs")
+    path, d = _latest()
+    assert d["roofline"].get("stale") is False, f"{path}: the line itself says its replayed counters are stale"
