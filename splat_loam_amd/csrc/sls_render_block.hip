@@ -151,9 +151,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 {
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
-    __shared__ float4 s_rec[64 * kRec4];
-    __shared__ uint32_t s_list[64];
-    __shared__ uint32_t s_flag[64];
+    // (record 64 is all zeros — opacity 0, range 0: never live — and pads the compacted list to a multiple of four,
+    //  so that a step needs no "is my slot beyond the list" test)
+    __shared__ float4 s_rec[65 * kRec4];
+    __shared__ uint32_t s_list[64 + 4];
+    __shared__ uint32_t s_flag[65];
     uint32_t bwd_rounds = 0, bwd_steps = 0;      // what the backward will have to do for this block (from the masks)
     const uint64_t t_start = DBG ? clock64() : 0;
     SLS_TRACE_BEGIN();
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const v2f pcr = mk2((float)px, (float)py);
     const float mscale = cam.far_c / (cam.far_c - cam.near_c);
     const uint32_t below = (1u << slot) - 1u, upto = (2u << slot) - 1u;   // quad bits of the earlier slots (and self)
+    const bool sge1 = slot >= 1, sge2 = slot >= 2, sge3 = slot >= 3;
 
     // replicated over the quad: Tr, done.  Per-lane partial sums: D, N*, M1, M2.
     float Tr = 1.0f, M1 = 0.0f, M2 = 0.0f;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const BlockCone cone = make_block_cone(cam, (float)x0 + 0.5f * (float)(BW - 1), (float)y0 + 0.5f * (float)(BH - 1),
                                            0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
     const int nr = (n + 63) / 64;
+    if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     SLS_STAGE_DECL
     if (nr > 0 && !wave_done) {
         SLS_WSTAGE_LOAD_IDX(range.x, 0, n)
@@ -229,57 +233,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         const uint64_t mask = wave_ballot(pass);
         const int npass = __builtin_popcountll(mask);
         if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
+        if (lane < 3) s_list[npass + lane] = 64u;          // pad to a multiple of four with the empty record
         __builtin_amdgcn_wave_barrier();
         SLS_PHASE(1);
         if (DBG) { st_staged += (uint32_t)cnt; st_pass += (uint32_t)npass; }
         for (int k = 0; k < npass; k += 4) {
-            const bool valid = (k + slot) < npass;
-            const int j = (int)s_list[min(k + slot, npass - 1)];
+            const int j = (int)s_list[k + slot];
             const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
             const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
             const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
             Eval e;
             eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
-            const bool live = valid && !done && !e.skip;
+            const bool live = !done && !e.skip;
             if (DBG) {
                 const uint64_t lb = wave_ballot(live);
                 st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(lb);
-                const uint64_t gb = wave_ballot(valid && inside && !e.skip);      // ignoring finished pixels
+                const uint64_t gb = wave_ballot(inside && !e.skip);      // ignoring finished pixels
                 for (int q = 0; q < 4; ++q) {
                     st_slots += (lb & (0x1111111111111111ull << q)) ? 1u : 0u;
                     st_geom += (gb & (0x1111111111111111ull << q)) ? 1u : 0u;
                 }
             }
+#ifdef SLS_FWD_SKIP_DEAD
+            // (a step none of whose 64 (pixel, entry) pairs is live: measured rare enough that testing for it — a
+            //  ballot of mask logic costs two half-rate VALU instructions — does not pay; kept as a build switch)
             if (!wave_ballot(live)) continue;
+#endif
             SLS_TRACE_STEP();
-            // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k
-            const float f = live ? 1.0f - e.alpha : 1.0f;
+            // alpha of the lanes that take part (0: the entry passes through, f = 1)
+            const float a = live ? e.alpha : 0.0f;
+            const float f = 1.0f - a;
+            // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k — every lane
+            // forms the three running products (the quad's f broadcast by DPP) and picks its own
             // (the DPP moves must execute in all lanes: never inside a conditional expression)
-            float E = Tr, I = Tr * f, sh;
-            sh = dppq<kQuadShr1>(I); E = slot >= 1 ? sh : E; I = E * f;
-            sh = dppq<kQuadShr1>(I); E = slot >= 2 ? sh : E; I = E * f;
-            sh = dppq<kQuadShr1>(I); E = slot >= 3 ? sh : E; I = E * f;
-            const bool term = live && (I < SLS_T_MIN);
-            const uint64_t tb = wave_ballot(term);
+            const float P1 = Tr * dppq<0x00>(f);
+            const float P2 = P1 * dppq<0x55>(f);
+            const float P3 = P2 * dppq<0xAA>(f);
+            float E = sge1 ? P1 : Tr;
+            E = sge2 ? P2 : E;
+            E = sge3 ? P3 : E;
+            const float I = E * f;
             // the transmittance behind the four entries (a finished pixel has f = 1 in every slot: Tr stays)
             const float I3 = dppq<0xFF>(I);
             bool upd = live;
-            if (tb) {
+            float w = a * E;
+            // T only falls along a pixel's slots and stays >= T_MIN while the pixel is alive, so some slot of a quad
+            // terminates iff the quad's last value is below the threshold: ONE compare on a VGPR feeds the ballot
+            if (wave_ballot(I3 < SLS_T_MIN)) {
                 // some pixel of the block terminates in this step (at most once per pixel): cut its quad at the
                 // first terminating slot
+                const bool term = live && (I < SLS_T_MIN);
+                const uint64_t tb = wave_ballot(term);
                 const uint32_t nib = (uint32_t)(tb >> (lane & 60)) & 15u;   // terminating slots of my pixel
                 const bool first_term = term && !(nib & below);
                 upd = live && !(nib & upto);
+                w = upd ? w : 0.0f;
                 cons = first_term ? contributor : cons;
                 const float Tt = quad_sum(first_term ? E : 0.0f);          // in front of the first terminating slot
                 Tr = nib ? Tt : I3;
                 done = done || (nib != 0u);
+                if (wave_all(done)) wave_done = true;
             } else {
                 Tr = I3;
             }
             if (blk_mask && upd) s_flag[j] = 1u;   // (same value from every lane: plain LDS store)
-            const float w = upd ? e.alpha * E : 0.0f;
-            const float dep = upd ? e.depth : 1.0f;
+            // (w = 0 where the lane does not take part and the depth of an evaluated pair is finite: no select needed;
+            //  the distortion's 1 / depth below wants a harmless value there)
+            const float dep = LEAN ? e.depth : (upd ? e.depth : 1.0f);
             D += dep * w;
             N01 += mk2(q2.x, q2.y) * w; N2 += q2.z * w;
             last = upd ? contributor : last;
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                 med = is_med ? dep : med;
                 medc = is_med ? contributor : medc;
             }
-            if (tb && wave_all(done)) { wave_done = true; break; }
+            if (wave_done) break;
         }
         SLS_PHASE(2);
         if (blk_mask) {
@@ -380,9 +400,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
-    __shared__ float4 s_rec[64 * kRec4];
-    __shared__ uint32_t s_list[64];
-    __shared__ uint32_t s_gidx[64];
+    // (record 64: all zeros, never active — pads the compacted list to a multiple of four, as in the forward)
+    __shared__ float4 s_rec[65 * kRec4];
+    __shared__ uint32_t s_list[64 + 4];
+    __shared__ uint32_t s_gidx[65];
     // contribution masks of a forward with the same block shape, else cull here
     const bool use_mask = blk_mask != nullptr && blk_mask[0] == block_mask_tag(BW);
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
@@ -448,6 +469,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const int tmax = (int)wmax;
     if (tmax > 0) {
         const int nr = (tmax + 63) / 64;
+        if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lane == 0) s_gidx[64] = 0u;
         SLS_STAGE_DECL
         SLS_WSTAGE_LOAD_IDX(range.x, nr - 1, tmax)
         SLS_WSTAGE_LOAD_REC()
@@ -489,19 +512,21 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             if (touched && pass) touched[my_idx] = 1;
             // survivors in DESCENDING list order
             if (pass) s_list[npass - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
+            if (lane < 3) s_list[npass + lane] = 64u;
             __builtin_amdgcn_wave_barrier();
             for (int k = 0; k < npass; k += 4) {
-                const bool valid = (k + slot) < npass;
-                const int j = (int)s_list[min(k + slot, npass - 1)];
+                const int j = (int)s_list[k + slot];
                 const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
                 const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
                 const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
                 Eval e;
                 eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
-                const bool act = valid && inside && (contributor <= last) && !e.skip;
-                if (!wave_ballot(act)) continue;
+                const bool act = inside && (contributor <= last) && !e.skip;
+                // (with the forward's masks every listed entry reached a pixel of this block: nothing to skip)
+                if (!use_mask && !wave_ballot(act)) continue;
                 SLS_TRACE_STEP();
-                const float om = act ? 1.0f - e.alpha : 1.0f;
+                const float a = act ? e.alpha : 0.0f;          // 0: the entry passes through (1 - a = 1, w = 0)
+                const float om = 1.0f - a;
                 const float rom = __builtin_amdgcn_rcpf(om);
                 // T in front of each entry: Ti = Tr * prod_{slots <= mine} rom, multiplied up in slot order
                 // (the DPP moves must execute in all lanes: never inside a conditional expression)
@@ -510,8 +535,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 2 ? sh : Ti;
                 sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 3 ? sh : Ti;
                 Tr = dppq<0xFF>(Ti);
-                const float w = act ? e.alpha * Ti : 0.0f;
-                const float dep = act ? e.depth : 1.0f;
+                const float w = a * Ti;
+                // (the depth of an evaluated pair is finite and meets w = 0 where the lane is inactive; the
+                //  distortion's 1 / depth wants a harmless value there)
+                const float dep = LEAN ? e.depth : (act ? e.depth : 1.0f);
                 float gdist = 0.0f, ddist = 0.0f;     // distortion terms of g_k and of dL/ddepth
                 if (!LEAN) {
                     const float rdep = __builtin_amdgcn_rcpf(dep);
@@ -552,11 +579,12 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 gl[7] = lp * e.dxy;                                             // fields 14, 15
                 const float tot = block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
                 const uint32_t gidx = s_gidx[j];
+                // (the padding entry is never active: its sums are exact zeros)
                 if (DET == 0) {
-                    if (valid && tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
+                    if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
                 } else if (DET == 1) {
-                    if (valid && tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
-                } else if (valid && tot != 0.0f) {
+                    if (tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
+                } else if (tot != 0.0f) {
                     const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
                     const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
                     atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
