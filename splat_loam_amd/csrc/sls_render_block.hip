@@ -521,9 +521,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
                 Eval e;
                 eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
-                const bool act = inside && (contributor <= last) && !e.skip;
-                // (with the forward's masks every listed entry reached a pixel of this block: nothing to skip)
-                if (!use_mask && !wave_ballot(act)) continue;
+                // (bitwise: three lane masks ANDed, no short-circuit control flow in the step; with the forward's masks
+                //  every listed entry reached a pixel of this block, and without them a step whose 64 pairs are all
+                //  inactive is rare — no dead-step test either: its ballot costs more than it saves, as in the forward)
+                const bool act = inside & (contributor <= last) & !e.skip;
                 SLS_TRACE_STEP();
                 const float a = act ? e.alpha : 0.0f;          // 0: the entry passes through (1 - a = 1, w = 0)
                 const float om = 1.0f - a;
