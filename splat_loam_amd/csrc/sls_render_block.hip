@@ -33,6 +33,11 @@ __device__ uint32_t g_trace[2][8192 * 4];
 // forward: shader clocks a wave spent waiting for the staged records (+ LDS store) / in cull + compaction / in the
 // steps / at the round's end
 __device__ uint32_t g_trace_phase[8192 * 4];
+// marks: wall-clock offsets (10 ns units) from the wave's start at up to four points of its life, taken when the
+// value passed (the result of the loads the point waits for) is in a register
+__device__ uint32_t g_trace_mark[2][8192 * 4];
+#define SLS_MARK(kern_, k_, v_) { asm volatile("" :: "v"(v_)); const uint32_t m_ = (uint32_t)(wall_clock64() - trace_t0); \
+                                  if (threadIdx.x == 0 && blockIdx.x < 8192) g_trace_mark[kern_][4 * blockIdx.x + (k_)] = m_; }
 #define SLS_PHASE_DECL() uint64_t ph_t = clock64(); uint32_t ph_acc[4] = { 0, 0, 0, 0 }
 #define SLS_PHASE(k_) { const uint64_t now_ = clock64(); ph_acc[k_] += (uint32_t)(now_ - ph_t); ph_t = now_; }
 #define SLS_PHASE_RESET() ph_t = clock64()
@@ -49,6 +54,7 @@ __device__ uint32_t g_trace_phase[8192 * 4];
         t[3] = (trace_rounds << 16) | (trace_steps & 0xFFFFu);                                            \
     }
 #else
+#define SLS_MARK(kern_, k_, v_)
 #define SLS_TRACE_BEGIN()
 #define SLS_TRACE_ACTIVE(m_)
 #define SLS_TRACE_ROUND()
@@ -195,6 +201,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const BlockCone cone = make_block_cone(cam, (float)x0 + 0.5f * (float)(BW - 1), (float)y0 + 0.5f * (float)(BH - 1),
                                            0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
     const int nr = (n + 63) / 64;
+    SLS_MARK(0, 0, n);
+    SLS_MARK(0, 1, d2);
     if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     SLS_STAGE_DECL
     if (nr > 0 && !wave_done) {
@@ -213,6 +221,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
+        if (r == 0) SLS_MARK(0, 2, sp4.x);
         if (r + 1 < nr) {
             SLS_WSTAGE_LOAD_REC()
             if (r + 2 < nr) { SLS_WSTAGE_LOAD_IDX(range.x, r + 2, n) }
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         SLS_PHASE(3);
     }
 
+    SLS_MARK(0, 3, Tr);
     // combine the four slots of a pixel
     D = quad_sum(D); const float N0 = quad_sum(N01.x), N1 = quad_sum(N01.y); N2 = quad_sum(N2);
     M1 = quad_sum(M1); M2 = quad_sum(M2);
@@ -421,6 +431,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
     }
     const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
+    SLS_MARK(1, 0, tile);
     const uint2 range = ranges[tile];
     const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
     const int px = x0 + (p % BW), py = y0 + (p / BW);
@@ -467,6 +478,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor(wmax, off, 64));
     const int tmax = (int)wmax;
+    SLS_MARK(1, 1, tmax);
+    SLS_MARK(1, 2, dD + dA + dN2);
     if (tmax > 0) {
         const int nr = (tmax + 63) / 64;
         if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -481,6 +494,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         uint64_t next_mask = use_mask ? blk_mask[block_mask_index(range.x, tile, nr - 1, kPerTile, sub)] : 0ull;
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
+            if (r == nr - 1) SLS_MARK(1, 3, sp4.x);
             SLS_TRACE_ROUND();
             const uint32_t my_idx = next_idx;
             s_gidx[lane] = my_idx;
@@ -606,6 +620,10 @@ extern "C" int sls_debug_read_trace(uint32_t *host)
 extern "C" int sls_debug_read_trace_phases(uint32_t *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_phase), sizeof(g_trace_phase));
+}
+extern "C" int sls_debug_read_trace_marks(uint32_t *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_mark), sizeof(g_trace_mark));
 }
 #endif
 

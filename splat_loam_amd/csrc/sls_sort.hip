@@ -28,6 +28,7 @@
 //   * the item count is read from DEVICE memory (count_ptr), grids are sized for
 //     a host-side capacity, so a whole iteration can be enqueued without a
 //     device->host sync (sls_mapping_step).
+#include <cstdlib>
 #include "sls_common.hpp"
 #include "sls_resort.hpp"
 
@@ -109,13 +110,15 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_hist_kernel
 // Thread t owns P = ceil(nchunks / 256) CONSECUTIVE entries: one pass to sum them, one wave scan + one barrier for
 // the 256 partial sums, one pass to write the running prefix (a loop over 256-entry slabs with two barriers each
 // cost 2 us more on the 1260-chunk rows of the tile sort: the kernel is nothing but its chain of latencies).
+// nchunks_fixed > 0: the rows have that many entries (chunks of the emission, see emit_tiles_kernel)
 __global__ __launch_bounds__(256) void sort_rowscan_kernel(uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ count_ptr, uint32_t cap,
-                                                           int nchunks_cap, uint32_t *__restrict__ totals)
+                                                           int nchunks_cap, uint32_t *__restrict__ totals,
+                                                           int nchunks_fixed)
 {
     __shared__ uint32_t s_wave[4];
-    const uint32_t R = load_count(count_ptr, cap);
-    const int nchunks = (int)((R + kSortWaveItems - 1) / kSortWaveItems);
+    const uint32_t R = nchunks_fixed > 0 ? 0u : load_count(count_ptr, cap);
+    const int nchunks = nchunks_fixed > 0 ? nchunks_fixed : (int)((R + kSortWaveItems - 1) / kSortWaveItems);
     uint32_t *row = cnt + (size_t)blockIdx.x * nchunks_cap;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int P = (nchunks + 255) / 256, i0 = (int)threadIdx.x * P, i1 = min(i0 + P, nchunks);
@@ -261,6 +264,147 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
     }
 }
 
+// step 3 when the chunks are the EMISSION's (emit_tiles_kernel counted the digits of the instances each of its
+// workgroups wrote: no histogram launch): chunk c = instances [chunk_start[c], chunk_start[c + 1]), a few hundred
+// to a few thousand; one wave per chunk, 16 rounds of 64 in registers at a time.  Same positions as the pass over
+// fixed 1024-item chunks: a stable partition does not care where the chunk boundaries are.
+template <typename KeyT, int BITS>
+__global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chunks_kernel(
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ chunk_start, uint32_t cap, int shift,
+    const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ totals, int nchunks,
+    uint2 *__restrict__ ranges_out, int nranges, uint32_t packed_val_mask)
+{
+    constexpr int BINS = 1 << BITS, PER = BINS / 256;
+    constexpr int WAVES = SortBlock<BITS>::kWaves, STR = BINS + 1;
+    __shared__ uint32_t s_cursor[WAVES * STR];
+    __shared__ uint32_t s_digit_base[BINS];
+    __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk0 = blockIdx.x * WAVES, chunk = chunk0 + wave;
+    // (the chunk's bounds, its rows of the count table and the digit totals travel together; the items follow)
+    const uint32_t cs = min(chunk_start[min(chunk, nchunks)], cap), ce = min(chunk_start[min(chunk + 1, nchunks)], cap);
+    KeyT k[kSortRounds];
+    uint32_t v[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) k[r] = keys_in[min(cs + (uint32_t)(r * 64 + lane), cap - 1u)];
+    if (vals_in) {
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) v[r] = vals_in[min(cs + (uint32_t)(r * 64 + lane), cap - 1u)];
+    }
+    constexpr int CPT = BINS / 64;
+    uint32_t my_cnt[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = threadIdx.x + q * 64 * WAVES, d = idx / WAVES, w = idx % WAVES;
+        my_cnt[q] = (chunk0 + w < nchunks) ? cnt[(size_t)d * nchunks + chunk0 + w] : 0u;
+    }
+    const bool scanner = threadIdx.x < 256;
+    uint32_t tot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tot[q] = scanner ? totals[threadIdx.x * PER + q] : 0u;
+    {   // exclusive scan of the BINS digit totals (PER consecutive ones per thread, first 256 threads)
+        uint32_t loc[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { loc[q] = sum; sum += tot[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (scanner && lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        if (scanner) {
+            uint32_t wave_prefix = 0;
+            for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) s_digit_base[threadIdx.x * PER + q] = wave_prefix + incl - sum + loc[q];
+            if (ranges_out && blockIdx.x == 0) {      // the digit bases ARE the tile ranges (A5)
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int d = threadIdx.x * PER + q;
+                    const uint32_t b0 = wave_prefix + incl - sum + loc[q], c = tot[q];
+                    if (d < nranges) ranges_out[d] = c ? make_uint2(b0, b0 + c) : make_uint2(0u, 0u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = threadIdx.x + q * 64 * WAVES, d = idx / WAVES, w = idx % WAVES;
+        s_cursor[w * STR + d] = s_digit_base[d] + my_cnt[q];
+    }
+    __syncthreads();
+    if (chunk >= nchunks) return;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t b0 = cs; b0 < ce; b0 += (uint32_t)kSortWaveItems) {
+        if (b0 != cs) {     // (a chunk of more than 1024 instances: the next 16 rounds)
+#pragma unroll
+            for (int r = 0; r < kSortRounds; ++r) k[r] = keys_in[min(b0 + (uint32_t)(r * 64 + lane), cap - 1u)];
+            if (vals_in) {
+#pragma unroll
+                for (int r = 0; r < kSortRounds; ++r) v[r] = vals_in[min(b0 + (uint32_t)(r * 64 + lane), cap - 1u)];
+            }
+        }
+        if (!vals_in) {     // packed mode: the value is the low part of the key
+#pragma unroll
+            for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) {
+            const uint32_t idx = b0 + (uint32_t)(r * 64 + lane);
+            if (b0 + (uint32_t)(r * 64) >= ce) break;       // (wave-uniform)
+            const bool valid = idx < ce;
+            const uint32_t digit = (uint32_t)(k[r] >> shift) & (uint32_t)(BINS - 1);
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < BITS; ++b) {
+                const bool bit = (digit >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            const uint32_t count = (uint32_t)__popcll(peers);
+            uint32_t pos = 0;
+            if (valid) pos = s_cursor[wave * STR + digit] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                if (keys_out) keys_out[pos] = k[r];
+                vals_out[pos] = v[r];
+                if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// rows of the emission's count table + scatter over its chunks (the histogram was the emission's)
+template <int BITS>
+static int tile_sort_emit_chunks(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+                                 const uint32_t *chunk_start, uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals,
+                                 int nchunks, uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st)
+{
+    {
+        ScopedTimer tm(T_SORT_ROWSCAN, st);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, st, cnt, (const uint32_t *)nullptr, cap, nchunks,
+                           totals, nchunks);
+    }
+    SLS_LAUNCH_CHECK("sort_rowscan_kernel");
+    {
+        ScopedTimer tm(T_SORT_SCATTER, st);
+        const int nblocks = (nchunks + SortBlock<BITS>::kWaves - 1) / SortBlock<BITS>::kWaves;
+        hipLaunchKernelGGL((sort_scatter_chunks_kernel<uint32_t, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st,
+                           kin, vin, kout, vout, chunk_start, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals,
+                           nchunks, ranges_out, nranges, packed_val_mask);
+    }
+    SLS_LAUNCH_CHECK("sort_scatter_chunks_kernel");
+    return SLS_OK;
+}
+
 // ---------------------------------------------------------------------------
 size_t sort_scratch_bytes(uint64_t cap)
 {
@@ -296,7 +440,7 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
     SLS_LAUNCH_CHECK("sort_hist_kernel");
     {
         ScopedTimer tm(T_SORT_ROWSCAN, st);
-        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, st, cnt, count_ptr, cap, nchunks, totals);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(1 << BITS), dim3(256), 0, st, cnt, count_ptr, cap, nchunks, totals, 0);
     }
     SLS_LAUNCH_CHECK("sort_rowscan_kernel");
     {
@@ -529,7 +673,8 @@ __global__ __launch_bounds__(256) void gather_scan_final_kernel(int N, const uin
 // rectangle (row-major: y outer, x inner, x wrapping modulo the grid width in
 // 360-degree mode, D5/D9).  Instances beyond `cap` are dropped and flagged.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const uint32_t *__restrict__ order,
+template <int EB>
+__global__ __launch_bounds__(EB) void emit_tiles_kernel(int N, int GX, const uint32_t *__restrict__ order,
                                                          const int4 *__restrict__ rect,
                                                          const uint32_t *__restrict__ tiles,
                                                          const uint64_t *__restrict__ tile_mask,
@@ -538,10 +683,21 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
                                                          uint32_t *__restrict__ tkeys, uint32_t *__restrict__ vals,
                                                          uint32_t *__restrict__ overflow, int pack_shift,
                                                          ScanHandoff fused, uint32_t *__restrict__ total_out,
-                                                         uint32_t *__restrict__ fail_flag)
+                                                         uint32_t *__restrict__ fail_flag,
+                                                         uint32_t *__restrict__ hist_cnt, int hist_bins,
+                                                         uint32_t *__restrict__ chunk_start)
 {
+    // hist_cnt != null: the workgroup is a CHUNK of the tile sort that follows — it counts the tiles of the instances
+    // it writes (LDS) and stores column blockIdx of the count table cnt[tile][chunk] and the chunk's first instance:
+    // the sort needs no histogram launch (sort_scatter_chunks_kernel)
+    __shared__ uint32_t s_hist[kSortMaxBins];
+    if (hist_cnt) {
+        for (int d = threadIdx.x; d < hist_bins; d += EB) s_hist[d] = 0u;
+        __syncthreads();
+    }
     // pack_shift > 0 (vals == null): one word per instance, (tile << pack_shift) | surfel
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int EW = EB / 64;                // waves of the workgroup = of a chunk of EB depth positions
+    const int i = blockIdx.x * EB + threadIdx.x;
     // ONE dependent round trip per surfel: the rectangle (all zeros for a culled surfel) and the mask of its tiles
     // that the footprint can reach (D10; null: the whole rectangle) give the tile count
     // (erec: the same two things packed by preprocess into one 16-byte word)
@@ -563,12 +719,12 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
     if (fused.block_sums) {
         // level 2 of the scan of tiles_touched done here (no scan launch, no offsets array): prefix of the
         // preceding 256-blocks' sums + inclusive scan inside the block; the last block publishes R
-        __shared__ uint32_t s_wave[4];
-        __shared__ uint32_t s_pre[4];
+        __shared__ uint32_t s_wave[EW];
+        __shared__ uint32_t s_pre[EW];
         if (fused.resort_windows > 0 && blockIdx.x == 0) resort_verify(fused.resort_windows, fused.resort_edges, fail_flag);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         uint32_t pre = 0;
-        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) pre += fused.block_sums[b];
+        for (int b = threadIdx.x; b < (int)blockIdx.x * (EB / 256); b += EB) pre += fused.block_sums[b];   // (sums of 256 positions)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
         uint32_t incl = t;
@@ -582,33 +738,48 @@ __global__ __launch_bounds__(256) void emit_tiles_kernel(int N, int GX, const ui
         __syncthreads();
         uint32_t wave_prefix = 0;
         for (int w = 0; w < wave; ++w) wave_prefix += s_wave[w];
-        end = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3] + wave_prefix + incl;
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *total_out = end;
+        uint32_t block_prefix = 0;
+#pragma unroll
+        for (int w = 0; w < EW; ++w) block_prefix += s_pre[w];
+        end = block_prefix + wave_prefix + incl;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == EB - 1) *total_out = end;
     } else {
         end = (i < N) ? offsets[i] : 0u;
     }
-    if (i >= N || !t) return;
+    if (chunk_start && threadIdx.x == 0) {
+        chunk_start[blockIdx.x] = end - t;                      // (thread 0 of a launched block is a surfel: i < N)
+        if (blockIdx.x == gridDim.x - 1 && !fused.block_sums) chunk_start[gridDim.x] = offsets[N - 1];
+    }
+    if (chunk_start && fused.block_sums && blockIdx.x == gridDim.x - 1 && threadIdx.x == EB - 1) chunk_start[gridDim.x] = end;
+    bool emit = i < N && t != 0u;
     uint32_t off = end - t;
-    if (end > cap) {
+    if (emit && end > cap) {
         // The buffers are too small: flag it (the caller repeats the iteration with more room) but
         // still fill every slot below cap, so that nothing downstream reads an uninitialised entry.
         if (overflow) atomicOr(overflow, 1u);
-        if (off >= cap) return;
+        if (off >= cap) emit = false;
     }
-    uint32_t bit = 0;
-    for (int y = 0; y < rc.w; ++y) {
-        const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
-        for (int k = 0; k < rc.y; ++k, ++bit) {
-            if (bit < 64u && !((mask >> bit) & 1ull)) continue;      // the footprint cannot reach this tile
-            int tx = rc.x + k;
-            if (tx >= GX) tx -= GX;
-            if (off < cap) {
-                const uint32_t tile = row + (uint32_t)tx;
-                if (vals) { tkeys[off] = tile; vals[off] = g; }
-                else tkeys[off] = (tile << pack_shift) | g;
+    if (emit) {
+        uint32_t bit = 0;
+        for (int y = 0; y < rc.w; ++y) {
+            const uint32_t row = (uint32_t)(rc.z + y) * (uint32_t)GX;
+            for (int k = 0; k < rc.y; ++k, ++bit) {
+                if (bit < 64u && !((mask >> bit) & 1ull)) continue;      // the footprint cannot reach this tile
+                int tx = rc.x + k;
+                if (tx >= GX) tx -= GX;
+                if (off < cap) {
+                    const uint32_t tile = row + (uint32_t)tx;
+                    if (vals) { tkeys[off] = tile; vals[off] = g; }
+                    else tkeys[off] = (tile << pack_shift) | g;
+                    if (hist_cnt) atomicAdd(&s_hist[tile], 1u);
+                }
+                ++off;
             }
-            ++off;
         }
+    }
+    if (hist_cnt) {
+        __syncthreads();
+        for (int d = threadIdx.x; d < hist_bins; d += EB) hist_cnt[(size_t)d * gridDim.x + blockIdx.x] = s_hist[d];
     }
 }
 
@@ -788,17 +959,46 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     // half the traffic in emit, histogram and scatter
     const int idx_bits = bits_for((uint32_t)(N - 1)) > 0 ? bits_for((uint32_t)(N - 1)) : 1;
     const bool packed = fused_ranges && tile_bits + idx_bits <= 32;
+    // The emission's workgroups as the chunks of the (single) sort pass: they count their instances' tiles themselves,
+    // the pass is row scan + scatter — one dependent launch less (SLS_NO_EMIT_HIST=1: the three-launch pass, A/B).
+    // Needs the count table (tiles x workgroups) and the chunk starts to fit the sort's scratch.
+    static const bool no_emit_hist = getenv("SLS_NO_EMIT_HIST") != nullptr && getenv("SLS_NO_EMIT_HIST")[0] == '1';
+    // Only while the count table (tiles x chunks words, written, scanned and read back as scattered words) stays small:
+    // at 500 k surfels / 64 x 2048 its 512 x 1954 words cost 14 us more than the launch saves, and chunks of 512
+    // positions (half the table) make the scatter's waves too few and too long (+16 us); measured gains: -3.3 us per
+    // iteration at 50 k / 64 x 1024, -3.2 us at 170 k.
+    const int bins = 1 << (tile_bits < 8 ? 8 : tile_bits);
+    constexpr int eb = 256;
+    const int nemit = (N + eb - 1) / eb;
+    uint32_t *cnt = (uint32_t *)scratch, *totals = cnt + (size_t)bins * nemit, *chunk_start = totals + bins;
+    const bool emit_hist = fused_ranges && !no_emit_hist && (size_t)bins * nemit <= (size_t)400000 &&
+                           ((size_t)bins * nemit + bins + nemit + 1) * sizeof(uint32_t) <= scratch_bytes;
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
-        hipLaunchKernelGGL(emit_tiles_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, cam.GX, order,
-                           (const int4 *)rect, tiles, tile_mask, (const int4 *)erec, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow,
-                           packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,
-                           overflow);
+#define SLS_EMIT(EB_) hipLaunchKernelGGL(emit_tiles_kernel<EB_>, dim3(nemit), dim3(EB_), 0, st, N, cam.GX, order,                 \
+                           (const int4 *)rect, tiles, tile_mask, (const int4 *)erec, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow, \
+                           packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,  \
+                           overflow, emit_hist ? cnt : (uint32_t *)nullptr, bins, emit_hist ? chunk_start : (uint32_t *)nullptr)
+        SLS_EMIT(eb);
+#undef SLS_EMIT
     }
     SLS_LAUNCH_CHECK("emit_tiles_kernel");
     int which = 0;
     int rc;
-    if (packed) {
+    if (emit_hist) {
+        const uint32_t *kin = tkeys, *vin = packed ? nullptr : vals;
+        const int shift = packed ? idx_bits : 0;
+        const uint32_t pmask = packed ? ((1u << idx_bits) - 1u) : 0u;
+        switch (tile_bits < 8 ? 8 : tile_bits) {
+#define SLS_CASE(B) case B: rc = tile_sort_emit_chunks<B>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit, \
+                                                          (uint2 *)ranges, T, pmask, st); break;
+        SLS_CASE(8) SLS_CASE(9) SLS_CASE(10)
+        default: rc = tile_sort_emit_chunks<11>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit,
+                                                (uint2 *)ranges, T, pmask, st); break;
+#undef SLS_CASE
+        }
+        which = 1;
+    } else if (packed) {
         rc = radix_sort_pairs_t<uint32_t>(tkeys, nullptr, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
                                           scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits);
     } else {

@@ -1,0 +1,18 @@
+#!/bin/bash
+# visit m: dense-round forward — parity, then A/B against the window-round forward at three sizes
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -15
+ab() {  # n h w
+  for rep in 1 2; do
+    for v in 1 0; do
+      SLS_FWD_WINDOW_ROUNDS=$v timeout 200 python bench.py --no-cpu-baseline --no-extras --n $1 --height $2 --width $3 2>/dev/null | python -c "
+import json, sys
+d = json.loads(sys.stdin.read())
+print('$1 $2x$3 window_rounds=$v', d['value'], d['ms_per_step'], {k: v['avg_us'] for k, v in d['kernels'].items() if 'render' in k})"
+    done
+  done
+}
+ab 500000 64 2048
+ab 170000 64 1024
+ab 50000 64 1024

@@ -9,7 +9,8 @@ from splat_loam_amd import _abi, synth
 from splat_loam_amd.engine import MappingEngine
 from splat_loam_amd.mapping import MappingConfig
 from splat_loam_amd.scene import Camera, SurfelModel
-N, H, W = 500000, 64, 2048
+N, H, W = [int(x) for x in os.environ.get("SLS_TRACE_SHAPE", "500000,64,2048").split(",")]
+NB = (H // 16) * (W // 16) * 16          # blocks (= waves) of a tile-kernel launch, at most 8192 recorded
 sc = synth.make_scene(N, H, W, seed=0)
 depth, valid = synth.make_targets(H, W, sc)
 cam = Camera(sc["K"], depth, None, valid, None, data_device="cuda:0")
@@ -24,12 +25,12 @@ lib = _abi.lib()
 buf = (C.c_uint32 * (2 * 8192 * 4))()
 lib.sls_debug_read_trace.argtypes = [C.c_void_p]
 assert lib.sls_debug_read_trace(buf) == 0
-tr = np.frombuffer(buf, dtype=np.uint32).reshape(2, 8192, 4).astype(np.int64)
+tr = np.frombuffer(buf, dtype=np.uint32).reshape(2, 8192, 4).astype(np.int64)[:, :NB]
 if hasattr(lib, "sls_debug_read_trace_phases"):
     pb = (C.c_uint32 * (8192 * 4))()
     lib.sls_debug_read_trace_phases.argtypes = [C.c_void_p]
     if lib.sls_debug_read_trace_phases(pb) == 0:
-        ph = np.frombuffer(pb, dtype=np.uint32).reshape(8192, 4).astype(np.float64)
+        ph = np.frombuffer(pb, dtype=np.uint32).reshape(8192, 4).astype(np.float64)[:NB]
         rounds_f = (tr[0, :, 3] >> 16).astype(np.float64)
         steps_f = (tr[0, :, 3] & 0xFFFF).astype(np.float64)
         dur_f = (tr[0, :, 1] - tr[0, :, 0]) * 0.01
@@ -38,6 +39,22 @@ if hasattr(lib, "sls_debug_read_trace_phases"):
             print(f"  forward phases [{name_}: {int(sel.sum())} waves, {rounds_f[sel].sum():.0f} rounds, {steps_f[sel].sum():.0f} steps]: shader clocks per round - "
                   f"wait for the staged records + store {tot[0] / rounds_f[sel].sum():.0f}, cull + compaction {tot[1] / rounds_f[sel].sum():.0f}, "
                   f"steps {tot[2] / rounds_f[sel].sum():.0f} ({tot[2] / max(steps_f[sel].sum(), 1):.0f} per step), round end {tot[3] / rounds_f[sel].sum():.0f}")
+marks = None
+if hasattr(lib, "sls_debug_read_trace_marks"):
+    mb = (C.c_uint32 * (2 * 8192 * 4))()
+    lib.sls_debug_read_trace_marks.argtypes = [C.c_void_p]
+    if lib.sls_debug_read_trace_marks(mb) == 0:
+        marks = np.frombuffer(mb, dtype=np.uint32).reshape(2, 8192, 4).astype(np.float64)[:, :NB] * 0.01
+        names = (("list range known", "pixel rays loaded", "first records in LDS", "rounds done"),
+                 ("block known (order lookup)", "pixel state loaded (tmax)", "consumer gradient ready", "first records in LDS"))
+        for k in range(2):
+            dur_k = (tr[k, :, 1] - tr[k, :, 0]) * 0.01
+            st_k = (tr[k, :, 0] - tr[k, :, 0].min()) * 0.01
+            for nm, sel in (("all waves", dur_k > 0), ("waves started in the first 2 us", st_k < 2.0), ("waves started after 60 % of the span", st_k > 0.6 * st_k.max())):
+                if sel.sum() == 0:
+                    continue
+                print(f"  {'fwd' if k == 0 else 'bwd'} marks [{nm}: {int(sel.sum())}] us from the wave's start (median): "
+                      + ", ".join(f"{names[k][q]} {np.median(marks[k][sel, q]):.2f}" for q in range(4)) + f", end {np.median(dur_k[sel]):.2f}")
 for k, name in enumerate(("fwd", "bwd")):
     t0, t1, hw, xcc = tr[k, :, 0], tr[k, :, 1], tr[k, :, 2], 0 * tr[k, :, 3]
     rounds, steps = tr[k, :, 3] >> 16, tr[k, :, 3] & 0xFFFF
@@ -55,7 +72,7 @@ for k, name in enumerate(("fwd", "bwd")):
     simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xc = xcc & 15
     uid = (((xc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
     print(f"{name}: span {f.max():.1f} us; wave duration mean {dur.mean():.1f} p50 {np.median(dur):.1f} p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f} us; "
-          f"distinct SIMDs {len(np.unique(uid))}; waves per SIMD min/mean/max {np.bincount(np.unique(uid, return_inverse=True)[1]).min()}/{8192 / len(np.unique(uid)):.1f}/{np.bincount(np.unique(uid, return_inverse=True)[1]).max()}")
+          f"distinct SIMDs {len(np.unique(uid))}; waves per SIMD min/mean/max {np.bincount(np.unique(uid, return_inverse=True)[1]).min()}/{NB / len(np.unique(uid)):.1f}/{np.bincount(np.unique(uid, return_inverse=True)[1]).max()}")
     grid = np.arange(0, f.max(), 1.0)
     occ = [(int(((s <= t) & (f > t)).sum())) for t in grid]
     print("  resident waves every 4 us:", occ[::4])
@@ -65,8 +82,8 @@ for k, name in enumerate(("fwd", "bwd")):
     order = np.argsort(s)
     print("  per-XCD wave count", np.bincount(xc, minlength=8)[:8])
     # who makes the tail?  (block -> tile as tile_of_block does for T % 32 == 0, 16 blocks per tile)
-    b = np.arange(8192); xcd_ = b % 8; i_ = b // 8; ts = i_ // 16
-    tile = ((ts >> 2) * 8 + xcd_) * 4 + (ts & 3); row = tile // 128
+    b = np.arange(NB); xcd_ = b % 8; i_ = b // 8; ts = i_ // 16
+    tile = ((ts >> 2) * 8 + xcd_) * 4 + (ts & 3); row = tile // (W // 16)
     late = f > 0.75 * f.max()
     print("  waves alive in the last quarter: %d; their start p10/p50/p90 %.1f/%.1f/%.1f us, duration p10/p50/p90 %.1f/%.1f/%.1f us; by tile row %s"
           % (late.sum(), *np.percentile(s[late], [10, 50, 90]), *np.percentile(dur[late], [10, 50, 90]), np.bincount(row[late], minlength=4)))
@@ -86,4 +103,6 @@ for k, name in enumerate(("fwd", "bwd")):
             t = heapq.heappop(h); heapq.heappush(h, t + dur[j])
         return max(h)
     print("  list-scheduling makespan with these durations: in block order %.1f us, longest first %.1f us, ideal %.1f us"
-          % (makespan(range(8192)), makespan(np.argsort(-dur)), dur.sum() / 4096))
+          % (makespan(range(NB)), makespan(np.argsort(-dur)), dur.sum() / 4096))
+if os.environ.get("SLS_TRACE_DUMP"):
+    np.save(os.environ["SLS_TRACE_DUMP"], tr)
