@@ -33,6 +33,7 @@ __device__ uint32_t g_trace[2][8192 * 4];
 // forward: shader clocks a wave spent waiting for the staged records (+ LDS store) / in cull + compaction / in the
 // steps / at the round's end
 __device__ uint32_t g_trace_phase[8192 * 4];
+__device__ uint32_t g_trace_phase_b[8192 * 4];    // backward: wait for the staged records + store / list / steps / (unused)
 // marks: wall-clock offsets (10 ns units) from the wave's start at up to four points of its life, taken when the
 // value passed (the result of the loads the point waits for) is in a register
 __device__ uint32_t g_trace_mark[2][8192 * 4];
@@ -42,6 +43,7 @@ __device__ uint32_t g_trace_mark[2][8192 * 4];
 #define SLS_PHASE(k_) { const uint64_t now_ = clock64(); ph_acc[k_] += (uint32_t)(now_ - ph_t); ph_t = now_; }
 #define SLS_PHASE_RESET() ph_t = clock64()
 #define SLS_PHASE_END() if (threadIdx.x == 0 && blockIdx.x < 8192) { for (int k_ = 0; k_ < 4; ++k_) g_trace_phase[4 * blockIdx.x + k_] = ph_acc[k_]; }
+#define SLS_PHASE_END_B() if (threadIdx.x == 0 && blockIdx.x < 8192) { for (int k_ = 0; k_ < 4; ++k_) g_trace_phase_b[4 * blockIdx.x + k_] = ph_acc[k_]; }
 #define SLS_TRACE_BEGIN() const uint64_t trace_t0 = wall_clock64(); uint32_t trace_rounds = 0, trace_steps = 0, trace_sparse = 0
 #define SLS_TRACE_ACTIVE(m_) { const int na_ = __builtin_popcountll((m_) & 0x1111111111111111ull); trace_sparse += (na_ <= 1 ? 1u : 0u) + (na_ <= 2 ? 1u << 10 : 0u) + (na_ <= 4 ? 1u << 20 : 0u); }
 #define SLS_TRACE_ROUND() ++trace_rounds
@@ -64,6 +66,7 @@ __device__ uint32_t g_trace_mark[2][8192 * 4];
 #define SLS_PHASE(k_)
 #define SLS_PHASE_RESET()
 #define SLS_PHASE_END()
+#define SLS_PHASE_END_B()
 #endif
 
 template <int CTRL>
@@ -101,19 +104,21 @@ __device__ __forceinline__ void quad_excl_total(float x, float k1, float k2, flo
     total = dppq<0xFF>(excl + x);
 }
 
-// Forward -> backward hand-over: one 64-bit word per (tile, round of 64 list entries, block)
-// with the entries that contributed to at least one pixel of the block, so that the backward
-// evaluates exactly those (the support-box test alone lets ~40 % useless pairs through).
-// Word 0 is a tag naming the producer's block shape; a tile's rounds start at
-// (first list entry >> 6) + tile, which never collides with its neighbours' rounds.
-__host__ __device__ inline uint64_t block_mask_tag(int bw) { return 0x534C4D41534B0000ull | (uint64_t)bw; }
-__device__ __forceinline__ size_t block_mask_index(uint32_t first, int tile, int r, int per_tile, int sub)
-{
-    return 1 + ((size_t)(first >> 6) + (size_t)tile + (size_t)r) * (size_t)per_tile + (size_t)sub;
-}
+// Forward -> backward hand-over: per pixel block the COMPACT list of the tile-list entries that contributed to at
+// least one of its pixels — (list position, surfel) pairs in list order — so that the backward evaluates exactly
+// those, 64 per round (round 3: it used to be one 64-bit word per (tile, 64 list positions, block); a backward round
+// then staged 64 records for the ~12 that were marked, and its rounds — wait for the records 2000-2400 shader clocks,
+// mask + list 1000-1200, against 1600 per step — were 28 % of a wave's life at C3 and 40 % at the mapper's real
+// sizes, tools/wave_trace.py).
+// Layout in 8-byte words: [0] tag naming the producer's block shape; [1, 1 + T*8) the blocks' entry counts (u32,
+// T*16 of them); then the entries: block `sub` of a tile whose list is [first, first + n) owns
+// [first*16 + sub*n, first*16 + (sub+1)*n) — room for every entry of the tile, so 16 words per instance of capacity
+// (only what contributes is ever written or read).
+__host__ __device__ inline uint64_t block_mask_tag(int bw) { return 0x534C4C4953540000ull | (uint64_t)bw; }
+__host__ __device__ inline size_t block_list_entries_word(int T, int per_tile) { return 1 + ((size_t)T * per_tile + 1) / 2; }
 size_t block_mask_bytes(uint64_t cap, int T)
 {
-    return sizeof(uint64_t) * (1 + ((size_t)(cap >> 6) + (size_t)T + 2) * (size_t)(kTilePix / 16));
+    return sizeof(uint64_t) * (block_list_entries_word(T, kTilePix / 16) + (size_t)cap * (size_t)(kTilePix / 16));
 }
 
 // Box (pixel coordinates, centre + half extents) of the pixels whose slot-0 lane
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     __shared__ float4 s_rec[65 * kRec4];
     __shared__ uint32_t s_list[64 + 4];
     __shared__ uint32_t s_flag[65];
-    uint32_t bwd_rounds = 0, bwd_steps = 0;      // what the backward will have to do for this block (from the masks)
+    uint32_t ccnt = 0;                            // entries of this block's compact list so far
     const uint64_t t_start = DBG ? clock64() : 0;
     SLS_TRACE_BEGIN();
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
@@ -211,6 +216,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, 1, n) }
     }
     if (blk_mask && blockIdx.x == 0 && lane == 0) blk_mask[0] = block_mask_tag(BW);
+    // the compact list of this block and the surfel of list entry (r * 64 + lane), requested a round ahead
+    uint2 *const clist = blk_mask ? reinterpret_cast<uint2 *>(blk_mask + block_list_entries_word(T, kPerTile))
+                                        + ((size_t)range.x * kPerTile + (size_t)sub * (size_t)n) : nullptr;
+    uint32_t my_idx_next = (blk_mask && nr > 0 && !wave_done) ? vals[range.x + (uint32_t)min(lane, n - 1)] : 0u;
     SLS_PHASE_DECL();
     for (int r = 0; r < nr && !wave_done; ++r) {
         float bcx, bcy, bhx, bhy;
@@ -222,8 +231,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
         if (r == 0) SLS_MARK(0, 2, sp4.x);
+        const uint32_t my_idx = my_idx_next;
         if (r + 1 < nr) {
             SLS_WSTAGE_LOAD_REC()
+            if (blk_mask) my_idx_next = vals[range.x + (uint32_t)min((r + 1) * 64 + lane, n - 1)];
             if (r + 2 < nr) { SLS_WSTAGE_LOAD_IDX(range.x, r + 2, n) }
         }
         const int cnt = min(64, n - r * 64);
@@ -329,9 +340,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         SLS_PHASE(2);
         if (blk_mask) {
             __builtin_amdgcn_wave_barrier();
-            const uint64_t rmask = wave_ballot(s_flag[lane] != 0u);
-            if (lane == 0) blk_mask[block_mask_index(range.x, tile, r, kPerTile, sub)] = rmask;
-            if (rmask) { bwd_rounds = (uint32_t)(r + 1); bwd_steps += (uint32_t)(__builtin_popcountll(rmask) + 3) / 4u; }
+            const bool fl = s_flag[lane] != 0u;
+            const uint64_t rmask = wave_ballot(fl);
+            if (fl) clist[ccnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(rmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rmask, 0u))] =
+                        make_uint2((uint32_t)(r * 64 + lane), my_idx);
+            ccnt += (uint32_t)__builtin_popcountll(rmask);
         }
         SLS_PHASE(3);
     }
@@ -357,8 +370,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         pix_state[pix] = make_float4(Tr, M1, M2, 0.0f);
         pix_contrib[pix] = make_uint2(last, medc_q);
     }
-    // cost of this block in the backward, for its longest-first launch order: ~1.7 us per round, ~0.49 us per step
-    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, (7u * bwd_rounds + 2u * bwd_steps) / 4u);
+    if (blk_mask && lane == 0) reinterpret_cast<uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] = ccnt;
+    // cost of this block in the backward, for its longest-first launch order: a round of 64 entries ~1.5 steps' worth
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, (3u * ((ccnt + 63u) / 64u) + 2u * ((ccnt + 3u) / 4u)) / 4u);
     if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
         uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
 #pragma unroll
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 //            with a 64-bit integer atomic into det_acc: 39 fractional bits below the largest term, |q| < 2^40,
 //            23 bits of headroom for the sum.  preprocess_bwd scales back by 2^(biased exponent - 166).
 // Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
-template <int BW, int BH, bool LEAN, bool FUSED, int DET>
+template <int BW, int BH, bool LEAN, bool FUSED, int DET, bool DENSE>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
@@ -412,10 +426,11 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     // (record 64: all zeros, never active — pads the compacted list to a multiple of four, as in the forward)
     __shared__ float4 s_rec[65 * kRec4];
-    __shared__ uint32_t s_list[64 + 4];
+    __shared__ uint32_t s_list[64 + 4];          // culling path: the round's survivors; DENSE: its entries' list positions
     __shared__ uint32_t s_gidx[65];
-    // contribution masks of a forward with the same block shape, else cull here
-    const bool use_mask = blk_mask != nullptr && blk_mask[0] == block_mask_tag(BW);
+    // DENSE: blk_mask is the compact-list hand-over of a forward with the same block shape (the launcher checks what
+    // it can, the tag settles it: another producer's buffer is not walked)
+    if (DENSE && blk_mask[0] != block_mask_tag(BW)) return;
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
@@ -480,7 +495,136 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const int tmax = (int)wmax;
     SLS_MARK(1, 1, tmax);
     SLS_MARK(1, 2, dD + dA + dN2);
-    if (tmax > 0) {
+    float Tr = Tf, S = 0.0f;   // replicated over the quad
+    // One step: the list entries in slots j (LDS record slot of my quad lane; 64 = the empty padding record) with
+    // contributor numbers `contributor`, back to front: slot 0 of a quad holds the LAST entry of the four.
+    auto blend_step = [&](const int j, const uint32_t contributor) {
+        const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
+        const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
+        Eval e;
+        eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
+        // (bitwise: three lane masks ANDed, no short-circuit control flow in the step; the compact list holds only
+        //  entries that reached a pixel of this block, and on the culling path a step whose 64 pairs are all inactive
+        //  is rare — no dead-step test: its ballot costs more than it saves, as in the forward)
+        const bool act = inside & (contributor <= last) & !e.skip;
+        SLS_TRACE_STEP();
+        const float a = act ? e.alpha : 0.0f;          // 0: the entry passes through (1 - a = 1, w = 0)
+        const float om = 1.0f - a;
+        const float rom = __builtin_amdgcn_rcpf(om);
+        // T in front of each entry: Ti = Tr * prod_{slots <= mine} rom, multiplied up in slot order
+        // (the DPP moves must execute in all lanes: never inside a conditional expression)
+        float Ti = Tr * rom, sh;
+        sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 1 ? sh : Ti;
+        sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 2 ? sh : Ti;
+        sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 3 ? sh : Ti;
+        Tr = dppq<0xFF>(Ti);
+        const float w = a * Ti;
+        // (the depth of an evaluated pair is finite and meets w = 0 where the lane is inactive; the
+        //  distortion's 1 / depth wants a harmless value there)
+        const float dep = LEAN ? e.depth : (act ? e.depth : 1.0f);
+        float gdist = 0.0f, ddist = 0.0f;     // distortion terms of g_k and of dL/ddepth
+        if (!LEAN) {
+            const float rdep = __builtin_amdgcn_rcpf(dep);
+            const float m = mscale * (1.0f - cam.near_c * rdep);
+            const float dm_dd = mscale * cam.near_c * rdep * rdep;
+            gdist = dDist * (M2 + m * m * Af - 2.0f * m * M1);
+            ddist = dDist * 2.0f * (m * Af - M1) * dm_dd;
+        }
+        const float gk = dD * dep + (dN01.x * q2.x + dN01.y * q2.y + dN2 * q2.z) + dA + gdist;
+        float Se, St;
+        quad_excl_total(w * gk, k1, k2, k3, Se, St);
+        const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
+        S += St;
+        float dL_ddepth = w * dD;
+        if (!LEAN) {
+            dL_ddepth += w * ddist;
+            dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
+        }
+        const bool unclamped = e.og < SLS_ALPHA_MAX;
+        const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
+        const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
+        const bool a3 = act && e.use3d, a2 = act && !e.use3d;
+        const v2f dL_duv = (dL_drho * 2.0f) * e.uv;                     // dL/d(u, v)
+        const v2f dL_dhuv0 = dL_duv * e.rinv;
+        const v2f dL_dhuv = mk2(a3 ? dL_dhuv0.x : 0.0f, a3 ? dL_dhuv0.y : 0.0f);   // dL/d(hu, hv)
+        const float dL_drinv = dL_duv.x * e.huv.x + dL_duv.y * e.huv.y + dL_ddepth * q0.w;
+        const float dL_dnd = a3 ? -dL_drinv * e.rinv * e.rinv : 0.0f;
+        const float lp = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) : 0.0f;
+        // fields of the gradient record, in the order `field` names: pairs that one packed instruction makes
+        v2f gl[kGrec / 2];
+        gl[0] = dL_dhuv.x * e.dl01;                                     // fields 0, 1
+        gl[1] = dL_dhuv.y * e.dl01;                                     // fields 4, 5
+        gl[2] = dL_dhuv * e.dl2;                                        // fields 2, 6
+        gl[3] = mk2(a3 ? dL_ddepth * e.rinv : 0.0f, a2 ? dL_ddepth : 0.0f);   // fields 3, 7
+        gl[4] = w * dN01 + dL_dnd * d01;                                // fields 8, 9
+        gl[5] = mk2(w * dN2 + dL_dnd * d2, dL_do);                      // fields 10, 11
+        gl[6] = dL_dhuv;                                                // fields 12, 13
+        gl[7] = lp * e.dxy;                                             // fields 14, 15
+        const float tot = block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
+        const uint32_t gidx = s_gidx[j];
+        // (the padding entry is never active: its sums are exact zeros)
+        if (DET == 0) {
+            if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
+        } else if (DET == 1) {
+            if (tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
+        } else if (tot != 0.0f) {
+            const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
+            const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
+            atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
+        }
+    };
+    if (DENSE) {
+        // ---- rounds of 64 entries of the forward's compact list (every one of them reached a pixel of this block)
+        const int n = (int)(range.y - range.x);
+        const uint32_t cc = tmax > 0 ? reinterpret_cast<const uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] : 0u;
+        const uint2 *const clist = reinterpret_cast<const uint2 *>(blk_mask + block_list_entries_word(T, kPerTile))
+                                   + ((size_t)range.x * kPerTile + (size_t)sub * (size_t)n);
+        if (cc > 0u) {
+            const int nr = (int)((cc + 63u) / 64u);
+            if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            SLS_STAGE_DECL
+            // The round's entries are STAGED in descending list order (LDS slot j = the round's entry cnt - 1 - j): a step
+            // takes slots k .. k + 3 as they lie — no index arithmetic or padding test in the step.  Only the first
+            // round processed (the list's tail) can be short: its three slots behind the last entry are cleared.
+#define SLS_CENTRY(r_, e_) ((uint32_t)((r_) * 64 + max((int)min(64u, cc - (uint32_t)((r_) * 64)) - 1 - (e_), 0)))
+#define SLS_CIDX1(i_, r_) clist[SLS_CENTRY(r_, ((i_) * 64 + lane) / kRec4)].y
+#define SLS_CSTAGE_LOAD_IDX(r_) si0 = SLS_CIDX1(0, r_); si1 = SLS_CIDX1(1, r_); si2 = SLS_CIDX1(2, r_); si3 = SLS_CIDX1(3, r_); si4 = SLS_CIDX1(4, r_);
+            SLS_CSTAGE_LOAD_IDX(nr - 1)
+            uint2 mine_next = clist[SLS_CENTRY(nr - 1, lane)];      // (list position, surfel) of the entry in slot `lane`
+            SLS_WSTAGE_LOAD_REC()
+            if (nr > 1) { SLS_CSTAGE_LOAD_IDX(nr - 2) }
+            SLS_PHASE_DECL();
+            for (int r = nr - 1; r >= 0; --r) {
+                SLS_PHASE_RESET();
+                SLS_WSTAGE_STORE()
+                if (r == nr - 1) SLS_MARK(1, 3, sp4.x);
+                SLS_TRACE_ROUND();
+                const uint2 mine = mine_next;
+                s_gidx[lane] = mine.y;
+                s_list[lane] = mine.x + 1u;              // (the contributor numbers of the round's entries)
+                if (r > 0) {
+                    SLS_WSTAGE_LOAD_REC()
+                    mine_next = clist[SLS_CENTRY(r - 1, lane)];
+                    if (r > 1) { SLS_CSTAGE_LOAD_IDX(r - 2) }
+                }
+                const int cnt = (int)min(64u, cc - (uint32_t)(r * 64));
+                if (lane < 3 * kRec4 && cnt * kRec4 + lane < 64 * kRec4) s_rec[cnt * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // only surfels listed here can have a non-zero gradient record: preprocess_bwd reads (and clears)
+                // the records of the others not at all.  One byte store per entry; same value from every block.
+                if (touched && lane < cnt) touched[mine.y] = 1;
+                __builtin_amdgcn_wave_barrier();
+                SLS_PHASE(0);
+                SLS_PHASE(1);
+                for (int k = 0; k < cnt; k += 4) blend_step(k + slot, s_list[k + slot]);
+                SLS_PHASE(2);
+            }
+#undef SLS_CENTRY
+#undef SLS_CIDX1
+#undef SLS_CSTAGE_LOAD_IDX
+            SLS_PHASE_END_B();
+        }
+    } else if (tmax > 0) {
+        // ---- no list from a forward of this block shape: rounds of 64 consecutive list entries, culled here
         const int nr = (tmax + 63) / 64;
         if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (lane == 0) s_gidx[64] = 0u;
@@ -489,12 +633,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         SLS_WSTAGE_LOAD_REC()
         uint32_t next_idx = vals[range.x + (uint32_t)min((nr - 1) * 64 + lane, tmax - 1)];   // surfel of entry (r*64 + lane)
         if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, nr - 2, tmax) }
-        float Tr = Tf, S = 0.0f;   // replicated over the quad
-        // the round's contribution mask is requested one round ahead: a load whose result the whole round waits for
-        uint64_t next_mask = use_mask ? blk_mask[block_mask_index(range.x, tile, nr - 1, kPerTile, sub)] : 0ull;
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
-            if (r == nr - 1) SLS_MARK(1, 3, sp4.x);
             SLS_TRACE_ROUND();
             const uint32_t my_idx = next_idx;
             s_gidx[lane] = my_idx;
@@ -505,24 +645,14 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             }
             const int cnt = min(64, tmax - r * 64);
             const uint32_t c_lo = (uint32_t)(r * 64 + 1);
-            uint64_t mask;
-            if (use_mask) {
-                mask = next_mask;
-                if (r > 0) next_mask = blk_mask[block_mask_index(range.x, tile, r - 1, kPerTile, sub)];
-                if (cnt < 64) mask &= (1ull << cnt) - 1ull;
-            } else {
-                float bcx, bcy, bhx, bhy;
-                if (!block_active_box<BW, BH>(wave_ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
-                __builtin_amdgcn_wave_barrier();
-                bool pass = false;
-                if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
-                mask = wave_ballot(pass);
-            }
+            float bcx, bcy, bhx, bhy;
+            if (!block_active_box<BW, BH>(wave_ballot(inside && last >= c_lo), x0, y0, bcx, bcy, bhx, bhy)) continue;
+            __builtin_amdgcn_wave_barrier();
+            bool pass = false;
+            if (lane < cnt) pass = cull_pass(s_rec[lane * kRec4 + 4], bcx, bcy, bhx, bhy, wrapW, invW);
+            const uint64_t mask = wave_ballot(pass);
             if (mask == 0) continue;
-            const bool pass = (mask >> lane) & 1ull;
             const int npass = __builtin_popcountll(mask);
-            // only surfels marked here can have a non-zero gradient record: preprocess_bwd reads (and clears)
-            // the records of the others not at all.  One byte store per round; same value from every block.
             if (touched && pass) touched[my_idx] = 1;
             // survivors in DESCENDING list order
             if (pass) s_list[npass - 1 - (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane;
@@ -530,83 +660,11 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             __builtin_amdgcn_wave_barrier();
             for (int k = 0; k < npass; k += 4) {
                 const int j = (int)s_list[k + slot];
-                const uint32_t contributor = (uint32_t)(r * 64 + j + 1);
-                const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
-                const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
-                Eval e;
-                eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
-                // (bitwise: three lane masks ANDed, no short-circuit control flow in the step; with the forward's masks
-                //  every listed entry reached a pixel of this block, and without them a step whose 64 pairs are all
-                //  inactive is rare — no dead-step test either: its ballot costs more than it saves, as in the forward)
-                const bool act = inside & (contributor <= last) & !e.skip;
-                SLS_TRACE_STEP();
-                const float a = act ? e.alpha : 0.0f;          // 0: the entry passes through (1 - a = 1, w = 0)
-                const float om = 1.0f - a;
-                const float rom = __builtin_amdgcn_rcpf(om);
-                // T in front of each entry: Ti = Tr * prod_{slots <= mine} rom, multiplied up in slot order
-                // (the DPP moves must execute in all lanes: never inside a conditional expression)
-                float Ti = Tr * rom, sh;
-                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 1 ? sh : Ti;
-                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 2 ? sh : Ti;
-                sh = dppq<kQuadShr1>(Ti) * rom; Ti = slot >= 3 ? sh : Ti;
-                Tr = dppq<0xFF>(Ti);
-                const float w = a * Ti;
-                // (the depth of an evaluated pair is finite and meets w = 0 where the lane is inactive; the
-                //  distortion's 1 / depth wants a harmless value there)
-                const float dep = LEAN ? e.depth : (act ? e.depth : 1.0f);
-                float gdist = 0.0f, ddist = 0.0f;     // distortion terms of g_k and of dL/ddepth
-                if (!LEAN) {
-                    const float rdep = __builtin_amdgcn_rcpf(dep);
-                    const float m = mscale * (1.0f - cam.near_c * rdep);
-                    const float dm_dd = mscale * cam.near_c * rdep * rdep;
-                    gdist = dDist * (M2 + m * m * Af - 2.0f * m * M1);
-                    ddist = dDist * 2.0f * (m * Af - M1) * dm_dd;
-                }
-                const float gk = dD * dep + (dN01.x * q2.x + dN01.y * q2.y + dN2 * q2.z) + dA + gdist;
-                float Se, St;
-                quad_excl_total(w * gk, k1, k2, k3, Se, St);
-                const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
-                S += St;
-                float dL_ddepth = w * dD;
-                if (!LEAN) {
-                    dL_ddepth += w * ddist;
-                    dL_ddepth += (act && contributor == medc) ? dMed : 0.0f;
-                }
-                const bool unclamped = e.og < SLS_ALPHA_MAX;
-                const float dL_do = unclamped ? dL_dalpha * e.G : 0.0f;
-                const float dL_drho = unclamped ? -0.5f * e.G * dL_dalpha * q2.w : 0.0f;
-                const bool a3 = act && e.use3d, a2 = act && !e.use3d;
-                const v2f dL_duv = (dL_drho * 2.0f) * e.uv;                     // dL/d(u, v)
-                const v2f dL_dhuv0 = dL_duv * e.rinv;
-                const v2f dL_dhuv = mk2(a3 ? dL_dhuv0.x : 0.0f, a3 ? dL_dhuv0.y : 0.0f);   // dL/d(hu, hv)
-                const float dL_drinv = dL_duv.x * e.huv.x + dL_duv.y * e.huv.y + dL_ddepth * q0.w;
-                const float dL_dnd = a3 ? -dL_drinv * e.rinv * e.rinv : 0.0f;
-                const float lp = a2 ? -dL_drho * (2.0f * SLS_FILTER_INV_SQUARE) : 0.0f;
-                // fields of the gradient record, in the order `field` names: pairs that one packed instruction makes
-                v2f gl[kGrec / 2];
-                gl[0] = dL_dhuv.x * e.dl01;                                     // fields 0, 1
-                gl[1] = dL_dhuv.y * e.dl01;                                     // fields 4, 5
-                gl[2] = dL_dhuv * e.dl2;                                        // fields 2, 6
-                gl[3] = mk2(a3 ? dL_ddepth * e.rinv : 0.0f, a2 ? dL_ddepth : 0.0f);   // fields 3, 7
-                gl[4] = w * dN01 + dL_dnd * d01;                                // fields 8, 9
-                gl[5] = mk2(w * dN2 + dL_dnd * d2, dL_do);                      // fields 10, 11
-                gl[6] = dL_dhuv;                                                // fields 12, 13
-                gl[7] = lp * e.dxy;                                             // fields 14, 15
-                const float tot = block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
-                const uint32_t gidx = s_gidx[j];
-                // (the padding entry is never active: its sums are exact zeros)
-                if (DET == 0) {
-                    if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
-                } else if (DET == 1) {
-                    if (tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
-                } else if (tot != 0.0f) {
-                    const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
-                    const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
-                    atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
-                }
+                blend_step(j, (uint32_t)(r * 64 + j + 1));
             }
         }
     }
+
     if (dbg_cycles && lane == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
     SLS_TRACE_END(1);
 }
@@ -620,6 +678,10 @@ extern "C" int sls_debug_read_trace(uint32_t *host)
 extern "C" int sls_debug_read_trace_phases(uint32_t *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_phase), sizeof(g_trace_phase));
+}
+extern "C" int sls_debug_read_trace_phases_b(uint32_t *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_phase_b), sizeof(g_trace_phase_b));
 }
 extern "C" int sls_debug_read_trace_marks(uint32_t *host)
 {
@@ -668,11 +730,17 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
         ca = *fused_consumer;
         cblocks = ((ca.W + 63) / 64) * ((ca.H + 3) / 4);
     }
-#define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
-    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
+    // The forward's compact lists are walked if they come from a forward of THIS block shape (the variants are a
+    // process-wide debug setting: equal at this moment means equal when the forward ran, in everything but a test
+    // that switches them in between — the kernel checks the buffer's tag); otherwise the backward culls for itself.
+    const bool dense = block_masks != nullptr && debug_state().fwd_variant == debug_state().bwd_variant;
+#define SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, DENSE_)                                                        \
+    hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_, DENSE_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
                        touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order)
+#define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
+    do { if (dense) SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, true); else SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, false); } while (0)
     if (det_max) {
         // deterministic accumulation: two launches of the 8x2 kernel (maximum, then fixed-point sum)
         SLS_REQUIRE(det_acc && shape == 1, "deterministic accumulation exists for the 8x2 kernel");
@@ -685,6 +753,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
         SLS_BWD_BLOCK(8, 2, true, true, 0);
     } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, false, 0); else SLS_BWD_BLOCK(4, 4, true, false, 0); }
     else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, false, 0); else SLS_BWD_BLOCK(4, 4, false, false, 0); }
+#undef SLS_BWD_LAUNCH
 #undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");
     return SLS_OK;

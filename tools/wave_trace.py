@@ -39,6 +39,18 @@ if hasattr(lib, "sls_debug_read_trace_phases"):
             print(f"  forward phases [{name_}: {int(sel.sum())} waves, {rounds_f[sel].sum():.0f} rounds, {steps_f[sel].sum():.0f} steps]: shader clocks per round - "
                   f"wait for the staged records + store {tot[0] / rounds_f[sel].sum():.0f}, cull + compaction {tot[1] / rounds_f[sel].sum():.0f}, "
                   f"steps {tot[2] / rounds_f[sel].sum():.0f} ({tot[2] / max(steps_f[sel].sum(), 1):.0f} per step), round end {tot[3] / rounds_f[sel].sum():.0f}")
+if hasattr(lib, "sls_debug_read_trace_phases_b"):
+    pb = (C.c_uint32 * (8192 * 4))()
+    lib.sls_debug_read_trace_phases_b.argtypes = [C.c_void_p]
+    if lib.sls_debug_read_trace_phases_b(pb) == 0:
+        ph = np.frombuffer(pb, dtype=np.uint32).reshape(8192, 4).astype(np.float64)[:NB]
+        rounds_b = (tr[1, :, 3] >> 16).astype(np.float64)
+        steps_b = (tr[1, :, 3] & 0xFFFF).astype(np.float64)
+        sel = rounds_b > 0
+        tot = ph[sel].sum(0)
+        print(f"  backward phases [{int(sel.sum())} waves, {rounds_b[sel].sum():.0f} rounds, {steps_b[sel].sum():.0f} steps]: shader clocks per round - "
+              f"wait for the staged records + store {tot[0] / rounds_b[sel].sum():.0f}, mask + list {tot[1] / rounds_b[sel].sum():.0f}, "
+              f"steps {tot[2] / rounds_b[sel].sum():.0f} ({tot[2] / max(steps_b[sel].sum(), 1):.0f} per step)")
 marks = None
 if hasattr(lib, "sls_debug_read_trace_marks"):
     mb = (C.c_uint32 * (2 * 8192 * 4))()
