@@ -132,10 +132,13 @@ int sls_forward_stage1(const SlsCamera *cam, int N,
  * pix_state: H*W float4 {T_final, M1, M2, 0}; pix_contrib: H*W uint2
  * {n_contrib, median_contrib}; tile_consumed: T uint32 (list entries consumed
  * before the tile finished, the R_eff of SURVEY §8d).
- * block_masks (optional, may be null; sls_block_mask_bytes(R, H, W) bytes): forward ->
- * backward hand-over, one 64-bit word per (tile, 64 list entries, pixel block) naming the
- * entries that reached a pixel of the block; with it sls_backward evaluates exactly the
- * (block, surfel) pairs that contributed instead of re-deriving them with a box test. */
+ * block_masks (optional, may be null; sls_block_mask_bytes(R, H, W) bytes = 128 bytes per
+ * instance of capacity + a header: room for every list entry in each of a tile's 16 pixel
+ * blocks, of which only what contributes is written or read): forward -> backward hand-over,
+ * per pixel block the compact list of the (list position, surfel) pairs that reached one of
+ * its pixels; with it sls_backward walks exactly those, 64 per round, instead of re-deriving
+ * them with a box test over the tile's whole list (the name is round 2's, when the hand-over
+ * was a bit mask per 64 list entries). */
 size_t sls_sort_scratch_bytes(uint64_t R);
 size_t sls_block_mask_bytes(uint64_t R, int H, int W);
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,

@@ -371,8 +371,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         pix_contrib[pix] = make_uint2(last, medc_q);
     }
     if (blk_mask && lane == 0) reinterpret_cast<uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] = ccnt;
-    // cost of this block in the backward, for its longest-first launch order: a round of 64 entries ~1.5 steps' worth
-    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, (3u * ((ccnt + 63u) / 64u) + 2u * ((ccnt + 3u) / 4u)) / 4u);
+    // cost of this block in the backward, for its longest-first launch order: steps, a round of 64 entries ~1.3 steps' worth + its latency
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, 2u * ((ccnt + 63u) / 64u) + (ccnt + 3u) / 4u);
     if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
         uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
 #pragma unroll
