@@ -251,7 +251,9 @@ typedef struct SlsMappingConfig {
                               * (two launches: per-field maximum, then fixed-point sum scaled by it): bit-identical
                               * gradients from run to run, about one extra tile-backward per iteration.  0: float
                               * atomics, whose order — and so the last bits of the sums — changes between runs */
-    int32_t pad0;
+    int32_t block_masks;     /* the forward tile kernel's dense rounds (tile sort delivers (surfel, block mask) pairs,
+                              * DESIGN.md section 4): 0 = where the lists are long enough to pay (capacity >= 1500
+                              * instances per tile), 1 = always, 2 = never.  Same results either way. */
     uint64_t *grad_bitmap;   /* optional DEVICE buffer of sls_grad_bitmap_words(N) uint64 (apply_adam = 0, flat `grads`):
                               * bit i of word i / 64 is set iff surfel i has a non-zero gradient in this iteration
                               * (the keyframe reached it, or the scale regulariser pushes on it); the two words behind

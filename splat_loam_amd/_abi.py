@@ -37,7 +37,7 @@ class SlsMappingConfig(C.Structure):
         ("status_mirror", C.c_void_p),
         ("void_flags_out", C.c_void_p),
         ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
-        ("deterministic", C.c_int32), ("pad0", C.c_int32),
+        ("deterministic", C.c_int32), ("block_masks", C.c_int32),
         ("grad_bitmap", C.c_void_p),
     ]
 

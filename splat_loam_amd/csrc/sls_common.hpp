@@ -132,6 +132,25 @@ inline DevCam make_devcam(const SlsCamera &c)
     return d;
 }
 
+// SlsBlockBox: a surfel's support box (the record's centre + half extents, what the tile kernels' cull_pass tests) as
+// two integer ranges over the image's 8x2 pixel blocks — block columns [lo, lo + n] modulo the NC columns of the image
+// (a block column c passes cull_pass iff |8c + 3.5 - cx| <= ex + 3.5), block rows [lo, hi] (|2r + 0.5 - cy| <= ey + 0.5);
+// 0.01 pixels of slack.  Packed as two words: x = lo | (n + 1) << 16 (0: no column), y = lo | (hi + 1) << 16.
+// Written per surfel by the preprocess, read by the tile sort's scatter to give every instance the mask of the blocks
+// of its tile that the surfel can reach (sls_sort.hip: block_mask_of).
+__device__ __forceinline__ uint2 make_block_box(float cx, float cy, float ex, float ey, int NC)
+{
+    if (!(ex >= 0.0f && ey >= 0.0f)) return make_uint2(0u, 0u);            // nothing of the surfel can be seen
+    const float lo = ceilf((cx - ex - 7.01f) * 0.125f), hi = floorf((cx + ex + 0.01f) * 0.125f);
+    const int n = (int)fminf(hi - lo, (float)NC);
+    int c0 = (int)fmaxf(fminf(lo, 1.0e6f), -1.0e6f) % NC;
+    c0 += c0 < 0 ? NC : 0;
+    const int r0 = (int)fminf(fmaxf(ceilf((cy - ey - 1.01f) * 0.5f), 0.0f), 65000.0f);
+    const int r1 = (int)fminf(floorf((cy + ey + 0.01f) * 0.5f), 65000.0f);
+    if (n < 0 || r1 < r0) return make_uint2(0u, 0u);
+    return make_uint2((uint32_t)c0 | ((uint32_t)(n + 1) << 16), (uint32_t)r0 | ((uint32_t)(r1 + 1) << 16));
+}
+
 // Ballot / all over the wave straight from the condition's lane mask.  HIP's __ballot() goes through an integer
 // compare of the zero-extended predicate: where the predicate is the result of scalar mask logic the compiler
 // materialises it as 0/1 in a VGPR and compares again — two half-rate VALU instructions per ballot in the tile

@@ -17,7 +17,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr,
                           const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr,
                           int32_t *erec = nullptr, const uint32_t *resort_prev_order = nullptr,
-                          uint64_t *resort_comp = nullptr);
+                          uint64_t *resort_comp = nullptr, uint32_t *sbox = nullptr);
 uint64_t *resort_comp_buffer(int N, void *scratch);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
@@ -42,10 +42,12 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
                     uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff = nullptr,
-                    uint32_t *total_out = nullptr);
+                    uint32_t *total_out = nullptr, const uint32_t *sbox = nullptr, const uint2 **bmask_out = nullptr,
+                    int bmask_mode = 0);
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
-                      uint64_t *block_masks = nullptr, bool no_median_dist = false, uint32_t *block_cost = nullptr);
+                      uint64_t *block_masks = nullptr, bool no_median_dist = false, uint32_t *block_cost = nullptr,
+                      const uint2 *bmask = nullptr);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
@@ -67,7 +69,7 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
 // workspace of sls_mapping_step: one caller-owned buffer, carved here
 // ---------------------------------------------------------------------------
 struct MapWs {
-    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; int32_t *erec; float *depth; uint32_t *order; uint32_t *offsets;
+    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; int32_t *erec; uint32_t *sbox; float *depth; uint32_t *order; uint32_t *offsets;
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
@@ -93,6 +95,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.tiles = (uint32_t *)take(n * 4);
     w.tmask = (uint64_t *)take(n * 8);
     w.erec = (int32_t *)take(n * 16);
+    w.sbox = (uint32_t *)take(n * 8);          // SlsBlockBox per surfel (sls_common.hpp: make_block_box)
     w.depth = (float *)take(n * 4);
     w.order = (uint32_t *)take(n * 4);
     w.offsets = (uint32_t *)take(n * 4);
@@ -192,14 +195,15 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     SLS_REQUIRE(R < (1ull << 32), "more than 2^32 tile instances");
     hipStream_t st = (hipStream_t)stream;
     const DevCam dc = make_devcam(*cam);
+    const uint2 *bmask = nullptr;     // (per-instance block masks in list order: a passenger of the tile sort)
     int rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched,
                              cam->tile_cull_min != 1 ? tile_mask : nullptr, nullptr, depth, offsets, tkeys, vals,
                              tkeys_tmp, vals_tmp, sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges,
-                             keys64_out, nullptr, st);
+                             keys64_out, nullptr, st, nullptr, nullptr, nullptr, &bmask);   // (no block boxes in the staged API: bmask stays null)
     if (rc) return rc;
     const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
     return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                             tile_consumed, st, false, block_masks);
+                             tile_consumed, st, false, block_masks, false, nullptr, bmask);
 }
 
 int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
@@ -330,7 +334,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
                                    okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
                                    merged_sort ? order : nullptr,
-                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr);
+                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox);
     if (rc) return rc;
     ScanHandoff handoff = { nullptr, 0, nullptr };   // the emission finishes the scan of tiles_touched
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
@@ -338,17 +342,21 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                                  merged_sort);
     if (rc) return rc;
     int in_tmp = 0;
+    const uint2 *bmask = nullptr;
     rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
                          (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
                          w.offsets, w.tkeys, w.vals,
                          w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
-                         &status_dev->overflow, st, &handoff, &status_dev->R);
+                         &status_dev->overflow, st, &handoff, &status_dev->R,
+                         // (pairs instead of values only if both tile kernels are the default 8x2 ones: no other reads them)
+                         (debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3) ? w.sbox : nullptr, &bmask,
+                         cfg->block_masks);
     if (rc) return rc;
     const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
                            nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
                            cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
-                           w.block_cost);
+                           w.block_cost, bmask);
     if (rc) return rc;
     // ---- loss + dL/dallmap --------------------------------------------------------
     // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the

@@ -390,6 +390,302 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 }
 
 // ---------------------------------------------------------------------------
+// A6 forward, dense rounds (8x2 blocks, when the tile sort delivered the instances' block masks).  A wave of the
+// kernel above spends a third of its life on per-round overhead (wait for the 64 staged records 1230, cull +
+// compaction 780, round end 280 shader clocks, against 825 per step) and the tile's list is the TILE's: of the 64
+// entries of a round only 25-50 % can reach this block's 16 pixels at all.  Here the list is read twice: a SCAN tests
+// 256 entries per round — two coalesced loads per entry quartet: the 16-bit block masks the emission computed from
+// the surfels' support boxes and the sort carried into list order (sls_sort.hip: sort_bmask_buffers), and the
+// surfel indices — and queues the survivors; a ROUND stages, culls and blends 64 queued survivors.  Rounds per block
+// 5.3 -> 3.3 at BASELINE config 3, 14.6 -> 5.0 at 170 k surfels / 64 x 1024, 6.2 -> 2.9 at 50 k.  The first 64 entries
+// go straight into round 0, so that the first records are requested as early as before.  Everything a pixel
+// accumulates is unchanged (same entries, same order, same arithmetic: the mask is the box test the round's cull
+// repeats, with 0.001 pixels of slack) and so is the hand-over to the backward: the block's compact list.
+// (The scan was first built on gathers of the records' support boxes: 256 scattered line requests per chunk, 4300-4800
+//  clocks of waiting per round, slower than the kernel above at every size.)
+// ---------------------------------------------------------------------------
+constexpr int kScanChunk = 256;      // list entries tested per scan: four consecutive ones per lane
+constexpr int kQueueCap = 320;       // ring of survivors waiting for a round: <= 64 before a scan + 256 from it
+template <int BW, int BH, bool DBG, bool LEAN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVES, SLS_FWD_WAVES))) void render_fwd_dense_kernel(uint64_t *__restrict__ blk_mask,
+    DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
+    const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
+    float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
+    uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles, uint32_t *__restrict__ block_cost,
+    const uint2 *__restrict__ bmask)
+{
+    static_assert(BW == 8 && BH == 2 && kTileW == 16 && kTileH == 16, "the block masks name the 8x2 blocks of a 16x16 tile");
+    constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
+    __shared__ float4 s_rec[65 * kRec4];          // (record 64: all zeros, pads a round's list to a multiple of four)
+    __shared__ uint32_t s_list[64 + 4];           // (list position << 7) | slot in s_rec
+    __shared__ uint32_t s_flag[65];
+    __shared__ uint32_t s_qpos[kQueueCap], s_qidx[kQueueCap];   // queued survivors: list position, surfel
+    __shared__ uint32_t s_rpos[2][64];            // list positions of the entries of the current / the next round
+    const uint64_t t_start = DBG ? clock64() : 0;
+    SLS_TRACE_BEGIN();
+    const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
+    const int T = cam.GX * cam.GY;
+    int tile, sub;
+    tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
+    const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
+    const int px = x0 + (p % BW), py = y0 + (p / BW);
+    const bool inside = (px < cam.W) && (py < cam.H);
+    const float wrapW = cam.wrap ? (float)cam.W : 0.0f, invW = cam.wrap ? 1.0f / (float)cam.W : 0.0f;
+
+    v2f d01 = mk2(1.0f, 0.0f);
+    float d2 = 0.0f;
+    if (inside) {
+        const float2 c = col_cs[px], r = row_cs[py];
+        d01 = mk2(c.x * r.x, c.y * r.x); d2 = r.y;
+    }
+    const v2f pcr = mk2((float)px, (float)py);
+    const float mscale = cam.far_c / (cam.far_c - cam.near_c);
+    const uint32_t below = (1u << slot) - 1u, upto = (2u << slot) - 1u;   // quad bits of the earlier slots (and self)
+    const bool sge1 = slot >= 1, sge2 = slot >= 2, sge3 = slot >= 3;
+
+    // replicated over the quad: Tr, done.  Per-lane partial sums: D, N*, M1, M2.
+    float Tr = 1.0f, M1 = 0.0f, M2 = 0.0f;
+    float D = 0.0f, N2 = 0.0f, med = 0.0f;
+    v2f N01 = mk2(0.0f, 0.0f);
+    uint32_t medc = 0, last = 0, cons = 0;
+    bool done = !inside;
+    bool wave_done = wave_all(done);
+    uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0, st_slots = 0, st_geom = 0;   // diagnostics only
+    uint32_t ccnt = 0;                            // entries of this block's compact list so far
+
+    const BlockCone cone = make_block_cone(cam, (float)x0 + 0.5f * (float)(BW - 1), (float)y0 + 0.5f * (float)(BH - 1),
+                                           0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
+    if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s_rpos[0][lane] = (uint32_t)lane;
+    // scan state (wave-uniform scalars) and its two chunks in flight
+    const int n_scan = max(n - 64, 0);
+    const int nchunks = (n_scan + kScanChunk - 1) / kScanChunk;
+    int sc_c = 0, qh = 0, qn = 0;
+    // the chunk in flight: surfels and block masks of list entries 64 + 256 c + 4 lane + (0..3)
+    uint32_t ci0 = 0, ci1 = 0, ci2 = 0, ci3 = 0, cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
+#define SLS_SCAN_POS(c_, e_) (range.x + (uint32_t)min(64 + (c_) * kScanChunk + 4 * lane + (e_), n - 1))
+#define SLS_SCAN_LOAD(c_)                                                                                              \
+    { const uint2 e0_ = bmask[SLS_SCAN_POS(c_, 0)], e1_ = bmask[SLS_SCAN_POS(c_, 1)], e2_ = bmask[SLS_SCAN_POS(c_, 2)],  \
+                  e3_ = bmask[SLS_SCAN_POS(c_, 3)];                                                                    \
+      ci0 = e0_.x; cm0 = e0_.y; ci1 = e1_.x; cm1 = e1_.y; ci2 = e2_.x; cm2 = e2_.y; ci3 = e3_.x; cm3 = e3_.y; }
+    // (the list is the tile sort's (surfel, block mask) pairs: `vals` is not written in this mode)
+#define SLS_EIDX1(i_, first, r_, limit) bmask[(first) + (uint32_t)min((r_) * 64 + ((i_) * 64 + lane) / kRec4, (limit) - 1)].x
+    SLS_STAGE_DECL
+    if (n > 0 && !wave_done) {
+        si0 = SLS_EIDX1(0, range.x, 0, n); si1 = SLS_EIDX1(1, range.x, 0, n); si2 = SLS_EIDX1(2, range.x, 0, n);
+        si3 = SLS_EIDX1(3, range.x, 0, n); si4 = SLS_EIDX1(4, range.x, 0, n);
+        if (nchunks > 0) { SLS_SCAN_LOAD(0) }
+        SLS_WSTAGE_LOAD_REC()
+    }
+#undef SLS_EIDX1
+    if (blk_mask && blockIdx.x == 0 && lane == 0) blk_mask[0] = block_mask_tag(BW);
+    // the compact list of this block (the hand-over to the backward) and, for round 0, the surfels of its entries
+    uint2 *const clist = blk_mask ? reinterpret_cast<uint2 *>(blk_mask + block_list_entries_word(T, kPerTile))
+                                        + ((size_t)range.x * kPerTile + (size_t)sub * (size_t)n) : nullptr;
+    __shared__ uint32_t s_ridx[2][64];            // surfels of the entries of the current / the next round
+    if (blk_mask && n > 0 && !wave_done) s_ridx[0][lane] = bmask[range.x + (uint32_t)min(lane, n - 1)].x;
+    int cur = 0, cur_k = min(n, 64);
+    SLS_PHASE_DECL();
+    while (cur_k > 0 && !wave_done) {
+        float bcx, bcy, bhx, bhy;
+        if (!block_active_box<BW, BH>(wave_ballot(!done), x0, y0, bcx, bcy, bhx, bhy)) break;
+        SLS_PHASE_RESET();
+        SLS_TRACE_ROUND();
+        SLS_TRACE_ACTIVE(wave_ballot(!done));
+        if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
+        // single wave: LDS operations complete in program order, no barrier needed
+        SLS_WSTAGE_STORE()
+        // --- scan: top the queue up from the chunk whose support boxes arrived (requested a round ago); goes on
+        //     (waiting for its loads) only while the queue is empty
+        while (sc_c < nchunks && qn <= 64) {
+            const int p0 = 64 + sc_c * kScanChunk + 4 * lane;
+            const bool t0 = (p0 + 0 < n) && ((cm0 >> sub) & 1u), t1 = (p0 + 1 < n) && ((cm1 >> sub) & 1u);
+            const bool t2 = (p0 + 2 < n) && ((cm2 >> sub) & 1u), t3 = (p0 + 3 < n) && ((cm3 >> sub) & 1u);
+            const uint64_t b0 = wave_ballot(t0), b1 = wave_ballot(t1), b2 = wave_ballot(t2), b3 = wave_ballot(t3);
+            // list order = lane-major: the survivors of the lower lanes come first
+            uint32_t off = (uint32_t)(qh + qn);
+            off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, off));
+            off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, off));
+            off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, off));
+            off = __builtin_amdgcn_mbcnt_hi((uint32_t)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b3, off));
+#define SLS_SCAN_PUSH(t_, e_, ci_)                                                              \
+            if (t_) { const uint32_t o_ = off >= (uint32_t)kQueueCap ? off - kQueueCap : off;   \
+                      s_qpos[o_] = (uint32_t)(p0 + (e_)); s_qidx[o_] = ci_; ++off; }
+            SLS_SCAN_PUSH(t0, 0, ci0) SLS_SCAN_PUSH(t1, 1, ci1) SLS_SCAN_PUSH(t2, 2, ci2) SLS_SCAN_PUSH(t3, 3, ci3)
+#undef SLS_SCAN_PUSH
+            qn += __builtin_popcountll(b0) + __builtin_popcountll(b1) + __builtin_popcountll(b2) + __builtin_popcountll(b3);
+            ++sc_c;
+            if (sc_c < nchunks) { SLS_SCAN_LOAD(sc_c) }
+            if (qn > 0) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // --- the next round: up to 64 queued entries
+        const int nb = cur ^ 1;
+        const int nk = min(qn, 64);
+        if (nk > 0) {
+            const int qa = qh + lane, ql = qa >= kQueueCap ? qa - kQueueCap : qa;
+            if (lane < nk) { s_rpos[nb][lane] = s_qpos[ql]; if (blk_mask) s_ridx[nb][lane] = s_qidx[ql]; }
+#define SLS_QIDX(i_) s_qidx[(qh + min(((i_) * 64 + lane) / kRec4, nk - 1)) >= kQueueCap ? (qh + min(((i_) * 64 + lane) / kRec4, nk - 1)) - kQueueCap : (qh + min(((i_) * 64 + lane) / kRec4, nk - 1))]
+            si0 = SLS_QIDX(0); si1 = SLS_QIDX(1); si2 = SLS_QIDX(2); si3 = SLS_QIDX(3); si4 = SLS_QIDX(4);
+#undef SLS_QIDX
+            SLS_WSTAGE_LOAD_REC()
+            qh += nk; qh = qh >= kQueueCap ? qh - kQueueCap : qh;
+            qn -= nk;
+        }
+        const int cnt = cur_k;
+        __builtin_amdgcn_wave_barrier();
+        SLS_PHASE(0);
+        bool pass = false;
+        if (lane < cnt) {
+            const float4 c4 = s_rec[lane * kRec4 + 4];
+            pass = cull_pass(c4, bcx, bcy, bhx, bhy, wrapW, invW);
+            if (pass) {
+                const float4 c3 = s_rec[lane * kRec4 + 3];
+                pass = !cone_outside(cone, s_rec[lane * kRec4 + 0], s_rec[lane * kRec4 + 1], s_rec[lane * kRec4 + 2], c3) ||
+                       disc_reaches(c3, c4, bcx, bcy, bhx, bhy, wrapW, invW);
+            }
+        }
+        const uint64_t mask = wave_ballot(pass);
+        const int npass = __builtin_popcountll(mask);
+        if (pass) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint32_t)lane | (s_rpos[cur][lane] << 7);
+        if (lane < 3) s_list[npass + lane] = 64u;          // pad to a multiple of four with the empty record
+        __builtin_amdgcn_wave_barrier();
+        SLS_PHASE(1);
+        if (DBG) { st_staged += (uint32_t)cnt; st_pass += (uint32_t)npass; }
+        for (int k = 0; k < npass; k += 4) {
+            const uint32_t lv = s_list[k + slot];
+            const int j = (int)(lv & 127u);
+            const uint32_t contributor = (lv >> 7) + 1u;
+            const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
+            const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
+            Eval e;
+            eval_surfel(q0, q1, q2, q3, q4, d01, d2, pcr, wrapW, invW, cam.near_c, e);
+            const bool live = !done && !e.skip;
+            if (DBG) {
+                const uint64_t lb = wave_ballot(live);
+                st_steps += 1u; st_lanes += (uint32_t)__builtin_popcountll(lb);
+                const uint64_t gb = wave_ballot(inside && !e.skip);      // ignoring finished pixels
+                for (int q = 0; q < 4; ++q) {
+                    st_slots += (lb & (0x1111111111111111ull << q)) ? 1u : 0u;
+                    st_geom += (gb & (0x1111111111111111ull << q)) ? 1u : 0u;
+                }
+            }
+            SLS_TRACE_STEP();
+            // alpha of the lanes that take part (0: the entry passes through, f = 1)
+            const float a = live ? e.alpha : 0.0f;
+            const float f = 1.0f - a;
+            // transmittance in front of each slot, multiplied up in list order: E = Tr * prod_{k<slot} f_k — every lane
+            // forms the three running products (the quad's f broadcast by DPP) and picks its own
+            // (the DPP moves must execute in all lanes: never inside a conditional expression)
+            const float P1 = Tr * dppq<0x00>(f);
+            const float P2 = P1 * dppq<0x55>(f);
+            const float P3 = P2 * dppq<0xAA>(f);
+            float E = sge1 ? P1 : Tr;
+            E = sge2 ? P2 : E;
+            E = sge3 ? P3 : E;
+            const float I = E * f;
+            // the transmittance behind the four entries (a finished pixel has f = 1 in every slot: Tr stays)
+            const float I3 = dppq<0xFF>(I);
+            bool upd = live;
+            float w = a * E;
+            // T only falls along a pixel's slots and stays >= T_MIN while the pixel is alive, so some slot of a quad
+            // terminates iff the quad's last value is below the threshold: ONE compare on a VGPR feeds the ballot
+            if (wave_ballot(I3 < SLS_T_MIN)) {
+                // some pixel of the block terminates in this step (at most once per pixel): cut its quad at the
+                // first terminating slot
+                const bool term = live && (I < SLS_T_MIN);
+                const uint64_t tb = wave_ballot(term);
+                const uint32_t nib = (uint32_t)(tb >> (lane & 60)) & 15u;   // terminating slots of my pixel
+                const bool first_term = term && !(nib & below);
+                upd = live && !(nib & upto);
+                w = upd ? w : 0.0f;
+                cons = first_term ? contributor : cons;
+                const float Tt = quad_sum(first_term ? E : 0.0f);          // in front of the first terminating slot
+                Tr = nib ? Tt : I3;
+                done = done || (nib != 0u);
+                if (wave_all(done)) wave_done = true;
+            } else {
+                Tr = I3;
+            }
+            if (blk_mask && upd) s_flag[j] = 1u;   // (same value from every lane: plain LDS store)
+            // (w = 0 where the lane does not take part and the depth of an evaluated pair is finite: no select needed;
+            //  the distortion's 1 / depth below wants a harmless value there)
+            const float dep = LEAN ? e.depth : (upd ? e.depth : 1.0f);
+            D += dep * w;
+            N01 += mk2(q2.x, q2.y) * w; N2 += q2.z * w;
+            last = upd ? contributor : last;
+            if (!LEAN) {
+                // Distortion: sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) over the exclusive prefixes is the
+                // pairwise form sum_{j<i} w_i w_j (m_i - m_j)^2 = A * M2 - M1^2 of the TOTALS (A = sum w = 1 - T):
+                // only the two moments are accumulated (per lane), no prefix over the slots, no running term.
+                const float m = mscale * (1.0f - cam.near_c * __builtin_amdgcn_rcpf(dep));
+                const float mw = m * w;
+                M1 += mw;
+                M2 += m * mw;
+                const bool is_med = upd && (E > 0.5f);
+                med = is_med ? dep : med;
+                medc = is_med ? contributor : medc;
+            }
+            if (wave_done) break;
+        }
+        SLS_PHASE(2);
+        if (blk_mask) {
+            __builtin_amdgcn_wave_barrier();
+            const bool fl = lane < cnt && s_flag[lane] != 0u;
+            const uint64_t rmask = wave_ballot(fl);
+            if (fl) clist[ccnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(rmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rmask, 0u))] =
+                        make_uint2(s_rpos[cur][lane], s_ridx[cur][lane]);
+            ccnt += (uint32_t)__builtin_popcountll(rmask);
+        }
+        cur = nb; cur_k = nk;
+        SLS_PHASE(3);
+    }
+#undef SLS_SCAN_POS
+#undef SLS_SCAN_LOAD
+
+    // combine the four slots of a pixel
+    D = quad_sum(D); const float N0 = quad_sum(N01.x), N1 = quad_sum(N01.y); N2 = quad_sum(N2);
+    M1 = quad_sum(M1); M2 = quad_sum(M2);
+    const float dist = (1.0f - Tr) * M2 - M1 * M1;
+    last = quad_max(last);
+    const uint32_t medc_q = quad_max(medc);
+    med = quad_sum((medc == medc_q && medc != 0u) ? med : 0.0f);
+    if (inside && slot == 0) {
+        const size_t P = (size_t)cam.H * cam.W;
+        const size_t pix = (size_t)py * cam.W + px;
+        allmap[SLS_CH_DEPTH * P + pix] = D;
+        allmap[SLS_CH_ALPHA * P + pix] = 1.0f - Tr;
+        allmap[(SLS_CH_NORMAL + 0) * P + pix] = N0;
+        allmap[(SLS_CH_NORMAL + 1) * P + pix] = N1;
+        allmap[(SLS_CH_NORMAL + 2) * P + pix] = N2;
+        allmap[SLS_CH_MEDIAN * P + pix] = med;
+        allmap[SLS_CH_DIST * P + pix] = dist;
+        pix_state[pix] = make_float4(Tr, M1, M2, 0.0f);
+        pix_contrib[pix] = make_uint2(last, medc_q);
+    }
+    if (blk_mask && lane == 0) reinterpret_cast<uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] = ccnt;
+    // cost of this block in the backward, for its longest-first launch order: steps, a round of 64 entries ~1.3 steps' worth + its latency
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, 2u * ((ccnt + 63u) / 64u) + (ccnt + 3u) / 4u);
+    if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
+        uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c = max(c, (uint32_t)__shfl_down(c, off, 64));
+        if (lane == 0) atomicMax(&tile_consumed[tile], c);
+    }
+    SLS_TRACE_END(0);
+    SLS_PHASE_END();
+    if (DBG && lane == 0) {
+        dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
+        uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
+        atomicAdd(&st[0], st_staged); atomicAdd(&st[1], st_pass);
+        atomicAdd(&st[2], st_steps); atomicAdd(&st[3], st_lanes); atomicAdd(&st[4], st_slots); atomicAdd(&st[5], st_geom);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // A7 backward.  Back to front, four list entries per step: slot 0 holds the
 // LAST entry of the four.  T_i = T_{i+1} / (1 - alpha_i) is multiplied up in
 // that order inside the quad, S (the suffix sum of w g) is an exclusive quad
@@ -692,21 +988,28 @@ extern "C" int sls_debug_read_trace_marks(uint32_t *host)
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean, uint32_t *block_cost)
+                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
     uint32_t *const g_dbg_fwd_cycles = debug_state().dbg_fwd_cycles;
     SLS_REQUIRE(shape == 0 || shape == 1, "tile-kernel variant must be 2 (4x4 blocks) or 3 (8x2 blocks)");
-#define SLS_FWD_BLOCK(BW_, BH_, DBG_, LEAN_)                                                                      \
-    hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_, LEAN_>), grid, block, 0, st, block_masks, cam,   \
-                       (const uint2 *)ranges, vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs, allmap,          \
-                       (float4 *)pix_state, (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles, block_cost)
+#define SLS_FWD_ARGS grid, block, 0, st, block_masks, cam, (const uint2 *)ranges, vals, (const float4 *)rec,     \
+                     (const float2 *)col_cs, (const float2 *)row_cs, allmap, (float4 *)pix_state,                \
+                     (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles, block_cost
+#define SLS_FWD_BLOCK(BW_, BH_, DBG_, LEAN_) hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_, LEAN_>), SLS_FWD_ARGS)
+#define SLS_FWD_DENSE(DBG_, LEAN_) hipLaunchKernelGGL((render_fwd_dense_kernel<8, 2, DBG_, LEAN_>), SLS_FWD_ARGS, bmask)
+    // the instances' block masks in list order (a passenger of the tile sort): dense rounds, 8x2 blocks only
+    if (bmask && shape == 1) {
+        if (g_dbg_fwd_cycles) SLS_FWD_DENSE(true, false); else if (lean) SLS_FWD_DENSE(false, true); else SLS_FWD_DENSE(false, false);
+    } else
     if (g_dbg_fwd_cycles) { if (shape == 1) SLS_FWD_BLOCK(8, 2, true, false); else SLS_FWD_BLOCK(4, 4, true, false); }
     else if (lean) { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, true); else SLS_FWD_BLOCK(4, 4, false, true); }
     else { if (shape == 1) SLS_FWD_BLOCK(8, 2, false, false); else SLS_FWD_BLOCK(4, 4, false, false); }
 #undef SLS_FWD_BLOCK
+#undef SLS_FWD_DENSE
+#undef SLS_FWD_ARGS
     SLS_LAUNCH_CHECK("render_fwd_block_kernel");
     return SLS_OK;
 }

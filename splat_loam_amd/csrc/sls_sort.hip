@@ -64,6 +64,32 @@ struct ScanHandoff {
 };
 __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restrict__ edges, uint32_t *__restrict__ flag);
 
+// The tile sort's list with block masks (launch_bin_sort, the mapping iteration): per instance, in list order, the
+// pair (surfel, mask of the sixteen 8x2 pixel blocks of its tile that the surfel's support box can reach) INSTEAD of
+// the bare surfel index.  The scatter has every instance's tile and surfel in registers: it fetches the surfel's box
+// as two integer ranges (sls_common.hpp: make_block_box, 8 bytes per surfel, written by the preprocess) and stores
+// the pair with the ONE scattered store it would spend on the value anyway.  The forward tile kernel reads the masks
+// instead of the records to decide what to stage (render_fwd_dense_kernel).  (Measured on the way: masks computed in
+// the emission from the records' support boxes — a gather from the 40 MB record array — +12...17 us there at 500 k
+// surfels and +4.7 us in the scatter that carried them; masks computed here but stored as a second, 2-byte array:
+// +8.1 us in the scatter at 500 k, +4.5 us at 50 k — a scattered store instruction costs what it costs, whatever its
+// width.)
+struct BlockMaskArgs { const uint2 *sbox; uint2 *out; int GX; float invGX; int NC; uint32_t n_surfels; };
+// bit 2*by + bx of the mask of an instance of `tile`; box = the surfel's block box
+__device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32_t tile, uint2 box)
+{
+    const int ty = (int)(((float)tile + 0.5f) * a.invGX), tx = (int)tile - ty * a.GX;
+    const int bc_lo = (int)(box.x & 0xFFFFu), bc_n = (int)(box.x >> 16) - 1;         // columns [bc_lo, bc_lo + bc_n] mod NC
+    const int br_lo = (int)(box.y & 0xFFFFu), br_hi = (int)(box.y >> 16) - 1;        // rows [br_lo, br_hi]
+    const int r0 = max(br_lo - ty * (kTileH / 2), 0), r1 = min(br_hi - ty * (kTileH / 2), kTileH / 2 - 1);
+    const uint32_t ym = r0 <= r1 ? (((4u << (2 * r1)) - 1u) & ~((1u << (2 * r0)) - 1u)) : 0u;
+    int d0 = 2 * tx - bc_lo;
+    d0 += d0 < 0 ? a.NC : 0;
+    const int d1 = d0 + 1 >= a.NC ? d0 + 1 - a.NC : d0 + 1;
+    const uint32_t xm = (d0 <= bc_n ? 0x5555u : 0u) | (d1 <= bc_n ? 0xAAAAu : 0u);
+    return ym & xm;
+}
+
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
@@ -157,7 +183,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
                                                            int shift, const uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ totals, int nchunks_cap,
                                                            uint2 *__restrict__ ranges_out, int nranges,
-                                                           uint32_t packed_val_mask)
+                                                           uint32_t packed_val_mask, BlockMaskArgs bm)
 {
     constexpr int BINS = 1 << BITS, PER = BINS / 256;   // digit totals handled per thread (of the first 256)
     constexpr int WAVES = SortBlock<BITS>::kWaves, STR = BINS + 1;
@@ -183,6 +209,11 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
     } else {   // packed mode: the value is the low part of the key
 #pragma unroll
         for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
+    }
+    uint2 box[kSortRounds];                    // (tile sort with block masks: the surfels' block boxes, one gather each)
+    if (bm.out) {
+#pragma unroll
+        for (int r = 0; r < kSortRounds; ++r) box[r] = bm.sbox[min(v[r], bm.n_surfels - 1u)];    // (clamped: slots beyond R hold anything)
     }
     constexpr int CPT = BINS / 64;             // count-table entries per thread: BINS * WAVES / (64 * WAVES)
     uint32_t my_cnt[CPT];
@@ -257,7 +288,8 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             if (keys_out) keys_out[pos] = k[r];     // (a caller that only wants the permutation passes null in the last pass)
-            vals_out[pos] = v[r];
+            if (bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, box[r]));
+            else vals_out[pos] = v[r];
             if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
         }
         __builtin_amdgcn_wave_barrier();
@@ -273,7 +305,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
     const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, KeyT *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ chunk_start, uint32_t cap, int shift,
     const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ totals, int nchunks,
-    uint2 *__restrict__ ranges_out, int nranges, uint32_t packed_val_mask)
+    uint2 *__restrict__ ranges_out, int nranges, uint32_t packed_val_mask, BlockMaskArgs bm)
 {
     constexpr int BINS = 1 << BITS, PER = BINS / 256;
     constexpr int WAVES = SortBlock<BITS>::kWaves, STR = BINS + 1;
@@ -353,6 +385,11 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
 #pragma unroll
             for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
         }
+        uint2 box[kSortRounds];                // (block masks: the surfels' block boxes, one gather each)
+        if (bm.out) {
+#pragma unroll
+            for (int r = 0; r < kSortRounds; ++r) box[r] = bm.sbox[min(v[r], bm.n_surfels - 1u)];
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < kSortRounds; ++r) {
@@ -374,7 +411,8 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
             __builtin_amdgcn_wave_barrier();
             if (valid) {
                 if (keys_out) keys_out[pos] = k[r];
-                vals_out[pos] = v[r];
+                if (bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, box[r]));
+                else vals_out[pos] = v[r];
                 if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
             }
             __builtin_amdgcn_wave_barrier();
@@ -386,7 +424,8 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
 template <int BITS>
 static int tile_sort_emit_chunks(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout,
                                  const uint32_t *chunk_start, uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals,
-                                 int nchunks, uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st)
+                                 int nchunks, uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st,
+                                 const BlockMaskArgs &bm)
 {
     {
         ScopedTimer tm(T_SORT_ROWSCAN, st);
@@ -399,17 +438,26 @@ static int tile_sort_emit_chunks(const uint32_t *kin, const uint32_t *vin, uint3
         const int nblocks = (nchunks + SortBlock<BITS>::kWaves - 1) / SortBlock<BITS>::kWaves;
         hipLaunchKernelGGL((sort_scatter_chunks_kernel<uint32_t, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st,
                            kin, vin, kout, vout, chunk_start, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals,
-                           nchunks, ranges_out, nranges, packed_val_mask);
+                           nchunks, ranges_out, nranges, packed_val_mask, bm);
     }
     SLS_LAUNCH_CHECK("sort_scatter_chunks_kernel");
     return SLS_OK;
 }
 
 // ---------------------------------------------------------------------------
-size_t sort_scratch_bytes(uint64_t cap)
+static size_t sort_core_bytes(uint64_t cap)
 {
     const uint64_t nchunks = (cap + kSortWaveItems - 1) / kSortWaveItems;
     return (size_t)(kSortMaxBins * (nchunks ? nchunks : 1) + kSortMaxBins) * sizeof(uint32_t);
+}
+// (count table + digit totals, and behind them the list of (surfel, block mask) pairs: sort_bmask_buffer)
+size_t sort_scratch_bytes(uint64_t cap)
+{
+    return sort_core_bytes(cap) + sizeof(uint2) * (size_t)cap + 64;
+}
+uint2 *sort_bmask_buffer(void *scratch, uint64_t cap)
+{
+    return (uint2 *)((char *)scratch + ((sort_core_bytes(cap) + 15) & ~(size_t)15));
 }
 
 // digit width: as few passes as 11-bit digits allow, then the narrowest digit that still fits
@@ -429,7 +477,8 @@ int sort_passes(int nbits)
 template <typename KeyT, int BITS>
 static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout, const uint32_t *count_ptr,
                       uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals, int nchunks, int /*unused*/,
-                      uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st)
+                      uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st,
+                      const BlockMaskArgs &bm)
 {
     const int nblocks = (nchunks + SortBlock<BITS>::kWaves - 1) / SortBlock<BITS>::kWaves;
     {
@@ -447,7 +496,7 @@ static int radix_pass(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t
         ScopedTimer tm(T_SORT_SCATTER, st);
         hipLaunchKernelGGL((sort_scatter_kernel<KeyT, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st, kin, vin, kout, vout,
                            count_ptr, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals, nchunks, ranges_out,
-                           nranges, packed_val_mask);
+                           nranges, packed_val_mask, bm);
     }
     SLS_LAUNCH_CHECK("sort_scatter_kernel");
     return SLS_OK;
@@ -466,7 +515,7 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
                               const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
                               size_t scratch_bytes, int *result_in_tmp, hipStream_t st,
                               uint2 *ranges_out = nullptr, int nranges = 0, bool drop_sorted_keys = false,
-                              int base_shift = 0)
+                              int base_shift = 0, BlockMaskArgs bm = BlockMaskArgs{ nullptr, nullptr, 1, 1.0f, 1, 1u })
 {
     *result_in_tmp = 0;
     if (cap == 0 || nbits <= 0) return SLS_OK;
@@ -493,7 +542,8 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         int rc;
         KeyT *kout = (drop_sorted_keys && p + 1 == npasses) ? nullptr : kb[dst];
 #define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kout, vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
-                                        0, ranges_out, nranges, packed_val_mask, st)
+                                        0, ranges_out, nranges, packed_val_mask, st,                           \
+                                        (npasses == 1 ? bm : BlockMaskArgs{ nullptr, nullptr, 1, 1.0f, 1, 1u }))
         switch (bits) {
         case 8: rc = SLS_PASS(8); break;
         case 9: rc = SLS_PASS(9); break;
@@ -939,10 +989,15 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                     const float *depth, const uint32_t *offsets,
                     uint32_t *tkeys, uint32_t *vals, uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *scratch,
                     size_t scratch_bytes, int *sorted_in_tmp, uint32_t *ranges, uint64_t *keys64_out,
-                    uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff, uint32_t *total_out)
+                    uint32_t *overflow, hipStream_t st, const ScanHandoff *handoff, uint32_t *total_out,
+                    const uint32_t *sbox, const uint2 **bmask_out, int bmask_mode)
 {
+    // sbox + bmask_out (optional): the sorted list comes out as (surfel, mask of reachable 8x2 pixel blocks) pairs in
+    // *bmask_out (sort_bmask_buffer) and the plain value arrays are NOT written; *bmask_out stays null — and the values
+    // are written as ever — where that is not possible (more than one sort pass, other tile sizes, switched off)
     const int T = cam.GX * cam.GY;
     *sorted_in_tmp = 0;
+    if (bmask_out) *bmask_out = nullptr;
     if (cap == 0 || N == 0) {
         SLS_HIP_CHECK(hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T, st));
         return SLS_OK;
@@ -972,7 +1027,20 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     const int nemit = (N + eb - 1) / eb;
     uint32_t *cnt = (uint32_t *)scratch, *totals = cnt + (size_t)bins * nemit, *chunk_start = totals + bins;
     const bool emit_hist = fused_ranges && !no_emit_hist && (size_t)bins * nemit <= (size_t)400000 &&
-                           ((size_t)bins * nemit + bins + nemit + 1) * sizeof(uint32_t) <= scratch_bytes;
+                           ((size_t)bins * nemit + bins + nemit + 1) * sizeof(uint32_t) <= sort_core_bytes(cap);
+    // SLS_NO_BLOCK_MASKS=1: no block masks, the forward walks the tiles' lists in rounds of 64 entries (A/B switch)
+    static const bool no_bmask = getenv("SLS_NO_BLOCK_MASKS") != nullptr && getenv("SLS_NO_BLOCK_MASKS")[0] == '1';
+    BlockMaskArgs bm = { nullptr, nullptr, cam.GX, 1.0f / (float)cam.GX, (cam.GX * kTileW) / 8, (uint32_t)N };
+    // ... and only where the tiles' lists are long enough for the forward to gain more than the scatter pays (its extra
+    // gather is a round trip in a chain of latencies: +3.2 us at 50 k surfels / 64 x 1024 for -3.8 us in the forward;
+    // +4.0 / -14.0 us at 170 k, +6.3 / -16.2 us at 500 k / 64 x 2048): capacity per tile as the host-side proxy
+    // (bmask_mode = SlsMappingConfig.block_masks: 0 auto, 1 always, 2 never)
+    const bool long_lists = bmask_mode == 1 || (bmask_mode == 0 && (uint64_t)cap >= 1500ull * (uint64_t)T);
+    if (sbox && bmask_out && fused_ranges && !no_bmask && kTileW == 16 && kTileH == 16 && long_lists) {
+        bm.sbox = (const uint2 *)sbox;
+        bm.out = sort_bmask_buffer(scratch, cap);
+        *bmask_out = bm.out;
+    }
     {
         ScopedTimer tm(T_EMIT_KEYS, st);
 #define SLS_EMIT(EB_) hipLaunchKernelGGL(emit_tiles_kernel<EB_>, dim3(nemit), dim3(EB_), 0, st, N, cam.GX, order,                 \
@@ -991,20 +1059,20 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
         const uint32_t pmask = packed ? ((1u << idx_bits) - 1u) : 0u;
         switch (tile_bits < 8 ? 8 : tile_bits) {
 #define SLS_CASE(B) case B: rc = tile_sort_emit_chunks<B>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit, \
-                                                          (uint2 *)ranges, T, pmask, st); break;
+                                                          (uint2 *)ranges, T, pmask, st, bm); break;
         SLS_CASE(8) SLS_CASE(9) SLS_CASE(10)
         default: rc = tile_sort_emit_chunks<11>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit,
-                                                (uint2 *)ranges, T, pmask, st); break;
+                                                (uint2 *)ranges, T, pmask, st, bm); break;
 #undef SLS_CASE
         }
         which = 1;
     } else if (packed) {
         rc = radix_sort_pairs_t<uint32_t>(tkeys, nullptr, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
-                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits);
+                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits, bm);
     } else {
         rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
                                           scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T,
-                                          fused_ranges);   // nobody reads the sorted tile ids then
+                                          fused_ranges, 0, bm);   // nobody reads the sorted tile ids then
     }
     if (rc) return rc;
     *sorted_in_tmp = which;

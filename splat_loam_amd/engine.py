@@ -145,6 +145,7 @@ class MappingEngine:
         self._dp_agreed, self._dp_use_rs = None, False    # (G, rank) the scheme was agreed for; the agreed verdict
         from .rasterizer import deterministic_mode
         self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
+        self.block_masks = int(os.environ.get("SLS_BLOCK_MASKS", "0"))   # 0: auto (long lists), 1: always, 2: never (SlsMappingConfig.block_masks)
         self._sx = None                   # sparse exchange: dict(bitmap, prefix, compact, cap, send) once set up
         self.exchanged_bytes = 0          # bytes this rank handed to collectives in the last keyframe-parallel step
         self.exchange_at_world_1 = False  # take the keyframe-parallel path (collectives + separate Adam) in a 1-rank group too
@@ -192,6 +193,7 @@ class MappingEngine:
         if self._dp is not None and not apply_adam:
             c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
         c.deterministic = 1 if self.deterministic else 0
+        c.block_masks = int(self.block_masks)
         if self._sx is not None and not apply_adam:
             c.grad_bitmap = self._sx["mine"].data_ptr()
         return c

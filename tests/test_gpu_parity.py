@@ -367,7 +367,12 @@ def test_full_size_properties(device):
     st2 = rasterize_forward(s2, t["means"], t["opac"], t["scales"], t["rots"])
     assert st2.R == st.R and np.array_equal(u32(st2.vals), vals), "fused-ranges path: same sorted list"
     assert np.array_equal(u32(st2.ranges).reshape(-1, 2), rng), "fused-ranges path: same ranges"
-    assert torch.equal(st2.allmap, st.allmap)
+    # (the two paths may run different forward kernels — dense rounds from the tile sort's block masks in the production
+    #  path, rounds of 64 list entries where the 64-bit keys were asked for: same entries in the same order, but a
+    #  pixel's four partial sums are split differently over the steps)
+    scale = st.allmap.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-12)
+    assert ((st2.allmap - st.allmap).abs() / scale).max().item() <= 2e-6
+    assert torch.equal(st2.pix_contrib, st.pix_contrib)
     am = st.allmap.cpu().numpy()
     assert np.isfinite(am).all()
     assert am[1].min() >= 0.0 and am[1].max() <= 1.0, "alpha in [0,1] (fed to BCE, slam/mapper.py:182)"
