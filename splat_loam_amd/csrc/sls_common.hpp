@@ -132,23 +132,25 @@ inline DevCam make_devcam(const SlsCamera &c)
     return d;
 }
 
-// SlsBlockBox: a surfel's support box (the record's centre + half extents, what the tile kernels' cull_pass tests) as
-// two integer ranges over the image's 8x2 pixel blocks — block columns [lo, lo + n] modulo the NC columns of the image
-// (a block column c passes cull_pass iff |8c + 3.5 - cx| <= ex + 3.5), block rows [lo, hi] (|2r + 0.5 - cy| <= ey + 0.5);
-// 0.01 pixels of slack.  Packed as two words: x = lo | (n + 1) << 16 (0: no column), y = lo | (hi + 1) << 16.
-// Written per surfel by the preprocess, read by the tile sort's scatter to give every instance the mask of the blocks
-// of its tile that the surfel can reach (sls_sort.hip: block_mask_of).
-__device__ __forceinline__ uint2 make_block_box(float cx, float cy, float ex, float ey, int NC)
+// Block box: a surfel's support box (the record's centre + half extents, what the tile kernels' cull_pass tests) as two
+// integer ranges over the image's 8x2 pixel blocks — block columns [lo, lo + n] modulo the NC columns of the image (a
+// block column c passes cull_pass iff |8c + 3.5 - cx| <= ex + 3.5), block rows [lo, hi] (|2r + 0.5 - cy| <= ey + 0.5);
+// 0.01 pixels of slack.  ONE word: column lo (9 bits) | n + 1 (10 bits, 0: nothing) | row lo (6 bits) | hi + 1 (7 bits)
+// — images up to 4096 x 128 (block_box_fits).  Written per surfel by the preprocess; the emission puts it into the
+// upper half of every instance word, the tile sort's scatter turns it into the mask of the blocks of the instance's
+// tile that the surfel can reach (sls_sort.hip: block_mask_of).
+__host__ __device__ inline bool block_box_fits(int W, int H) { return W <= 4096 && H <= 128; }
+__device__ __forceinline__ uint32_t make_block_box(float cx, float cy, float ex, float ey, int NC)
 {
-    if (!(ex >= 0.0f && ey >= 0.0f)) return make_uint2(0u, 0u);            // nothing of the surfel can be seen
+    if (!(ex >= 0.0f && ey >= 0.0f)) return 0u;                            // nothing of the surfel can be seen
     const float lo = ceilf((cx - ex - 7.01f) * 0.125f), hi = floorf((cx + ex + 0.01f) * 0.125f);
-    const int n = (int)fminf(hi - lo, (float)NC);
+    const int n = (int)fminf(hi - lo, (float)(NC - 1));                    // (NC - 1: every column)
     int c0 = (int)fmaxf(fminf(lo, 1.0e6f), -1.0e6f) % NC;
     c0 += c0 < 0 ? NC : 0;
-    const int r0 = (int)fminf(fmaxf(ceilf((cy - ey - 1.01f) * 0.5f), 0.0f), 65000.0f);
-    const int r1 = (int)fminf(floorf((cy + ey + 0.01f) * 0.5f), 65000.0f);
-    if (n < 0 || r1 < r0) return make_uint2(0u, 0u);
-    return make_uint2((uint32_t)c0 | ((uint32_t)(n + 1) << 16), (uint32_t)r0 | ((uint32_t)(r1 + 1) << 16));
+    const int r0 = (int)fminf(fmaxf(ceilf((cy - ey - 1.01f) * 0.5f), 0.0f), 63.0f);
+    const int r1 = (int)fminf(floorf((cy + ey + 0.01f) * 0.5f), 63.0f);
+    if (n < 0 || r1 < r0) return 0u;
+    return (uint32_t)c0 | ((uint32_t)(n + 1) << 9) | ((uint32_t)r0 << 19) | ((uint32_t)(r1 + 1) << 25);
 }
 
 // Ballot / all over the wave straight from the condition's lane mask.  HIP's __ballot() goes through an integer

@@ -95,7 +95,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.tiles = (uint32_t *)take(n * 4);
     w.tmask = (uint64_t *)take(n * 8);
     w.erec = (int32_t *)take(n * 16);
-    w.sbox = (uint32_t *)take(n * 8);          // SlsBlockBox per surfel (sls_common.hpp: make_block_box)
+    w.sbox = (uint32_t *)take(n * 4);          // block box per surfel (sls_common.hpp: make_block_box)
     w.depth = (float *)take(n * 4);
     w.order = (uint32_t *)take(n * 4);
     w.offsets = (uint32_t *)take(n * 4);

@@ -182,7 +182,7 @@ struct PreFwdArgs {
     const float *means; const float2 *scales; const float4 *rots; const float *opac;
     float4 *rec; int *radii; int4 *rect; uint32_t *tiles; float *depth; uint32_t *order_keys, *order_vals, *n_dev;
     const float2 *col_cs, *row_cs; uint64_t *tile_mask; int4 *erec;
-    uint2 *sbox;      // optional: the surfels' block boxes (make_block_box) for the tile sort's block masks
+    uint32_t *sbox;   // optional: the surfels' block boxes (make_block_box) for the tile sort's block masks
 };
 constexpr int kPreCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
 constexpr int kPreSliceBytes = kPreCullBytes > 64 * kRec4 * 16 ? kPreCullBytes : 64 * kRec4 * 16;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
     }
     if (i < N) {
         tiles[i] = my_tiles;
-        if (pa.sbox) pa.sbox[i] = my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : make_uint2(0u, 0u);
+        if (pa.sbox) pa.sbox[i] = my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u;
         if (tile_mask) tile_mask[i] = my_mask;
         // what the emission reads, in ONE 16-byte gather: the rectangle (16-bit fields) and the mask
         if (erec) erec[i] = make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
@@ -684,7 +684,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
     pa.col_cs = (const float2 *)col_cs; pa.row_cs = (const float2 *)row_cs;
     pa.tile_mask = (col_cs && row_cs) ? tile_mask : nullptr;
     pa.erec = (cam.GX < 65536 && cam.GY < 65536) ? (int4 *)erec : nullptr;
-    pa.sbox = (cam.GX * kTileW) / 8 < 65536 && cam.H < 65536 ? (uint2 *)sbox : nullptr;
+    pa.sbox = block_box_fits(cam.GX * kTileW, cam.H) ? sbox : nullptr;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
     if (resort_prev_order && resort_comp) {
         // merged with the repair's window sort (which overwrites the sort's identity permutation: not written here)

@@ -66,21 +66,23 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
 
 // The tile sort's list with block masks (launch_bin_sort, the mapping iteration): per instance, in list order, the
 // pair (surfel, mask of the sixteen 8x2 pixel blocks of its tile that the surfel's support box can reach) INSTEAD of
-// the bare surfel index.  The scatter has every instance's tile and surfel in registers: it fetches the surfel's box
-// as two integer ranges (sls_common.hpp: make_block_box, 8 bytes per surfel, written by the preprocess) and stores
-// the pair with the ONE scattered store it would spend on the value anyway.  The forward tile kernel reads the masks
+// the bare surfel index.  An instance is then a 64-bit word: the packed (tile, surfel) word below, the surfel's block
+// box (sls_common.hpp: make_block_box, one word per surfel from the preprocess, fetched by the emission with the
+// gather it makes anyway) above; the pass sorts on the same digit, and the scatter — tile and box in registers —
+// stores the pair with the ONE scattered store it would spend on the value.  The forward tile kernel reads the masks
 // instead of the records to decide what to stage (render_fwd_dense_kernel).  (Measured on the way: masks computed in
 // the emission from the records' support boxes — a gather from the 40 MB record array — +12...17 us there at 500 k
-// surfels and +4.7 us in the scatter that carried them; masks computed here but stored as a second, 2-byte array:
-// +8.1 us in the scatter at 500 k, +4.5 us at 50 k — a scattered store instruction costs what it costs, whatever its
-// width.)
-struct BlockMaskArgs { const uint2 *sbox; uint2 *out; int GX; float invGX; int NC; uint32_t n_surfels; };
+// surfels and +4.7 us in the scatter that carried them; computed in the scatter from a per-surfel gather but stored
+// as a second, 2-byte array: +8.1 us in the scatter at 500 k — a scattered store instruction costs what it costs,
+// whatever its width; the gather alone, with the pair store: +6.3 us at 500 k, +3.2 us at 50 k — a round trip in a
+// chain of latencies.)
+struct BlockMaskArgs { uint2 *out; int GX; float invGX; int NC; };
 // bit 2*by + bx of the mask of an instance of `tile`; box = the surfel's block box
-__device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32_t tile, uint2 box)
+__device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32_t tile, uint32_t box)
 {
     const int ty = (int)(((float)tile + 0.5f) * a.invGX), tx = (int)tile - ty * a.GX;
-    const int bc_lo = (int)(box.x & 0xFFFFu), bc_n = (int)(box.x >> 16) - 1;         // columns [bc_lo, bc_lo + bc_n] mod NC
-    const int br_lo = (int)(box.y & 0xFFFFu), br_hi = (int)(box.y >> 16) - 1;        // rows [br_lo, br_hi]
+    const int bc_lo = (int)(box & 511u), bc_n = (int)((box >> 9) & 1023u) - 1;       // columns [bc_lo, bc_lo + bc_n] mod NC
+    const int br_lo = (int)((box >> 19) & 63u), br_hi = (int)(box >> 25) - 1;        // rows [br_lo, br_hi]
     const int r0 = max(br_lo - ty * (kTileH / 2), 0), r1 = min(br_hi - ty * (kTileH / 2), kTileH / 2 - 1);
     const uint32_t ym = r0 <= r1 ? (((4u << (2 * r1)) - 1u) & ~((1u << (2 * r0)) - 1u)) : 0u;
     int d0 = 2 * tx - bc_lo;
@@ -210,11 +212,6 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
 #pragma unroll
         for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
     }
-    uint2 box[kSortRounds];                    // (tile sort with block masks: the surfels' block boxes, one gather each)
-    if (bm.out) {
-#pragma unroll
-        for (int r = 0; r < kSortRounds; ++r) box[r] = bm.sbox[min(v[r], bm.n_surfels - 1u)];    // (clamped: slots beyond R hold anything)
-    }
     constexpr int CPT = BINS / 64;             // count-table entries per thread: BINS * WAVES / (64 * WAVES)
     uint32_t my_cnt[CPT];
 #pragma unroll
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_ker
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             if (keys_out) keys_out[pos] = k[r];     // (a caller that only wants the permutation passes null in the last pass)
-            if (bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, box[r]));
+            if (sizeof(KeyT) == 8 && bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, (uint32_t)((uint64_t)k[r] >> 32)));
             else vals_out[pos] = v[r];
             if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
         }
@@ -385,11 +382,6 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
 #pragma unroll
             for (int r = 0; r < kSortRounds; ++r) v[r] = (uint32_t)k[r] & packed_val_mask;
         }
-        uint2 box[kSortRounds];                // (block masks: the surfels' block boxes, one gather each)
-        if (bm.out) {
-#pragma unroll
-            for (int r = 0; r < kSortRounds; ++r) box[r] = bm.sbox[min(v[r], bm.n_surfels - 1u)];
-        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < kSortRounds; ++r) {
@@ -411,7 +403,7 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
             __builtin_amdgcn_wave_barrier();
             if (valid) {
                 if (keys_out) keys_out[pos] = k[r];
-                if (bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, box[r]));
+                if (sizeof(KeyT) == 8 && bm.out) bm.out[pos] = make_uint2(v[r], block_mask_of(bm, digit, (uint32_t)((uint64_t)k[r] >> 32)));
                 else vals_out[pos] = v[r];
                 if (rank == count - 1) s_cursor[wave * STR + digit] = pos + 1;
             }
@@ -421,8 +413,8 @@ __global__ __launch_bounds__(64 * SortBlock<BITS>::kWaves) void sort_scatter_chu
 }
 
 // rows of the emission's count table + scatter over its chunks (the histogram was the emission's)
-template <int BITS>
-static int tile_sort_emit_chunks(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout,
+template <typename KeyT, int BITS>
+static int tile_sort_emit_chunks(const KeyT *kin, const uint32_t *vin, KeyT *kout, uint32_t *vout,
                                  const uint32_t *chunk_start, uint32_t cap, int shift, uint32_t *cnt, uint32_t *totals,
                                  int nchunks, uint2 *ranges_out, int nranges, uint32_t packed_val_mask, hipStream_t st,
                                  const BlockMaskArgs &bm)
@@ -436,7 +428,7 @@ static int tile_sort_emit_chunks(const uint32_t *kin, const uint32_t *vin, uint3
     {
         ScopedTimer tm(T_SORT_SCATTER, st);
         const int nblocks = (nchunks + SortBlock<BITS>::kWaves - 1) / SortBlock<BITS>::kWaves;
-        hipLaunchKernelGGL((sort_scatter_chunks_kernel<uint32_t, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st,
+        hipLaunchKernelGGL((sort_scatter_chunks_kernel<KeyT, BITS>), dim3(nblocks), dim3(64 * SortBlock<BITS>::kWaves), 0, st,
                            kin, vin, kout, vout, chunk_start, cap, shift, (const uint32_t *)cnt, (const uint32_t *)totals,
                            nchunks, ranges_out, nranges, packed_val_mask, bm);
     }
@@ -450,14 +442,19 @@ static size_t sort_core_bytes(uint64_t cap)
     const uint64_t nchunks = (cap + kSortWaveItems - 1) / kSortWaveItems;
     return (size_t)(kSortMaxBins * (nchunks ? nchunks : 1) + kSortMaxBins) * sizeof(uint32_t);
 }
-// (count table + digit totals, and behind them the list of (surfel, block mask) pairs: sort_bmask_buffer)
+// (count table + digit totals, and behind them the list of (surfel, block mask) pairs and the 64-bit instances it
+//  is sorted from: sort_bmask_buffer, sort_wide_buffer)
 size_t sort_scratch_bytes(uint64_t cap)
 {
-    return sort_core_bytes(cap) + sizeof(uint2) * (size_t)cap + 64;
+    return sort_core_bytes(cap) + 2 * sizeof(uint64_t) * (size_t)cap + 64;
 }
 uint2 *sort_bmask_buffer(void *scratch, uint64_t cap)
 {
     return (uint2 *)((char *)scratch + ((sort_core_bytes(cap) + 15) & ~(size_t)15));
+}
+uint64_t *sort_wide_buffer(void *scratch, uint64_t cap)
+{
+    return (uint64_t *)(sort_bmask_buffer(scratch, cap) + cap);
 }
 
 // digit width: as few passes as 11-bit digits allow, then the narrowest digit that still fits
@@ -515,7 +512,7 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
                               const uint32_t *count_ptr, uint32_t cap, int nbits, void *scratch,
                               size_t scratch_bytes, int *result_in_tmp, hipStream_t st,
                               uint2 *ranges_out = nullptr, int nranges = 0, bool drop_sorted_keys = false,
-                              int base_shift = 0, BlockMaskArgs bm = BlockMaskArgs{ nullptr, nullptr, 1, 1.0f, 1, 1u })
+                              int base_shift = 0, BlockMaskArgs bm = BlockMaskArgs{ nullptr, 1, 1.0f, 1 })
 {
     *result_in_tmp = 0;
     if (cap == 0 || nbits <= 0) return SLS_OK;
@@ -543,7 +540,7 @@ static int radix_sort_pairs_t(KeyT *keys, uint32_t *vals, KeyT *keys_tmp, uint32
         KeyT *kout = (drop_sorted_keys && p + 1 == npasses) ? nullptr : kb[dst];
 #define SLS_PASS(B) radix_pass<KeyT, B>(kb[src], vb[src], kout, vb[dst], count_ptr, cap, shift, cnt, totals, nchunks, \
                                         0, ranges_out, nranges, packed_val_mask, st,                           \
-                                        (npasses == 1 ? bm : BlockMaskArgs{ nullptr, nullptr, 1, 1.0f, 1, 1u }))
+                                        (npasses == 1 ? bm : BlockMaskArgs{ nullptr, 1, 1.0f, 1 }))
         switch (bits) {
         case 8: rc = SLS_PASS(8); break;
         case 9: rc = SLS_PASS(9); break;
@@ -735,8 +732,10 @@ __global__ __launch_bounds__(EB) void emit_tiles_kernel(int N, int GX, const uin
                                                          ScanHandoff fused, uint32_t *__restrict__ total_out,
                                                          uint32_t *__restrict__ fail_flag,
                                                          uint32_t *__restrict__ hist_cnt, int hist_bins,
-                                                         uint32_t *__restrict__ chunk_start)
+                                                         uint32_t *__restrict__ chunk_start,
+                                                         const uint32_t *__restrict__ sbox, uint64_t *__restrict__ wide)
 {
+    // wide != null (packed mode): an instance is 64 bits — the surfel's block box above the (tile, surfel) word
     // hist_cnt != null: the workgroup is a CHUNK of the tile sort that follows — it counts the tiles of the instances
     // it writes (LDS) and stores column blockIdx of the count table cnt[tile][chunk] and the chunk's first instance:
     // the sort needs no histogram launch (sort_scatter_chunks_kernel)
@@ -762,6 +761,7 @@ __global__ __launch_bounds__(EB) void emit_tiles_kernel(int N, int GX, const uin
         rc = rect[g];
         mask = (tile_mask && (uint32_t)(rc.y * rc.w) <= 64u) ? tile_mask[g] : ~0ull;
     }
+    const uint64_t box_hi = wide ? ((uint64_t)sbox[g] << 32) : 0ull;
     const uint32_t nrect = (uint32_t)(rc.y * rc.w);
     if (nrect > 64u) mask = ~0ull;
     const uint32_t t = (i < N) ? (nrect <= 64u ? (uint32_t)__popcll(mask & (nrect >= 64u ? ~0ull : ((1ull << nrect) - 1ull))) : nrect) : 0u;
@@ -819,7 +819,8 @@ __global__ __launch_bounds__(EB) void emit_tiles_kernel(int N, int GX, const uin
                 if (tx >= GX) tx -= GX;
                 if (off < cap) {
                     const uint32_t tile = row + (uint32_t)tx;
-                    if (vals) { tkeys[off] = tile; vals[off] = g; }
+                    if (wide) wide[off] = box_hi | (uint64_t)((tile << pack_shift) | g);
+                    else if (vals) { tkeys[off] = tile; vals[off] = g; }
                     else tkeys[off] = (tile << pack_shift) | g;
                     if (hist_cnt) atomicAdd(&s_hist[tile], 1u);
                 }
@@ -1030,15 +1031,15 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                            ((size_t)bins * nemit + bins + nemit + 1) * sizeof(uint32_t) <= sort_core_bytes(cap);
     // SLS_NO_BLOCK_MASKS=1: no block masks, the forward walks the tiles' lists in rounds of 64 entries (A/B switch)
     static const bool no_bmask = getenv("SLS_NO_BLOCK_MASKS") != nullptr && getenv("SLS_NO_BLOCK_MASKS")[0] == '1';
-    BlockMaskArgs bm = { nullptr, nullptr, cam.GX, 1.0f / (float)cam.GX, (cam.GX * kTileW) / 8, (uint32_t)N };
-    // ... and only where the tiles' lists are long enough for the forward to gain more than the scatter pays (its extra
-    // gather is a round trip in a chain of latencies: +3.2 us at 50 k surfels / 64 x 1024 for -3.8 us in the forward;
-    // +4.0 / -14.0 us at 170 k, +6.3 / -16.2 us at 500 k / 64 x 2048): capacity per tile as the host-side proxy
-    // (bmask_mode = SlsMappingConfig.block_masks: 0 auto, 1 always, 2 never)
+    // ... and only where the tiles' lists are long enough for the forward to gain more than the binning pays:
+    // capacity per tile as the host-side proxy (bmask_mode = SlsMappingConfig.block_masks: 0 auto, 1 always, 2 never)
     const bool long_lists = bmask_mode == 1 || (bmask_mode == 0 && (uint64_t)cap >= 1500ull * (uint64_t)T);
-    if (sbox && bmask_out && fused_ranges && !no_bmask && kTileW == 16 && kTileH == 16 && long_lists) {
-        bm.sbox = (const uint2 *)sbox;
+    BlockMaskArgs bm = { nullptr, cam.GX, 1.0f / (float)cam.GX, (cam.GX * kTileW) / 8 };
+    uint64_t *wide = nullptr;
+    if (sbox && bmask_out && packed && !no_bmask && kTileW == 16 && kTileH == 16 && long_lists &&
+        block_box_fits(cam.GX * kTileW, cam.H)) {
         bm.out = sort_bmask_buffer(scratch, cap);
+        wide = sort_wide_buffer(scratch, cap);
         *bmask_out = bm.out;
     }
     {
@@ -1046,7 +1047,8 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
 #define SLS_EMIT(EB_) hipLaunchKernelGGL(emit_tiles_kernel<EB_>, dim3(nemit), dim3(EB_), 0, st, N, cam.GX, order,                 \
                            (const int4 *)rect, tiles, tile_mask, (const int4 *)erec, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow, \
                            packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,  \
-                           overflow, emit_hist ? cnt : (uint32_t *)nullptr, bins, emit_hist ? chunk_start : (uint32_t *)nullptr)
+                           overflow, emit_hist ? cnt : (uint32_t *)nullptr, bins, emit_hist ? chunk_start : (uint32_t *)nullptr, \
+                           sbox, wide)
         SLS_EMIT(eb);
 #undef SLS_EMIT
     }
@@ -1054,25 +1056,28 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     int which = 0;
     int rc;
     if (emit_hist) {
-        const uint32_t *kin = tkeys, *vin = packed ? nullptr : vals;
+        const uint32_t *vin = packed ? nullptr : vals;
         const int shift = packed ? idx_bits : 0;
         const uint32_t pmask = packed ? ((1u << idx_bits) - 1u) : 0u;
-        switch (tile_bits < 8 ? 8 : tile_bits) {
-#define SLS_CASE(B) case B: rc = tile_sort_emit_chunks<B>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit, \
-                                                          (uint2 *)ranges, T, pmask, st, bm); break;
-        SLS_CASE(8) SLS_CASE(9) SLS_CASE(10)
-        default: rc = tile_sort_emit_chunks<11>(kin, vin, nullptr, vals_tmp, chunk_start, cap, shift, cnt, totals, nemit,
-                                                (uint2 *)ranges, T, pmask, st, bm); break;
-#undef SLS_CASE
+#define SLS_CASE(K_, B) case B: rc = tile_sort_emit_chunks<K_, B>(wide ? (const K_ *)wide : (const K_ *)tkeys, vin, (K_ *)nullptr, vals_tmp, chunk_start, \
+                                                              cap, shift, cnt, totals, nemit, (uint2 *)ranges, T, pmask, st, bm); break;
+        if (wide) {
+            switch (tile_bits < 8 ? 8 : tile_bits) { SLS_CASE(uint64_t, 8) SLS_CASE(uint64_t, 9) SLS_CASE(uint64_t, 10) default: SLS_CASE(uint64_t, 11) }
+        } else {
+            switch (tile_bits < 8 ? 8 : tile_bits) { SLS_CASE(uint32_t, 8) SLS_CASE(uint32_t, 9) SLS_CASE(uint32_t, 10) default: SLS_CASE(uint32_t, 11) }
         }
+#undef SLS_CASE
         which = 1;
+    } else if (wide) {
+        rc = radix_sort_pairs_t<uint64_t>(wide, nullptr, nullptr, vals_tmp, count_ptr, cap, tile_bits, scratch,
+                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits, bm);
     } else if (packed) {
         rc = radix_sort_pairs_t<uint32_t>(tkeys, nullptr, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
-                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits, bm);
+                                          scratch_bytes, &which, st, (uint2 *)ranges, T, true, idx_bits);
     } else {
         rc = radix_sort_pairs_t<uint32_t>(tkeys, vals, tkeys_tmp, vals_tmp, count_ptr, cap, tile_bits, scratch,
                                           scratch_bytes, &which, st, fused_ranges ? (uint2 *)ranges : nullptr, T,
-                                          fused_ranges, 0, bm);   // nobody reads the sorted tile ids then
+                                          fused_ranges);   // nobody reads the sorted tile ids then
     }
     if (rc) return rc;
     *sorted_in_tmp = which;
