@@ -56,8 +56,8 @@ typedef struct SlsCamera {
     int32_t wrap;           /* 1: azimuth wraps (360 deg image), D5             */
     int32_t tile_cull_min;  /* D10: the binning emits only the instances of a surfel's tile rectangle whose tile the
                              * footprint can reach (include/sls_det_math.h: sls_tile_outside), for rectangles of at
-                             * least this many (and at most 64) tiles.  0: the default (SLS_TILE_CULL_MIN_DEFAULT, 6);
-                             * 1: test off, every tile of the rectangle (the pre-D10 lists); k >= 2: threshold k */
+                             * least this many (and at most 64) tiles.  0: the default (SLS_TILE_CULL_MIN_DEFAULT: off since
+                             * round 3, include/sls_spec.h); 1: test off, every tile of the rectangle; k >= 2: threshold k */
     float fx, fy, cx, cy;   /* K = projmatrix[:3,:3]^T : u = fx*az+cx, v = fy*el+cy */
     float scale_modifier;
     float near_cut, far_cut;

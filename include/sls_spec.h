@@ -16,12 +16,15 @@
 #define SLS_CUTOFF 3.0f
 #define SLS_RMIN_PX 2.1213203435596424f
 #define SLS_FILTER_INV_SQUARE 2.0f
-/* D10: the binning tests a surfel's tile rectangle tile by tile (include/sls_det_math.h) when it has at least this
- * many tiles (and at most 64).  On the bench scene rectangles of >= 3 tiles are 28 % of the surfels, 57 % of the
- * instances and 97 % of what the test removes; measured on MI355X (profiles/r03e): threshold 3 -> 0.2676 ms per
- * iteration, 6 -> 0.2688, off -> 0.2701 (the tests cost the VALU-bound preprocess kernel 6.9 / 5.4 us, the shorter
- * lists give the tile kernels 8.1 / 6.0 us back). */
-#define SLS_TILE_CULL_MIN_DEFAULT 3
+/* D10: the binning can test a surfel's tile rectangle tile by tile (include/sls_det_math.h) when it has at least
+ * SlsCamera.tile_cull_min tiles (and at most 64).  On the bench scene rectangles of >= 3 tiles are 28 % of the
+ * surfels, 57 % of the instances and 97 % of what the test removes (-12 % instances).  Default: 0 = OFF since both
+ * tile kernels run dense rounds (round 3): while they walked the tiles' lists in rounds of 64 entries, threshold 3
+ * gave 0.2676 ms per iteration against 0.2701 without the test (profiles/r03e: +6.9 us in the VALU-bound preprocess
+ * kernel for -8.1 us in the tile kernels); with compact lists for the backward and a scanned list for the forward
+ * the shorter lists are worth 1.6 us in the forward and nothing in the backward: 0.2321 ms with threshold 3 or 6,
+ * 0.2286 ms without at 500 k surfels / 64 x 2048, no difference at 170 k / 50 k (tools/gpu_r03w.sh). */
+#define SLS_TILE_CULL_MIN_DEFAULT 0
 /* blending thresholds */
 #define SLS_ALPHA_MAX 0.99f
 #define SLS_ALPHA_MIN (1.0f / 255.0f)

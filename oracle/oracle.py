@@ -23,7 +23,7 @@ REC_STRIDE = 20
 GREC_STRIDE = 16
 NEAR = float(np.float32(0.2))  # SLS_NEAR / SLS_FAR are float literals
 FAR = 100.0
-TILE_CULL_MIN_DEFAULT = 3   # SLS_TILE_CULL_MIN_DEFAULT (include/sls_spec.h)
+TILE_CULL_MIN_DEFAULT = 0   # SLS_TILE_CULL_MIN_DEFAULT (include/sls_spec.h): 0 = the test is off by default
 
 
 def build(force: bool = False) -> None:

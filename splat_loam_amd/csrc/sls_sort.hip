@@ -1029,14 +1029,12 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     uint32_t *cnt = (uint32_t *)scratch, *totals = cnt + (size_t)bins * nemit, *chunk_start = totals + bins;
     const bool emit_hist = fused_ranges && !no_emit_hist && (size_t)bins * nemit <= (size_t)400000 &&
                            ((size_t)bins * nemit + bins + nemit + 1) * sizeof(uint32_t) <= sort_core_bytes(cap);
-    // SLS_NO_BLOCK_MASKS=1: no block masks, the forward walks the tiles' lists in rounds of 64 entries (A/B switch)
-    static const bool no_bmask = getenv("SLS_NO_BLOCK_MASKS") != nullptr && getenv("SLS_NO_BLOCK_MASKS")[0] == '1';
-    // ... and only where the tiles' lists are long enough for the forward to gain more than the binning pays:
+    // Block masks (the forward's dense rounds) only where the tiles' lists are long enough for the forward to gain more than the binning pays:
     // capacity per tile as the host-side proxy (bmask_mode = SlsMappingConfig.block_masks: 0 auto, 1 always, 2 never)
     const bool long_lists = bmask_mode == 1 || (bmask_mode == 0 && (uint64_t)cap >= 1500ull * (uint64_t)T);
     BlockMaskArgs bm = { nullptr, cam.GX, 1.0f / (float)cam.GX, (cam.GX * kTileW) / 8 };
     uint64_t *wide = nullptr;
-    if (sbox && bmask_out && packed && !no_bmask && kTileW == 16 && kTileH == 16 && long_lists &&
+    if (sbox && bmask_out && packed && kTileW == 16 && kTileH == 16 && long_lists &&
         block_box_fits(cam.GX * kTileW, cam.H)) {
         bm.out = sort_bmask_buffer(scratch, cap);
         wide = sort_wide_buffer(scratch, cap);
