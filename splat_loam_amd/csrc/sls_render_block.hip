@@ -394,13 +394,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 // kernel above spends a third of its life on per-round overhead (wait for the 64 staged records 1230, cull +
 // compaction 780, round end 280 shader clocks, against 825 per step) and the tile's list is the TILE's: of the 64
 // entries of a round only 25-50 % can reach this block's 16 pixels at all.  Here the list is read twice: a SCAN tests
-// 256 entries per round — two coalesced loads per entry quartet: the 16-bit block masks the emission computed from
-// the surfels' support boxes and the sort carried into list order (sls_sort.hip: sort_bmask_buffers), and the
-// surfel indices — and queues the survivors; a ROUND stages, culls and blends 64 queued survivors.  Rounds per block
-// 5.3 -> 3.3 at BASELINE config 3, 14.6 -> 5.0 at 170 k surfels / 64 x 1024, 6.2 -> 2.9 at 50 k.  The first 64 entries
-// go straight into round 0, so that the first records are requested as early as before.  Everything a pixel
+// 256 entries per round — four coalesced 8-byte loads per lane: the (surfel, block mask) pairs the tile sort's
+// scatter stored in list order (sls_sort.hip: block_mask_of, from the surfels' block boxes) — and queues the
+// survivors; a ROUND stages, culls and blends 64 queued survivors.  Rounds per block 5.3 -> 3.3 at BASELINE config 3,
+// 14.6 -> 5.0 at 170 k surfels / 64 x 1024, 6.2 -> 2.9 at 50 k.  The first 64 entries go straight into round 0, so
+// that the first records are requested as early as before.  Everything a pixel
 // accumulates is unchanged (same entries, same order, same arithmetic: the mask is the box test the round's cull
-// repeats, with 0.001 pixels of slack) and so is the hand-over to the backward: the block's compact list.
+// repeats, with 0.01 pixels of slack) and so is the hand-over to the backward: the block's compact list.
 // (The scan was first built on gathers of the records' support boxes: 256 scattered line requests per chunk, 4300-4800
 //  clocks of waiting per round, slower than the kernel above at every size.)
 // ---------------------------------------------------------------------------
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                                            0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
     if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     s_rpos[0][lane] = (uint32_t)lane;
-    // scan state (wave-uniform scalars) and its two chunks in flight
+    // scan state (wave-uniform scalars); ONE chunk of 256 (surfel, mask) pairs is in flight
     const int n_scan = max(n - 64, 0);
     const int nchunks = (n_scan + kScanChunk - 1) / kScanChunk;
     int sc_c = 0, qh = 0, qn = 0;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         if (blk_mask) s_flag[lane] = 0u;   // entries of this round that reach at least one pixel of the block
         // single wave: LDS operations complete in program order, no barrier needed
         SLS_WSTAGE_STORE()
-        // --- scan: top the queue up from the chunk whose support boxes arrived (requested a round ago); goes on
+        // --- scan: top the queue up from the chunk whose pairs arrived (requested a round ago); goes on
         //     (waiting for its loads) only while the queue is empty
         while (sc_c < nchunks && qn <= 64) {
             const int p0 = 64 + sc_c * kScanChunk + 4 * lane;
