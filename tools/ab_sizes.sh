@@ -1,5 +1,6 @@
 #!/bin/bash
-# visit y: A/B of library builds at three sizes, every command under its own short timeout
+# A/B of library builds (gpurun_tmp_<name>.so, as tools/ab_bench.sh) at three sizes: VARIANTS="a b" bash tools/ab_sizes.sh
+# Every command runs under its own short timeout: a hung variant costs a minute, not the visit.
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 for shape in "500000 64 2048" "170000 64 1024" "50000 64 1024"; do
