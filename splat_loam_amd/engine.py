@@ -113,6 +113,13 @@ class MappingEngine:
         self._lag_dev = torch.zeros((2, 8), dtype=torch.int32, device=self.dev)
         self._lag_host = torch.zeros((2, 8), dtype=torch.int32).pin_memory()
         self._lag_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        # With the status mirror (the iteration's last kernel stores the status block into pinned host memory, word 7
+        # last) the host needs no event to know that an iteration has finished: it arms words 0 and 7 of the slot with a
+        # value the device never writes and polls them — no event record on the stream, no event wait
+        # (SLS_NO_STATUS_POLL=1: events, for A/B runs)
+        self._lag_np = self._lag_host.numpy()
+        self.status_poll = os.environ.get("SLS_NO_STATUS_POLL", "0") != "1"
+        self._lag_polled = [False, False]
         self._group = None
         self._lag_ready = []              # statuses of finished iterations not handed out yet (lagged mode)
         self.flushed = []
@@ -357,6 +364,7 @@ class MappingEngine:
     def _step_lagged(self, camera):
         slot = 0 if self._lag_pending is None else self._lag_pending[0] ^ 1
         group = self._group
+        polled = False
         if self._sharded(group):
             # keyframe-parallel: the group's verdict is known on the device only (the void flags ride the
             # gradient all-reduce and guard Adam), so the host can lag here exactly as on one GPU
@@ -369,13 +377,19 @@ class MappingEngine:
                 self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
         elif self.status_mirror:
             # the iteration's last kernel mirrors the status block into pinned host memory: no copy kernel
+            polled = self.status_poll
+            if polled:
+                self._lag_np[slot, 0] = -1
+                self._lag_np[slot, 7] = -1
             self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot],
                           mirror=self._lag_host[slot].data_ptr())
         else:
             self._enqueue(camera, apply_adam=True, with_regulariser=True, status=self._lag_dev[slot])
             self._lag_host[slot].copy_(self._lag_dev[slot], non_blocking=True)
         self.t += 1
-        self._lag_ev[slot].record(torch.cuda.current_stream(self.dev))
+        self._lag_polled[slot] = polled
+        if not polled:
+            self._lag_ev[slot].record(torch.cuda.current_stream(self.dev))
         prev, self._lag_pending = self._lag_pending, (slot, camera)
         if prev is not None:
             self._lag_collect(prev, redo_current=True)
@@ -385,7 +399,16 @@ class MappingEngine:
 
     def _lag_collect(self, prev, redo_current):
         pslot, pcam = prev
-        self._lag_ev[pslot].synchronize()
+        if self._lag_polled[pslot]:
+            row, spins = self._lag_np[pslot], 0
+            while row[7] == -1 or row[0] == -1:          # (the device writes word 7 last, and never this value)
+                spins += 1
+                if spins > 2_000_000:                    # ~1 s: something else is wrong — let the stream say what
+                    torch.cuda.current_stream(self.dev).synchronize()
+                    if row[7] == -1 or row[0] == -1:
+                        raise RuntimeError("the mapping iteration's status never reached its host mirror")
+        else:
+            self._lag_ev[pslot].synchronize()
         st = self._note(self._parse_status(self._lag_host[pslot].clone()))
         if not st["overflow"]:
             self.last = st
