@@ -304,6 +304,17 @@ class MappingEngine:
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
+    @staticmethod
+    def _parse_status_np(h):
+        """_parse_status on a NumPy row (int32 x 8) of the pinned mirror: no tensor ops on the host's critical path"""
+        import numpy as np
+        f = h.view(np.float32)
+        R, flags = int(h[0]) & 0xFFFFFFFF, int(h[1])
+        return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
+                "exchange_too_small": bool(flags & 4), "exchange_count": int(h[7]) & 0xFFFFFFFF,
+                "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
+                "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
+
     @torch.no_grad()
     def step(self, camera, group=None, sync: bool = True):
         """One mapping iteration on `camera`.  Returns the status dict (sync=True)
@@ -407,9 +418,10 @@ class MappingEngine:
                     torch.cuda.current_stream(self.dev).synchronize()
                     if row[7] == -1 or row[0] == -1:
                         raise RuntimeError("the mapping iteration's status never reached its host mirror")
+            st = self._note(self._parse_status_np(row.copy()))
         else:
             self._lag_ev[pslot].synchronize()
-        st = self._note(self._parse_status(self._lag_host[pslot].clone()))
+            st = self._note(self._parse_status(self._lag_host[pslot].clone()))
         if not st["overflow"]:
             self.last = st
             self._lag_ready.append(st)
