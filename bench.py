@@ -343,11 +343,12 @@ def main():
     log(f"scene ready; dp_mode={dp_mode} calibration={dp_cal}")
     model, engine = fresh(full_sort=args.full_sort, dp_mode=dp_mode)
     timing = not args.no_timing
-    # events around the dominant kernel only (2 per step, ~10 us): it is timed live inside the
-    # timed region without the ~0.2 ms/step that 60 event records per step would add
+    # events around the dominant kernel only, and around one launch in eight of it (mode 4): the kernel is timed
+    # live inside the timed region, and the iteration — host-bound at this size — pays for 1/8 of an event pair
+    # instead of the ~60 event records that timing every launch would add
     n_iters = args.steps * ips
     dt, step = run(model, engine, cams if n_kf > 1 else [cam], args.warmup * ips, n_iters, pick=pick_rank,
-                   after_warmup=(lambda: lib.sls_timing_enable(3)) if timing else None)
+                   after_warmup=(lambda: lib.sls_timing_enable(4)) if timing else None)
     if engine is not None and status_read is False:
         assert not engine._read_status()["overflow"], "instance buffers overflowed during the timed region"
 
@@ -372,7 +373,9 @@ def main():
         barrier()
         kernels = collect()
         lib.sls_timing_enable(0)
-        kernels.update(live)
+        for name, (ms, c) in live.items():   # the live average over the sampled launches, at the pass's launch count
+            c_all = kernels.get(name, (0.0, c))[1] or c
+            kernels[name] = (ms / c * c_all, c_all)
         if engine is not None and engine.comm_events:
             ev = engine.comm_events
             engine.comm_events = None
@@ -460,7 +463,8 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source, "stale": stale,
                     "kernel_source_hash": src_hash,
                     "avg_launch_us": round(ms / c * 1e3, 2), "alg_bytes_per_launch": int(b), "valu": valu,
-                    "note": "achieved/frac: algorithmic bytes / live HIP-event time of this run against the HBM peak "
+                    "live_launches_timed": live.get(dom, (0.0, 0))[1],
+                    "note": "achieved/frac: algorithmic bytes / live HIP-event time of this run (one launch in eight of the timed region bracketed) against the HBM peak "
                             "(the contract's figure).  valu_frac: the kernel's VALU counter reading relative to what "
                             "the same counter shows at the measured peak issue rate of plain FP32 instructions; the "
                             "step loops are made of half- and quarter-rate classes (DPP, v_cmp, packed, lane swaps, "

@@ -418,7 +418,8 @@ int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t 
  * out (later launches untimed). */
 int sls_timing_slots(void);
 const char *sls_timing_name(int slot);
-int sls_timing_enable(int mode);   /* 0 off, 1 every launch, 2 the two tile kernels only, 3 render_bwd only */
+int sls_timing_enable(int mode);   /* 0 off, 1 every launch, 2 the two tile kernels only, 3 render_bwd only,
+                                    * 4 every 8th render_bwd launch (a timed region that keeps its own clock) */
 int sls_timing_collect(double *total_ms_host, int64_t *counts_host);
 
 /* Diagnostic: when non-null, the tile kernels write the shader-clock cycles each
