@@ -40,6 +40,13 @@ def test_latest_bench_line_has_the_contract_fields():
         # calibrated: the kernel's VALU counter reading relative to the same counter at the measured
         # peak issue rate of plain FP32 instructions — a fraction, not the raw 0.95 "busy" figure
         assert 0.0 < r["valu_frac"] < 1.0 and r["valu_calibration"]["peak_valu_issue_busy_quad"] > 1.0
+    if "live_launches_timed" in r:
+        # the dominant kernel is timed live on a SAMPLE of the timed region's launches (sls_timing_enable(4)); its row
+        # of the per-kernel table must still describe every launch of an iteration, at the live average
+        k = d["kernels"][r["kernel"]]
+        assert r["live_launches_timed"] >= 8 and abs(k["avg_us"] - r["avg_launch_us"]) < 0.02
+        assert 0.9 <= k["launches_per_iteration"] <= 1.2
+        assert abs(k["us_per_iteration"] - k["avg_us"] * k["launches_per_iteration"]) <= 0.02 * k["us_per_iteration"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, f"cpu_baseline.{k} missing"
