@@ -102,12 +102,16 @@ int sls_ray_tables_at(const SlsCamera *cam, float col_offset, float row_offset, 
 
 /* ---- forward, stage 1: preprocess + depth order + scan ---------------------
  * col_cs / row_cs: the DEVICE copies of sls_ray_tables (the tile test of D10 takes its tile-centre directions
- * from them; may be null with cam->tile_cull_min = 1).
+ * from them; needed only while that test is on: cam->tile_cull_min >= 2, or 0 with a non-zero default).
  * rec: N*20 floats, radii: N int32, rect: N*4 int32 {txlo,ncols,tylo,nrows},
  * tiles_touched: N uint32 = number of tile instances the surfel emits,
  * tile_mask: N uint64 — bit k set: the k-th tile of the rectangle (row-major, the emission order) is emitted;
  *   rectangles of fewer than cam->tile_cull_min or more than 64 tiles are not tested and emit every tile (mask =
- *   all ones below the tile count),
+ *   all ones below the tile count); may be null while the test is off,
+ * block_box (optional, may be null): N uint32 — the surfel's support box as two ranges over the image's 8x2 pixel
+ *   blocks (one word; images up to 4096 x 128).  Handed to stage 2, it lets the tile sort deliver the sorted list
+ *   as (surfel, mask of the tile's sixteen pixel blocks the surfel can reach) pairs, which the forward tile kernel
+ *   scans 256 at a time instead of staging every record (its "dense rounds", the kernel sls_mapping_step runs),
  * depth: N floats (range of the centre, the sort key),
  * order: N uint32 = surfel index at each position of the (range, index) order (ALL surfels,
  *        culled ones included at their range; they have tiles_touched = 0 and emit nothing),
@@ -120,14 +124,20 @@ int sls_forward_stage1(const SlsCamera *cam, int N,
                        const float *means3D, const float *scales, const float *rotations,
                        const float *opacities, const float *col_cs, const float *row_cs,
                        float *rec, int32_t *radii, int32_t *rect, uint32_t *tiles_touched, uint64_t *tile_mask,
+                       uint32_t *block_box,
                        float *depth, uint32_t *order, uint32_t *offsets, uint32_t *total_out,
                        void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- forward, stage 2: binning, stable sort by tile, ranges, per-tile render
  * total_dev: the device word stage 1 wrote (= R).  tile_keys/vals and the _tmp
- * pair: R uint32 each (ping-pong); on return *sorted_in_tmp tells which pair
- * holds the sorted list (tile id, surfel index).  keys64_out (optional, R
- * uint64): the 64-bit keys (tile << 32 | depth bits) the list is ordered by.
+ * pair: R uint32 each (ping-pong).  keys64_out (optional, R uint64): the 64-bit keys
+ * (tile << 32 | depth bits) the list is ordered by (asks for the two-array sort: no pairs then).
+ * The sorted list of surfel indices comes back as (*sorted_list, *sorted_stride): entry j is
+ * (*sorted_list)[j * *sorted_stride] — stride 1: a plain array (vals or vals_tmp; *sorted_in_tmp says which, and
+ * which of tile_keys / tile_keys_tmp holds the sorted tile ids when the sort kept them); stride 2: the
+ * (surfel, block mask) pairs inside sort_scratch (block_box given, lists long enough or list_pairs = 1, at most
+ * 2048 tiles): sort_scratch then has to stay alive as long as the list is used (the backward, the caller).
+ * list_pairs: 0 = pairs where R >= 1500 T (the rule of sls_mapping_step), 1 = whenever possible, 2 = never.
  * ranges: T*2 uint32 with T = ceil(W/tw)*ceil(H/th).  allmap: 7*H*W floats;
  * pix_state: H*W float4 {T_final, M1, M2, 0}; pix_contrib: H*W uint2
  * {n_contrib, median_contrib}; tile_consumed: T uint32 (list entries consumed
@@ -138,36 +148,40 @@ int sls_forward_stage1(const SlsCamera *cam, int N,
  * per pixel block the compact list of the (list position, surfel) pairs that reached one of
  * its pixels; with it sls_backward walks exactly those, 64 per round, instead of re-deriving
  * them with a box test over the tile's whole list (the name is round 2's, when the hand-over
- * was a bit mask per 64 list entries). */
+ * was a bit mask per 64 list entries).  *block_masks_shape (may be null): which pixel-block shape wrote it
+ * (0: none, 2: 4x4, 3: 8x2) — hand it to sls_backward together with the buffer. */
 size_t sls_sort_scratch_bytes(uint64_t R);
 size_t sls_block_mask_bytes(uint64_t R, int H, int W);
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R,
                        const float *rec, const int32_t *rect, const uint32_t *tiles_touched,
-                       const uint64_t *tile_mask,
+                       const uint64_t *tile_mask, const uint32_t *block_box,
                        const float *depth, const uint32_t *order, const uint32_t *offsets,
                        const uint32_t *total_dev,
                        uint32_t *tile_keys, uint32_t *vals, uint32_t *tile_keys_tmp, uint32_t *vals_tmp,
                        void *sort_scratch, size_t sort_scratch_bytes, int *sorted_in_tmp,
-                       uint64_t *keys64_out,
+                       uint64_t *keys64_out, int list_pairs,
+                       const uint32_t **sorted_list, int *sorted_stride,
                        uint32_t *ranges, const float *col_cs, const float *row_cs,
                        float *allmap, float *pix_state, uint32_t *pix_contrib,
-                       uint32_t *tile_consumed, uint64_t *block_masks, void *stream);
+                       uint32_t *tile_consumed, uint64_t *block_masks, int *block_masks_shape, void *stream);
 
 /* ---- backward ----------------------------------------------------------
- * vals_sorted/ranges/rec/pix_* are the forward's buffers (never allmap: the
- * caller may have overwritten it in place).  grec: N*16 floats of scratch
- * (zeroed by the call).  Outputs: dL/dmeans3D (N*3), dL/dscales (N*2),
+ * vals_sorted (+ vals_stride: 1 or 2, as stage 2 returned them)/ranges/rec/pix_* are the forward's buffers
+ * (never allmap: the caller may have overwritten it in place).  block_masks + block_masks_shape: the forward's
+ * hand-over and the block shape that wrote it; the compact lists are walked only if that shape is the backward
+ * kernel's own (otherwise, or with null / 0, the backward culls the tile's list itself).  grec: N*16 floats of
+ * scratch (zeroed by the call).  Outputs: dL/dmeans3D (N*3), dL/dscales (N*2),
  * dL/drotations (N*4, w.r.t. the normalised quaternion as passed in),
  * dL/dopacities (N). */
 int sls_backward(const SlsCamera *cam, int N, uint64_t R,
                  const float *means3D, const float *scales, const float *rotations,
                  const int32_t *radii, const float *rec,
-                 const uint32_t *ranges, const uint32_t *vals_sorted,
+                 const uint32_t *ranges, const uint32_t *vals_sorted, int vals_stride,
                  const float *col_cs, const float *row_cs,
                  const float *pix_state, const uint32_t *pix_contrib,
                  const float *dL_dallmap, float *grec,
                  float *dL_dmeans3D, float *dL_dscales, float *dL_drotations,
-                 float *dL_dopacities, const uint64_t *block_masks, void *stream);
+                 float *dL_dopacities, const uint64_t *block_masks, int block_masks_shape, void *stream);
 
 /* The same backward with DETERMINISTIC accumulation of the per-surfel gradient records: integer atomics
  * instead of float atomics (first launch: the largest |contribution| per surfel and field; second launch:
@@ -178,11 +192,12 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R,
 size_t sls_backward_det_scratch_bytes(int N);
 int sls_backward_det(const SlsCamera *cam, int N, uint64_t R,
                      const float *means3D, const float *scales, const float *rotations, const int32_t *radii,
-                     const float *rec, const uint32_t *ranges, const uint32_t *vals_sorted,
+                     const float *rec, const uint32_t *ranges, const uint32_t *vals_sorted, int vals_stride,
                      const float *col_cs, const float *row_cs, const float *pix_state, const uint32_t *pix_contrib,
                      const float *dL_dallmap,
                      float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dopacities,
-                     const uint64_t *block_masks, void *det_scratch, size_t det_scratch_bytes, void *stream);
+                     const uint64_t *block_masks, int block_masks_shape, void *det_scratch, size_t det_scratch_bytes,
+                     void *stream);
 
 /* ---- fused consumer of allmap: render() post-processing + mapper loss ------
  * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of

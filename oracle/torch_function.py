@@ -33,6 +33,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 TILE = (16, 16)
+BACKWARD_THREADS = 1     # threads of the checker's tile backward under autograd (a test at full size raises it)
 
 
 class _OracleRasterize(torch.autograd.Function):
@@ -51,7 +52,7 @@ class _OracleRasterize(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _g_radii, g_allmap):
-        b = ctx.o.backward(ctx.st, g_allmap.detach().numpy(), want_abs=False)
+        b = ctx.o.backward(ctx.st, g_allmap.detach().numpy(), threads=BACKWARD_THREADS, want_abs=False)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.dtype)
         return t(b["dmeans"]), None, t(b["dopac"]), t(b["dscales"]), t(b["drots"]), None, None
 

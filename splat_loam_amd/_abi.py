@@ -81,19 +81,22 @@ _PROTOS = {
     "sls_consumer_fwd_bwd": (C.c_int, [C.c_int, C.c_int] + [_VP] * 5 + [C.c_float] * 3 + [C.c_int, _VP, _VP, _VP,
                                                                                          C.c_size_t, _VP]),
     "sls_stage1_scratch_bytes": (C.c_size_t, [C.c_int]),
-    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 15 + [_VP, C.c_size_t, _VP]),
+    "sls_forward_stage1": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 16 + [_VP, C.c_size_t, _VP]),
     "sls_sort_scratch_bytes": (C.c_size_t, [C.c_uint64]),
-    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 12 +
-                           [_VP, C.c_size_t, C.POINTER(C.c_int), _VP] + [_VP] * 8 + [_VP]),
+    "sls_forward_stage2": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 13 +
+                           [_VP, C.c_size_t, C.POINTER(C.c_int), _VP, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)] +
+                           [_VP] * 8 + [C.POINTER(C.c_int), _VP]),
     "sls_block_mask_bytes": (C.c_size_t, [C.c_uint64, C.c_int, C.c_int]),
     "sls_mapping_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),
     "sls_mapping_workspace_bytes_cfg": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(SlsMappingConfig)]),
     "sls_mapping_step": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 7 + [C.c_int64, _VP, _VP, C.c_int] +
                          [_VP] * 4 + [C.POINTER(SlsMappingConfig), C.c_uint64, _VP, C.c_size_t, _VP,
                                       C.POINTER(C.c_void_p), _VP]),
-    "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 18 + [_VP]),
+    "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 7 + [C.c_int] + [_VP] * 11 +
+                     [C.c_int, _VP]),
     "sls_backward_det_scratch_bytes": (C.c_size_t, [C.c_int]),
-    "sls_backward_det": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 17 + [_VP, C.c_size_t, _VP]),
+    "sls_backward_det": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 7 + [C.c_int] + [_VP] * 10 +
+                         [C.c_int, _VP, C.c_size_t, _VP]),
     "sls_adam_step": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double, C.c_int64, _VP]),
     "sls_adam_step_guarded": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP]),

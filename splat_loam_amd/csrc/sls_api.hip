@@ -112,11 +112,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, int64_t total_uni
         const uint32_t bits = (void_flags[0] > 0.0f ? 1u : 0u) | (void_flags[1] > 0.0f ? 2u : 0u);
         if (blockIdx.x == 0 && threadIdx.x == 0 && status_block) {
             status_block[1] = bits;                       // SlsMappingStatus.overflow: the group's verdict
-            if (status_mirror) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    __builtin_nontemporal_store(k == 1 ? bits : status_block[k], status_mirror + k);
-            }
+            if (status_mirror) mirror_status_block(status_block, status_mirror, true, bits);
         }
         if (bits) return;
     }

@@ -330,6 +330,22 @@ struct AdamFuse {
     int grad_bitmap_words;                // (N + 63) / 64
 };
 
+// Copy of an iteration's finished status block (8 words) into its pinned host mirror, by ONE lane.  The host polls
+// words 0 and 7 (engine.py: it arms them with a value the device never writes): words 0..6 are made visible at
+// system scope BEFORE word 7 is stored, so a host that sees word 7 sees the whole row.
+__device__ __forceinline__ void mirror_status_block(const uint32_t *src, uint32_t *mirror, bool override1 = false,
+                                                    uint32_t word1 = 0u)
+{
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = src[k];
+    if (override1) w[1] = word1;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) __builtin_nontemporal_store(w[k], mirror + k);
+    __threadfence_system();
+    __builtin_nontemporal_store(w[7], mirror + 7);
+}
+
 // XCD-aware block -> tile remap: the dispatcher places block b on XCD b % 8
 // (speed only, never correctness); give each XCD a contiguous run of tiles so
 // neighbouring tiles, which share surfel records, share an L2.

@@ -112,10 +112,7 @@ __global__ __launch_bounds__(256) void exchange_adam_kernel(int N, SparseAdamArg
                                                             uint32_t *__restrict__ status_mirror)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && status_mirror) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(status_block[k], status_mirror + k);
-    }
+    if (i == 0 && status_mirror) mirror_status_block(status_block, status_mirror);
     if (status_block[1] != 0u) return;        // void: the verdict of the group or an exchange buffer too small
     if (i >= N) return;
     float g[10];

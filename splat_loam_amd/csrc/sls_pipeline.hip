@@ -53,7 +53,7 @@ int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
                       uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr,
                       uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr,
-                      const uint32_t *block_order = nullptr);
+                      const uint32_t *block_order = nullptr, int vals_stride = 1, int block_masks_shape = -1);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -145,8 +145,8 @@ size_t sls_stage1_scratch_bytes(int N) { return order_scratch_bytes(N); }
 int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const float *scales,
                        const float *rotations, const float *opacities, const float *col_cs, const float *row_cs,
                        float *rec, int32_t *radii, int32_t *rect,
-                       uint32_t *tiles_touched, uint64_t *tile_mask, float *depth, uint32_t *order, uint32_t *offsets,
-                       uint32_t *total_out, void *scratch, size_t scratch_bytes, void *stream)
+                       uint32_t *tiles_touched, uint64_t *tile_mask, uint32_t *block_box, float *depth, uint32_t *order,
+                       uint32_t *offsets, uint32_t *total_out, void *scratch, size_t scratch_bytes, void *stream)
 {
     SLS_REQUIRE(cam && total_out, "null pointer");
     SLS_REQUIRE(N >= 0, "negative N");
@@ -158,17 +158,21 @@ int sls_forward_stage1(const SlsCamera *cam, int N, const float *means3D, const 
     SLS_REQUIRE(means3D && scales && rotations && opacities && rec && radii && rect && tiles_touched && depth &&
                     order && offsets && scratch,
                 "null pointer");
-    SLS_REQUIRE(cam->tile_cull_min == 1 || (col_cs && row_cs && tile_mask),
-                "the tile-level footprint test (SlsCamera.tile_cull_min != 1) needs the ray tables and a tile_mask buffer");
     const DevCam dc = make_devcam(*cam);
+    // (the ray tables and the mask buffer are D10's: required only while the tile-level footprint test is on)
+    SLS_REQUIRE(dc.tile_cull == 0 || (col_cs && row_cs && tile_mask),
+                "the tile-level footprint test (SlsCamera.tile_cull_min >= 2) needs the ray tables and a tile_mask buffer");
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("stage1 scratch too small");
         return SLS_E_SCRATCH;
     }
+    // without the tables the preprocess writes no masks: every tile of every rectangle is emitted
+    if (tile_mask && !(col_cs && row_cs)) SLS_HIP_CHECK(hipMemsetAsync(tile_mask, 0xFF, sizeof(uint64_t) * (size_t)N, st));
     uint32_t *okeys, *ovals, *n_dev;
     depth_order_key_buffers(N, scratch, order, &okeys, &ovals, &n_dev);
     int rc = launch_preprocess_fwd(dc, 0, 0.0f, 0.0f, nullptr, N, means3D, scales, rotations, opacities, rec, radii,
-                                   rect, tiles_touched, depth, okeys, ovals, n_dev, st, nullptr, col_cs, row_cs, tile_mask);
+                                   rect, tiles_touched, depth, okeys, ovals, n_dev, st, nullptr, col_cs, row_cs, tile_mask,
+                                   nullptr, nullptr, nullptr, block_box);
     if (rc) return rc;
     return launch_depth_order_scan(N, depth, tiles_touched, order, offsets, total_out, scratch, scratch_bytes, 1, st);
 }
@@ -180,38 +184,50 @@ size_t sls_block_mask_bytes(uint64_t R, int H, int W)
 }
 
 int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec, const int32_t *rect,
-                       const uint32_t *tiles_touched, const uint64_t *tile_mask, const float *depth, const uint32_t *order,
+                       const uint32_t *tiles_touched, const uint64_t *tile_mask, const uint32_t *block_box,
+                       const float *depth, const uint32_t *order,
                        const uint32_t *offsets, const uint32_t *total_dev, uint32_t *tkeys, uint32_t *vals,
                        uint32_t *tkeys_tmp, uint32_t *vals_tmp, void *sort_scratch, size_t sort_scratch_bytes_,
-                       int *sorted_in_tmp, uint64_t *keys64_out, uint32_t *ranges, const float *col_cs,
+                       int *sorted_in_tmp, uint64_t *keys64_out, int list_pairs, const uint32_t **sorted_list,
+                       int *sorted_stride, uint32_t *ranges, const float *col_cs,
                        const float *row_cs, float *allmap, float *pix_state, uint32_t *pix_contrib,
-                       uint32_t *tile_consumed, uint64_t *block_masks, void *stream)
+                       uint32_t *tile_consumed, uint64_t *block_masks, int *block_masks_shape, void *stream)
 {
-    SLS_REQUIRE(cam && sorted_in_tmp && ranges && col_cs && row_cs && allmap && pix_state && pix_contrib,
+    SLS_REQUIRE(cam && sorted_in_tmp && sorted_list && sorted_stride && ranges && col_cs && row_cs && allmap &&
+                    pix_state && pix_contrib,
                 "null pointer");
     SLS_REQUIRE(R == 0 || (rec && rect && tiles_touched && depth && order && offsets && total_dev && tkeys && vals &&
                            tkeys_tmp && vals_tmp && sort_scratch),
                 "null pointer");
     SLS_REQUIRE(R < (1ull << 32), "more than 2^32 tile instances");
+    SLS_REQUIRE(list_pairs >= 0 && list_pairs <= 2, "list_pairs: 0 auto, 1 whenever possible, 2 never");
     hipStream_t st = (hipStream_t)stream;
     const DevCam dc = make_devcam(*cam);
-    const uint2 *bmask = nullptr;     // (per-instance block masks in list order: a passenger of the tile sort)
+    // With the surfels' block boxes the tile sort delivers (surfel, block mask) pairs in list order and the forward
+    // runs its dense rounds — the kernels of sls_mapping_step, under the same long-list rule (R is exact here)
+    const uint2 *bmask = nullptr;
+    const bool default_kernels = debug_state().fwd_variant == 3;
     int rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched,
-                             cam->tile_cull_min != 1 ? tile_mask : nullptr, nullptr, depth, offsets, tkeys, vals,
+                             dc.tile_cull ? tile_mask : nullptr, nullptr, depth, offsets, tkeys, vals,
                              tkeys_tmp, vals_tmp, sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges,
-                             keys64_out, nullptr, st, nullptr, nullptr, nullptr, &bmask);   // (no block boxes in the staged API: bmask stays null)
+                             keys64_out, nullptr, st, nullptr, nullptr,
+                             (default_kernels && !keys64_out) ? block_box : nullptr, &bmask, list_pairs);
     if (rc) return rc;
     const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
+    *sorted_list = bmask ? (const uint32_t *)bmask : sorted_vals;
+    *sorted_stride = bmask ? 2 : 1;
+    if (block_masks_shape) *block_masks_shape = block_masks ? (int)debug_state().fwd_variant : 0;
     return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
                              tile_consumed, st, false, block_masks, false, nullptr, bmask);
 }
 
 int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
                  const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
-                 const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
+                 const uint32_t *vals_sorted, int vals_stride, const float *col_cs, const float *row_cs,
+                 const float *pix_state,
                  const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, float *dL_dmeans3D,
                  float *dL_dscales, float *dL_drotations, float *dL_dopacities, const uint64_t *block_masks,
-                 void *stream)
+                 int block_masks_shape, void *stream)
 {
     SLS_REQUIRE(cam, "null pointer");
     SLS_REQUIRE(N >= 0, "negative N");
@@ -219,6 +235,7 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
     SLS_REQUIRE(means3D && scales && rotations && radii && grec && dL_dmeans3D && dL_dscales && dL_drotations &&
                     dL_dopacities,
                 "null pointer");
+    SLS_REQUIRE(vals_stride == 1 || vals_stride == 2, "vals_stride: 1 (plain list) or 2 ((surfel, block mask) pairs)");
     hipStream_t st = (hipStream_t)stream;
     const DevCam dc = make_devcam(*cam);
     {
@@ -229,7 +246,8 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
         SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   grec, st, block_masks);
+                                   grec, st, block_masks_shape ? block_masks : nullptr, false, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, vals_stride, block_masks_shape);
         if (rc) return rc;
     }
     return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, grec, dL_dmeans3D,
@@ -240,10 +258,11 @@ size_t sls_backward_det_scratch_bytes(int N) { return N > 0 ? (size_t)N * SLS_GR
 
 int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
                      const float *rotations, const int32_t *radii, const float *rec, const uint32_t *ranges,
-                     const uint32_t *vals_sorted, const float *col_cs, const float *row_cs, const float *pix_state,
+                     const uint32_t *vals_sorted, int vals_stride, const float *col_cs, const float *row_cs,
+                     const float *pix_state,
                      const uint32_t *pix_contrib, const float *dL_dallmap, float *dL_dmeans3D, float *dL_dscales,
-                     float *dL_drotations, float *dL_dopacities, const uint64_t *block_masks, void *det_scratch,
-                     size_t det_scratch_bytes, void *stream)
+                     float *dL_drotations, float *dL_dopacities, const uint64_t *block_masks, int block_masks_shape,
+                     void *det_scratch, size_t det_scratch_bytes, void *stream)
 {
     SLS_REQUIRE(cam, "null pointer");
     SLS_REQUIRE(N >= 0, "negative N");
@@ -251,6 +270,7 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
     SLS_REQUIRE(means3D && scales && rotations && radii && det_scratch && dL_dmeans3D && dL_dscales && dL_drotations &&
                     dL_dopacities,
                 "null pointer");
+    SLS_REQUIRE(vals_stride == 1 || vals_stride == 2, "vals_stride: 1 (plain list) or 2 ((surfel, block mask) pairs)");
     if (det_scratch_bytes < sls_backward_det_scratch_bytes(N)) {
         set_error("deterministic-backward scratch too small");
         return SLS_E_SCRATCH;
@@ -264,7 +284,8 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
         SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   nullptr, st, block_masks, false, nullptr, nullptr, mx, acc);
+                                   nullptr, st, block_masks_shape ? block_masks : nullptr, false, nullptr, nullptr, mx, acc,
+                                   nullptr, vals_stride, block_masks_shape);
         if (rc) return rc;
     }
     AdamFuse fuse;
@@ -302,6 +323,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_REQUIRE(!cfg->apply_adam || (exp_avg && exp_avg_sq && adam_step >= 1), "Adam state missing");
     SLS_REQUIRE(R_capacity > 0 && R_capacity < (1ull << 32), "bad instance capacity");
     SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    // (every argument check before the first launch: an argument error must not leave half an iteration on the stream)
+    SLS_REQUIRE(!cfg->grad_bitmap || (!cfg->apply_adam && !cfg->grad_chunk),
+                "the gradient bitmap belongs to apply_adam = 0 with the flat bucket");
+    SLS_REQUIRE(!cfg->grad_chunk ||
+                    (!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
+                     (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&
+                     (uint64_t)10 * (uint64_t)N < (1ull << 32)),
+                "reduce-scatter gradient layout: apply_adam = 0, even N, chunk a multiple of 4 covering 10 N");
     const int H = cam->H, W = cam->W;
     const MapWs w = carve(N, H, W, R_capacity, workspace, cfg->deterministic != 0);
     if (workspace_bytes < w.total) {
@@ -352,7 +381,9 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                          (debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3) ? w.sbox : nullptr, &bmask,
                          cfg->block_masks);
     if (rc) return rc;
-    const uint32_t *sorted_vals = in_tmp ? w.vals_tmp : w.vals;
+    // (with the pairs the plain value arrays are not written: the list IS the pairs, two words apart)
+    const uint32_t *sorted_vals = bmask ? (const uint32_t *)bmask : (in_tmp ? w.vals_tmp : w.vals);
+    const int vals_stride = bmask ? 2 : 1;
     rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
                            nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
                            cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
@@ -379,7 +410,8 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
     rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                            w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
-                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order);
+                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
+                           vals_stride, (int)debug_state().fwd_variant);
     if (rc) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
@@ -398,15 +430,10 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.void_count = 1; fuse.void_stride = 0;
     if (det) { fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc; }
     if (cfg->grad_bitmap) {
-        SLS_REQUIRE(!cfg->apply_adam && !cfg->grad_chunk, "the gradient bitmap belongs to apply_adam = 0 with the flat bucket");
         fuse.grad_bitmap = cfg->grad_bitmap;
         fuse.grad_bitmap_words = (N + 63) / 64;
     }
     if (cfg->grad_chunk) {
-        SLS_REQUIRE(!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
-                        (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&
-                        (uint64_t)10 * (uint64_t)N < (1ull << 32),
-                    "reduce-scatter gradient layout: apply_adam = 0, even N, chunk a multiple of 4 covering 10 N");
         fuse.gchunk = cfg->grad_chunk;
         fuse.gbase = grads;
         fuse.void_flags = grads + cfg->grad_chunk;

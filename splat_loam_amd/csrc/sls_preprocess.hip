@@ -487,10 +487,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 af.void_flags[(size_t)g * af.void_stride + 1] = (bits & ~1u) ? 1.0f : 0.0f;
             }
         }
-        if (af.status_mirror) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(af.status_src[k], af.status_mirror + k);
-        }
+        if (af.status_mirror) mirror_status_block(af.status_src, af.status_mirror);
         if (af.grad_bitmap) {   // sparse exchange: this rank's verdict behind the bitmap (OR-reduced with the bitmap)
             const uint32_t bits = af.status_src[1];
             af.grad_bitmap[af.grad_bitmap_words] = (bits & 1u) ? 1ull : 0ull;

@@ -713,7 +713,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
     uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
-    uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order)
+    uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order,
+    int vstride)
 {
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
     SLS_TRACE_BEGIN();
@@ -921,14 +922,17 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         }
     } else if (tmax > 0) {
         // ---- no list from a forward of this block shape: rounds of 64 consecutive list entries, culled here
+        // (the list: surfel indices `vstride` words apart — 2 where the tile sort delivered (surfel, block mask) pairs)
         const int nr = (tmax + 63) / 64;
         if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (lane == 0) s_gidx[64] = 0u;
         SLS_STAGE_DECL
-        SLS_WSTAGE_LOAD_IDX(range.x, nr - 1, tmax)
+#define SLS_SIDX1(i_, r_) vals[(size_t)(range.x + (uint32_t)min((r_) * 64 + ((i_) * 64 + lane) / kRec4, tmax - 1)) * (size_t)vstride]
+#define SLS_SSTAGE_LOAD_IDX(r_) si0 = SLS_SIDX1(0, r_); si1 = SLS_SIDX1(1, r_); si2 = SLS_SIDX1(2, r_); si3 = SLS_SIDX1(3, r_); si4 = SLS_SIDX1(4, r_);
+        SLS_SSTAGE_LOAD_IDX(nr - 1)
         SLS_WSTAGE_LOAD_REC()
-        uint32_t next_idx = vals[range.x + (uint32_t)min((nr - 1) * 64 + lane, tmax - 1)];   // surfel of entry (r*64 + lane)
-        if (nr > 1) { SLS_WSTAGE_LOAD_IDX(range.x, nr - 2, tmax) }
+        uint32_t next_idx = vals[(size_t)(range.x + (uint32_t)min((nr - 1) * 64 + lane, tmax - 1)) * (size_t)vstride];   // surfel of entry (r*64 + lane)
+        if (nr > 1) { SLS_SSTAGE_LOAD_IDX(nr - 2) }
         for (int r = nr - 1; r >= 0; --r) {
             SLS_WSTAGE_STORE()
             SLS_TRACE_ROUND();
@@ -936,8 +940,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             s_gidx[lane] = my_idx;
             if (r > 0) {
                 SLS_WSTAGE_LOAD_REC()
-                next_idx = vals[range.x + (uint32_t)((r - 1) * 64 + lane)];
-                if (r > 1) { SLS_WSTAGE_LOAD_IDX(range.x, r - 2, tmax) }
+                next_idx = vals[(size_t)(range.x + (uint32_t)((r - 1) * 64 + lane)) * (size_t)vstride];
+                if (r > 1) { SLS_SSTAGE_LOAD_IDX(r - 2) }
             }
             const int cnt = min(64, tmax - r * 64);
             const uint32_t c_lo = (uint32_t)(r * 64 + 1);
@@ -959,6 +963,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 blend_step(j, (uint32_t)(r * 64 + j + 1));
             }
         }
+#undef SLS_SIDX1
+#undef SLS_SSTAGE_LOAD_IDX
     }
 
     if (dbg_cycles && lane == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
@@ -1019,7 +1025,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
-                            const uint32_t *block_order)
+                            const uint32_t *block_order, int vals_stride, bool dense)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -1033,15 +1039,13 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
         ca = *fused_consumer;
         cblocks = ((ca.W + 63) / 64) * ((ca.H + 3) / 4);
     }
-    // The forward's compact lists are walked if they come from a forward of THIS block shape (the variants are a
-    // process-wide debug setting: equal at this moment means equal when the forward ran, in everything but a test
-    // that switches them in between — the kernel checks the buffer's tag); otherwise the backward culls for itself.
-    const bool dense = block_masks != nullptr && debug_state().fwd_variant == debug_state().bwd_variant;
+    // `dense`: the forward's compact lists come from a forward of THIS block shape (the caller carries the producer's
+    // shape next to the buffer; the kernel checks the buffer's tag as a last guard); otherwise the backward culls.
 #define SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, DENSE_)                                                        \
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_, DENSE_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order)
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride)
 #define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
     do { if (dense) SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, true); else SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, false); } while (0)
     if (det_max) {

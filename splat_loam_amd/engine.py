@@ -149,7 +149,7 @@ class MappingEngine:
         # keyframe-parallel exchange (set up at the first sharded step)
         self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
         self._dp = None                   # dict(G, rank, C, flat, gshard) once the reduce-scatter layout is in place
-        self._dp_agreed, self._dp_use_rs = None, False    # (G, rank) the scheme was agreed for; the agreed verdict
+        self._dp_agreed, self._dp_use_rs, self._dp_scheme = None, False, 0    # (G, rank) the scheme was agreed for; the agreed verdict
         from .rasterizer import deterministic_mode
         self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
         self.block_masks = int(os.environ.get("SLS_BLOCK_MASKS", "0"))   # 0: auto (long lists), 1: always, 2: never (SlsMappingConfig.block_masks)
@@ -465,7 +465,11 @@ class MappingEngine:
 
     def flush(self):
         """Drains the lagged pipeline: returns the status of the LAST iteration (None if there was none);
-        `self.flushed` lists every status that had not been handed out yet, oldest first."""
+        `self.flushed` lists every status that had not been handed out yet, oldest first.
+        NOT a stream synchronisation: with the polled status mirror the host learns an iteration's status from the
+        FIRST thread of its last kernel, so that kernel (the Adam update) may still be running when this returns.
+        Whatever reads the parameters next through torch is ordered behind it on the stream; a caller that hands
+        the pointers to something else synchronises the stream itself."""
         if self._lag_pending is not None:
             prev, self._lag_pending = self._lag_pending, None
             self._lag_collect(prev, redo_current=False)
@@ -484,7 +488,25 @@ class MappingEngine:
                 raise RuntimeError("the process group changed under an engine whose optimiser state is sharded "
                                    f"({self._dp['G']} ranks -> {G}): build a new engine (or remap(reset_state=True))")
             return
-        if self.dp_mode == "sparse":
+        if self._dp_agreed != (G, rank):
+            # every rank must run the SAME collective sequence: agree on the scheme once instead of trusting that
+            # SLS_DP_MODE / N agree everywhere — MIN and MAX of a mode code (sparse 2, rs_ag 1, allreduce 0; a rank
+            # that cannot shard asks for allreduce): sparse only if EVERY rank asks for it, a mix of sparse and a
+            # dense scheme is an error on every rank (different collectives would hang), rs_ag needs all ranks able
+            want = 2 if self.dp_mode == "sparse" else (1 if (self.dp_mode == "rs_ag" and N % 2 == 0 and 10 * N < 2 ** 32) else 0)
+            t = torch.tensor([want, -want], dtype=torch.int32, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            lo, hi = int(t[0].item()), -int(t[1].item())
+            if hi == 2 and lo != 2:
+                raise RuntimeError("keyframe-parallel ranks disagree on the gradient exchange: some ask for dp_mode "
+                                   "'sparse', others for a dense scheme (check SLS_DP_MODE on every rank)")
+            self._dp_use_rs = lo == 1
+            self._dp_agreed = (G, rank)
+            self._dp_scheme = lo
+        if self._dp_scheme == 2:
+            if self._sx is not None and (self._sx["G"], self._sx["rank"]) != (G, rank):
+                raise RuntimeError("the process group changed under an engine set up for the sparse exchange "
+                                   f"({self._sx['G']} ranks -> {G}): build a new engine (or remap())")
             if self._sx is None:
                 lib = _abi.lib()
                 nw = int(lib.sls_grad_bitmap_words(N))
@@ -493,16 +515,9 @@ class MappingEngine:
                             "all": torch.zeros((G * nw,), dtype=torch.int64, device=self.dev),      # every rank's
                             "prefix": torch.zeros((nw,), dtype=torch.int32, device=self.dev),
                             "compact": torch.zeros((10 * N,), dtype=torch.float32, device=self.dev),
-                            "send": N}          # slots handed to the SUM collective: all of them until the union's size is known
+                            "send": N,          # slots handed to the SUM collective: all of them until the union's size is known
+                            "G": G, "rank": rank}
             return
-        if self._dp_agreed != (G, rank):
-            # every rank must run the SAME collective sequence: agree on the scheme once (MIN over ranks of
-            # "this rank can and wants to shard"), instead of trusting that SLS_DP_MODE / N agree everywhere
-            want = 1 if (self.dp_mode == "rs_ag" and N % 2 == 0 and 10 * N < 2 ** 32) else 0
-            t = torch.tensor([want], dtype=torch.int32, device=self.dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-            self._dp_use_rs = bool(int(t.item()))
-            self._dp_agreed = (G, rank)
         if not self._dp_use_rs:
             return
         C = dp_chunk(N, G)

@@ -48,9 +48,10 @@ def pix_offset() -> tuple:
     global _PIX_OFFSET
     if _PIX_OFFSET is None:
         env = os.environ.get("SLS_PIX_OFFSET", "")
-        _PIX_OFFSET = tuple(float(v) for v in env.split(",")) if env else (0.0, 0.0)
-        if len(_PIX_OFFSET) != 2:
+        parsed = tuple(float(v) for v in env.split(",")) if env else (0.0, 0.0)
+        if len(parsed) != 2:                     # (validated before it is cached: a malformed value raises every time)
             raise ValueError("SLS_PIX_OFFSET must be 'ox,oy'")
+        _PIX_OFFSET = parsed
     return _PIX_OFFSET
 
 
@@ -142,13 +143,23 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 class ForwardState:
     """Everything the backward (and the tests) need from one forward."""
-    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "tmask", "depth", "order", "offsets", "keys", "vals",
-                 "ranges", "pix_state", "pix_contrib", "tile_consumed", "block_masks", "allmap")
+    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "tmask", "sbox", "depth", "order", "offsets", "keys",
+                 "vals", "vals_ptr", "vals_stride", "sort_scratch", "ranges", "pix_state", "pix_contrib", "tile_consumed",
+                 "block_masks", "block_masks_shape", "allmap")
+
+
+def list_pairs_mode() -> int:
+    """Process default of sls_forward_stage2's `list_pairs` (SLS_BLOCK_MASKS, the engine's switch): 0 = the sorted
+    list comes as (surfel, block mask) pairs — and the forward runs its dense rounds — where a tile's list averages
+    1500 entries or more, 1 = whenever possible, 2 = never."""
+    return int(os.environ.get("SLS_BLOCK_MASKS", "0"))
 
 
 def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
-                      want_keys: bool = False) -> ForwardState:
-    """preprocess -> depth order -> scan -> [host reads R] -> binning -> stable sort by tile -> ranges -> render."""
+                      want_keys: bool = False, list_pairs: Optional[int] = None) -> ForwardState:
+    """preprocess -> depth order -> scan -> [host reads R] -> binning -> stable sort by tile -> ranges -> render.
+    `want_keys` (tests): also the 64-bit keys (tile << 32 | depth bits) the list is ordered by, derived here from the
+    list, the ranges and the depths, so that the kernels under test are the production ones."""
     for name, t in (("means3D", means3D), ("opacities", opacities), ("scales", scales), ("rotations", rotations)):
         _need_cuda(t, name)
     lib = _abi.lib()
@@ -178,6 +189,7 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.rect = torch.empty((N, 4), dtype=i32, device=dev)
     s.tiles = torch.empty((N,), dtype=u32, device=dev)
     s.tmask = torch.empty((N,), dtype=torch.int64, device=dev)     # D10: which tiles of the rectangle are emitted
+    s.sbox = torch.empty((N,), dtype=u32, device=dev)              # the surfels' block boxes (for the list's block masks)
     s.depth = torch.empty((N,), dtype=f32, device=dev)
     s.order = torch.empty((N,), dtype=u32, device=dev)
     s.offsets = torch.empty((N,), dtype=u32, device=dev)
@@ -187,7 +199,8 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                       opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
                                       s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
-                                      s.tiles.data_ptr(), s.tmask.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(),
+                                      s.tiles.data_ptr(), s.tmask.data_ptr(), s.sbox.data_ptr(), s.depth.data_ptr(),
+                                      s.order.data_ptr(), s.offsets.data_ptr(),
                                       total.data_ptr(), scratch1.data_ptr(), sb, st), "sls_forward_stage1")
     dbg()
     R = int(total.item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
@@ -195,33 +208,53 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     Ra = max(R, 1)
     keys_a = torch.empty((Ra,), dtype=u32, device=dev)
     keys_b = torch.empty((Ra,), dtype=u32, device=dev)
-    keys64 = torch.empty((Ra,), dtype=torch.int64, device=dev) if want_keys else None
     vals_a = torch.empty((Ra,), dtype=u32, device=dev)
     vals_b = torch.empty((Ra,), dtype=u32, device=dev)
     ssb = int(lib.sls_sort_scratch_bytes(R))
-    sort_scratch = torch.empty((max(ssb, 4),), dtype=torch.uint8, device=dev)
+    s.sort_scratch = torch.empty((max(ssb, 4),), dtype=torch.uint8, device=dev)
     s.ranges = torch.empty((T, 2), dtype=u32, device=dev)
     s.allmap = torch.empty((7, H, W), dtype=f32, device=dev)
     s.pix_state = torch.empty((H * W, 4), dtype=f32, device=dev)
     s.pix_contrib = torch.empty((H * W, 2), dtype=u32, device=dev)
     s.tile_consumed = torch.empty((T,), dtype=u32, device=dev)
-    s.block_masks = torch.empty((int(lib.sls_block_mask_bytes(R, H, W)) // 8,), dtype=torch.int64, device=dev)
-    in_tmp = C.c_int(0)
+    # forward -> backward hand-over: 128 B per instance of capacity (room for every list entry in each of a tile's 16
+    # pixel blocks; only what contributes is written).  SLS_NO_HANDOVER=1 (memory-tight callers): no buffer, the
+    # backward culls the tiles' lists itself (about a third slower at the mapper's sizes).
+    s.block_masks = None if os.environ.get("SLS_NO_HANDOVER", "0") == "1" else \
+        torch.empty((int(lib.sls_block_mask_bytes(R, H, W)) // 8,), dtype=torch.int64, device=dev)
+    in_tmp, stride, shape = C.c_int(0), C.c_int(1), C.c_int(0)
+    lst = C.c_void_p(0)
     _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
-                                      s.tmask.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(), s.offsets.data_ptr(), total.data_ptr(),
+                                      s.tmask.data_ptr(), s.sbox.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(),
+                                      s.offsets.data_ptr(), total.data_ptr(),
                                       keys_a.data_ptr(), vals_a.data_ptr(), keys_b.data_ptr(), vals_b.data_ptr(),
-                                      sort_scratch.data_ptr(), ssb, C.byref(in_tmp),
-                                      keys64.data_ptr() if want_keys else None, s.ranges.data_ptr(),
+                                      s.sort_scratch.data_ptr(), ssb, C.byref(in_tmp), None,
+                                      list_pairs_mode() if list_pairs is None else int(list_pairs),
+                                      C.byref(lst), C.byref(stride), s.ranges.data_ptr(),
                                       ce.col_cs.data_ptr(),
                                       ce.row_cs.data_ptr(), s.allmap.data_ptr(), s.pix_state.data_ptr(),
-                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(), s.block_masks.data_ptr(), st),
+                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(),
+                                      s.block_masks.data_ptr() if s.block_masks is not None else None,
+                                      C.byref(shape), st),
                "sls_forward_stage2")
     dbg()
-    s.vals = vals_b if in_tmp.value else vals_a
-    s.keys = keys64        # 64-bit (tile << 32 | depth bits) keys, only when asked for (tests)
+    s.vals_stride, s.block_masks_shape = int(stride.value), int(shape.value)
+    if s.vals_stride == 2:
+        # the list is the tile sort's (surfel, block mask) pairs inside the sort scratch: a strided view of it
+        off = int(lst.value) - s.sort_scratch.data_ptr()
+        s.vals = s.sort_scratch[off:off + 8 * Ra].view(torch.int32).view(Ra, 2)[:, 0]
+    else:
+        s.vals = vals_b if in_tmp.value else vals_a
+        s.sort_scratch = None
+    s.vals_ptr = int(lst.value) if R > 0 else s.vals.data_ptr()
     if R == 0:
         s.vals = s.vals[:0]
-        s.keys = keys64[:0] if want_keys else None
+    s.keys = None
+    if want_keys:   # (tile << 32 | depth bits) of every list entry, from the ranges, the list and the depths
+        cnt = (s.ranges[:, 1].long() - s.ranges[:, 0].long()) & 0xFFFFFFFF
+        tile = torch.repeat_interleave(torch.arange(T, device=dev, dtype=torch.int64), cnt)
+        bits = s.depth.view(torch.int32)[s.vals.long()].long() & 0xFFFFFFFF
+        s.keys = (tile << 32) | bits
     return s
 
 
@@ -242,24 +275,26 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
     drots = torch.empty((N, 4), dtype=f32, device=dev)
     dopac = torch.empty((N, 1), dtype=f32, device=dev)
     ce = state.cam
+    bm = state.block_masks.data_ptr() if state.block_masks is not None else None
     if deterministic_mode() if deterministic is None else deterministic:
         nbytes = int(lib.sls_backward_det_scratch_bytes(N))
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         _abi.check(lib.sls_backward_det(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
                                         rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
-                                        state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
+                                        state.ranges.data_ptr(), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
                                         ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
                                         dL.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(), drots.data_ptr(),
-                                        dopac.data_ptr(), state.block_masks.data_ptr(), scratch.data_ptr(), nbytes,
-                                        _stream(dev)), "sls_backward_det")
+                                        dopac.data_ptr(), bm, state.block_masks_shape,
+                                        scratch.data_ptr(), nbytes, _stream(dev)), "sls_backward_det")
         return dmeans, dscales, drots, dopac, None
     grec = torch.empty((N, lib.sls_grec_stride()), dtype=f32, device=dev)
     _abi.check(lib.sls_backward(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
                                 rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
-                                state.ranges.data_ptr(), state.vals.data_ptr(), ce.col_cs.data_ptr(),
+                                state.ranges.data_ptr(), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
                                 ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
                                 dL.data_ptr(), grec.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(),
-                                drots.data_ptr(), dopac.data_ptr(), state.block_masks.data_ptr(), _stream(dev)),
+                                drots.data_ptr(), dopac.data_ptr(), bm,
+                                state.block_masks_shape, _stream(dev)),
                "sls_backward")
     return dmeans, dscales, drots, dopac, grec
 

@@ -163,15 +163,20 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("list_pairs", [2, 1], ids=["plain-list", "pairs-dense"])
 @pytest.mark.parametrize("name,N,H,W,kw", CASES, ids=[c[0] for c in CASES])
-def test_forward_backward_parity(device, oracle32, name, N, H, W, kw):
+def test_forward_backward_parity(device, oracle32, name, N, H, W, kw, list_pairs):
+    """The drop-in interface (sls_forward_stage1/2 + sls_backward) against the checker, with the sorted list as a
+    plain array (forward in rounds of 64 list entries) and as the tile sort's (surfel, block mask) pairs (forward in
+    dense rounds: the kernels of sls_mapping_step; not possible beyond 2048 tiles, where the list stays plain)."""
     kw = dict(kw)
     hfov = kw.pop("hfov_deg", 360.0)
     sc, view, proj = scene_and_camera(N, H, W, seed=11, hfov_deg=hfov, **kw)
     if name == "dense_near":
         from splat_loam_amd import synth
         view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(3)[2])
-    st, t = hip_forward(device, sc, view, proj, H, W)
+    st, t = hip_forward(device, sc, view, proj, H, W, list_pairs=list_pairs)
+    assert st.vals_stride == (2 if (list_pairs == 1 and name != "many_tiles" and st.R > 0) else 1)
     from splat_loam_amd import _abi
     cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
     ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
@@ -360,16 +365,17 @@ def test_full_size_properties(device):
     tile_ids = (keys >> np.uint64(32)).astype(np.int64)
     cnt = np.bincount(tile_ids, minlength=rng.shape[0])
     assert np.array_equal((rng[:, 1] - rng[:, 0]).astype(np.int64), cnt), "ranges partition the list"
-    # production path (no 64-bit keys asked for): ranges come from the tile sort's digit bases,
-    # the sorted tile ids are never written -> same list, same ranges, same image
+    # hip_forward IS the production path of the drop-in interface: ranges from the tile sort's digit bases, and at this
+    # size (R >= 1500 instances per tile) the list as (surfel, block mask) pairs with the forward in dense rounds —
+    # the kernels sls_mapping_step runs.  Against it: the same forward with plain lists and rounds of 64 entries.
+    assert st.vals_stride == 2 and st.block_masks_shape == 3, "C3 through the staged API runs the dense forward"
     from splat_loam_amd.rasterizer import GaussianRasterizationSettings, rasterize_forward
     s2 = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device))
-    st2 = rasterize_forward(s2, t["means"], t["opac"], t["scales"], t["rots"])
-    assert st2.R == st.R and np.array_equal(u32(st2.vals), vals), "fused-ranges path: same sorted list"
-    assert np.array_equal(u32(st2.ranges).reshape(-1, 2), rng), "fused-ranges path: same ranges"
-    # (the two paths may run different forward kernels — dense rounds from the tile sort's block masks in the production
-    #  path, rounds of 64 list entries where the 64-bit keys were asked for: same entries in the same order, but a
-    #  pixel's four partial sums are split differently over the steps)
+    st2 = rasterize_forward(s2, t["means"], t["opac"], t["scales"], t["rots"], list_pairs=2)
+    assert st2.vals_stride == 1
+    assert st2.R == st.R and np.array_equal(u32(st2.vals), vals), "plain-list path: same sorted list"
+    assert np.array_equal(u32(st2.ranges).reshape(-1, 2), rng), "plain-list path: same ranges"
+    # (same entries in the same order, but a pixel's four partial sums are split differently over the steps)
     scale = st.allmap.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-12)
     assert ((st2.allmap - st.allmap).abs() / scale).max().item() <= 2e-6
     assert torch.equal(st2.pix_contrib, st.pix_contrib)
@@ -749,13 +755,34 @@ def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, 
     try:
         N, H, W = 20000, 64, 512
         sc, view, proj = scene_and_camera(N, H, W, seed=21, range_lo=2.0, range_hi=30.0)
-        st, t = hip_forward(device, sc, view, proj, H, W)
+        # (pairs wherever the forward can use them: the 8x2 forward then hands the 4x4 backward a list two words apart)
+        st, t = hip_forward(device, sc, view, proj, H, W, list_pairs=1)
+        assert st.vals_stride == (2 if fwd_variant == 3 else 1) and st.block_masks_shape == fwd_variant
         cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
         ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
         _compare_forward(oracle32, st, ost, cam, f"variant{fwd_variant}")
         _compare_backward(oracle32, st, t, ost, sc, f"variant{bwd_variant}")
     finally:
         lib.sls_debug_variant(3, 3)
+
+
+def test_backward_after_the_variants_changed(device, oracle32):
+    """a forward at 4x4 pixel blocks, then BOTH variants switched to 8x2 before the backward.  The
+    hand-over buffer was written by another block shape: the backward must cull for itself (the state carries the
+    producer's shape), not walk — or silently skip — a list that is not its own."""
+    from splat_loam_amd import _abi
+    lib = _abi.lib()
+    N, H, W = 8000, 32, 512
+    sc, view, proj = scene_and_camera(N, H, W, seed=22, range_lo=2.0, range_hi=20.0)
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    lib.sls_debug_variant(2, 2)
+    try:
+        st, t = hip_forward(device, sc, view, proj, H, W)
+        assert st.block_masks_shape == 2
+    finally:
+        lib.sls_debug_variant(3, 3)
+    _compare_backward(oracle32, st, t, ost, sc, "fwd4x4-then-8x2")
 
 
 def _engine_rank(rank, world, port, out_dir, mode="sync", dp_mode="rs_ag"):

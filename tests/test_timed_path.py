@@ -82,6 +82,27 @@ def _raw_scene(N, H, W, seed, hfov_deg=360.0, **kw):
 ], ids=["small", "c2", "ragged-no-wrap"])
 @pytest.mark.parametrize("block_masks", [2, 1], ids=["window-rounds", "dense-rounds"])
 def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw, block_masks):
+    _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed=23)
+
+
+def test_engine_gradients_match_checker_chain_c3(device, oracle32):
+    """the instantiations bench.py TIMES at the size it times them — BASELINE config 3, the bench
+    scene itself (500 000 surfels, 64x2048, seed 0), `block_masks = 0`: the automatic rule switches the tile sort to
+    (surfel, block mask) pairs (2400-entry lists, the forward's 320-entry ring wrapping many times, 9-round blocks),
+    i.e. render_fwd_dense_kernel<8,2,false,LEAN>, render_bwd_block_kernel<8,2,LEAN,FUSED,0,DENSE> and the fused
+    Adam of sls_mapping_step against the checker chain, the checker on every host thread."""
+    import oracle.torch_function as otf
+    oracle32.set_threads(oracle32.max_threads())
+    otf.BACKWARD_THREADS = oracle32.max_threads()
+    try:
+        eng = _check_engine_against_checker_chain(device, "c3_500k_64x2048", 500000, 64, 2048, {}, 0, seed=0)
+    finally:
+        otf.BACKWARD_THREADS = 1
+    # the automatic rule did choose the dense kernels: capacity >= 1500 instances per tile
+    assert eng.capacity >= 1500 * (64 // 16) * (2048 // 16)
+
+
+def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed):
     """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
     chain.  Two comparisons:
       * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
@@ -92,7 +113,7 @@ def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw, block_m
     Element-wise: every gradient entry above 1e-3 of its tensor's maximum agrees to 2e-3 relative."""
     from splat_loam_amd import synth
     from splat_loam_amd.mapping import MappingConfig
-    sc, raw, depth, valid = _raw_scene(N, H, W, seed=23, **kw)
+    sc, raw, depth, valid = _raw_scene(N, H, W, seed=seed, **kw)
     valid = valid.copy(); valid[0, :2, :9] = 0
     pose = synth.keyframe_poses(2)[1]
     view, proj = synth.camera_matrices(sc["K"], pose)
@@ -132,6 +153,7 @@ def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw, block_m
         sure = np.abs(gg) > 1e-6 * np.abs(gg).max()
         step = p.detach().cpu().numpy() - raw[k]
         assert np.allclose(step[sure], (-lrs[k] * np.sign(gg))[sure], rtol=1e-3, atol=1e-9), k
+    return eng
 
 
 def test_g5_reference_trajectory_through_engine(device):
