@@ -527,27 +527,6 @@ def main():
             sc2 = scene if (n2, h2, w2) == (N, H, W) else synth.make_scene(n2, h2, w2, seed=0)
             d2_, v2_ = (depth, valid) if (n2, h2, w2) == (N, H, W) else synth.make_targets(h2, w2, sc2)
             cam2 = Camera(sc2["K"], d2_, None, v2_, poses[0], data_device=str(dev))
-            res = {}
-            # (i) the rasterizer alone, forward + backward through autograd, dL/dallmap given
-            mdl = SurfelModel.from_activated(sc2["means"], sc2["scales"], sc2["rots"], sc2["opac"], device=str(dev))
-            with torch.no_grad():
-                leaves = [t.detach().clone().requires_grad_(True) for t in
-                          (mdl.get_xyz, mdl.get_opacity, mdl.get_scaling, mdl.get_rotation)]
-            st_ = GaussianRasterizationSettings(h2, w2, 1.0, cam2.world_view_transform, cam2.projection_matrix, False, False)
-            rast = GR(raster_settings=st_)
-            dL = torch.randn((7, h2, w2), device=dev)
-
-            def fb():
-                for t in leaves:
-                    t.grad = None
-                _, am = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), opacities=leaves[1],
-                             scales=leaves[2], rotations=leaves[3], cov3D_precomp=None)
-                am.backward(dL)
-
-            def fwd_only():
-                with torch.no_grad():
-                    rast(means3D=leaves[0], means2D=leaves[0], opacities=leaves[1], scales=leaves[2],
-                         rotations=leaves[3], cov3D_precomp=None)
 
             def timed(fn, n_w, n_t):
                 for _ in range(n_w):
@@ -558,64 +537,56 @@ def main():
                     fn()
                 torch.cuda.synchronize(dev)
                 return (time.perf_counter() - t0) / n_t * 1e3
-            res["rasterizer_fwd_ms"] = round(timed(fwd_only, warm, iters), 4)
-            res["rasterizer_fwd_bwd_ms"] = round(timed(fb, warm, iters), 4)
-            lib.sls_timing_enable(1)
-            for _ in range(10):
-                fb()
-            torch.cuda.synchronize(dev)
-            res["kernels_us"] = {k: round(ms / c * 1e3, 2) for k, (ms, c) in collect().items()}
-            lib.sls_timing_enable(0)
-            del mdl, leaves
-            # (ii) a whole iteration of Mapper.optimize on one keyframe, torch glue as the reference has it
-            for name, fn in (("iteration_torch_glue_ms", lambda m: float(optimize_step(m, cam2, cfg))),
-                             ("iteration_hip_consumer_ms", lambda m: float(optimize_step_fused(m, cam2, cfg)))):
+
+            def one(lean):
+                res = {}
+                # (i) the rasterizer alone, forward + backward through autograd, dL/dallmap given
                 mdl = SurfelModel.from_activated(sc2["means"], sc2["scales"], sc2["rots"], sc2["opac"], device=str(dev))
-                mdl.training_setup(fused=True)
-                res[name] = round(timed(lambda: fn(mdl), warm, iters), 4)
-                del mdl
-            res["Msplats_per_s_torch_glue"] = round(n2 / (res["iteration_torch_glue_ms"] * 1e-3) / 1e6, 1)
-            return res
-        # keyframe-parallel readiness that one GPU can establish: the size of the UNION of the
-        # touched sets — what dp_mode "sparse" puts on the wire — for G = 2, 4, 8 ranks, by rendering the ranks'
-        # keyframes one after another on the same model and OR-ing their non-zero-gradient sets
-        def sparse_union():
-            from splat_loam_amd.fused import fused_loss
-            m = SurfelModel.from_activated(scene["means"], scene["scales"], scene["rots"], scene["opac"], device=str(dev))
-            with torch.no_grad():      # the model as the timed iterations left it
-                for dst, src in zip((m._xyz, m._scaling, m._rotation, m._opacity),
-                                    (model._xyz, model._scaling, model._rotation, model._opacity)):
-                    dst.copy_(src)
-            params = (m._xyz, m._opacity, m._scaling, m._rotation)
-            sets = []
-            for k in range(min(8, n_kf)):
-                for p_ in params:
-                    p_.grad = None
-                fused_loss(m, cams[k], cfg, with_regulariser=(k == 0)).backward()
-                sets.append(torch.cat([p_.grad.reshape(N, -1) for p_ in params], dim=1).ne(0).any(dim=1))
-            out = {"per_keyframe_rows": [int(x.sum().item()) for x in sets]}
-            rng_u = np.random.default_rng(3)
-            for G in (2, 4, 8):
-                if G > len(sets):
-                    continue
-                u = torch.stack(sets[:G]).any(dim=0)
-                rows = int(u.sum().item())
-                drawn = []
-                for _ in range(50):      # ranks drawing their keyframes as the mapper does
-                    ks = rng_u.choice(len(sets), size=G, p=kf_p[:len(sets)] / kf_p[:len(sets)].sum())
-                    drawn.append(int(torch.stack([sets[int(k_)] for k_ in ks]).any(dim=0).sum().item()))
-                out[f"G{G}"] = {"union_rows_window": rows, "bytes_per_rank_window": 40 * rows + G * ((N + 63) // 64) * 8,
-                                "union_rows_sampled_mean": int(np.mean(drawn)), "union_rows_sampled_max": int(np.max(drawn)),
-                                "dense_bytes_per_rank": 40 * N}
-            out["note"] = ("rows = surfels with a non-zero gradient on at least one of the G ranks (rank 0 carries the scale "
-                           "regulariser); window: rank g renders keyframe g of the window (BASELINE config 5); sampled: every "
-                           "rank draws its keyframe with the mapper's probabilities, 50 draws; bytes = 40 B per row SUM-reduced "
-                           "+ the G bitmaps all-gathered; measured on ONE GPU, no collective involved")
-            return out
-        try:
-            extras["sparse_union"] = sparse_union()
-        except Exception as e:      # (a report, never a reason to lose the bench line)
-            extras["sparse_union"] = {"error": str(e)}
+                with torch.no_grad():
+                    leaves = [t.detach().clone().requires_grad_(True) for t in
+                              (mdl.get_xyz, mdl.get_opacity, mdl.get_scaling, mdl.get_rotation)]
+                st_ = GaussianRasterizationSettings(h2, w2, 1.0, cam2.world_view_transform, cam2.projection_matrix,
+                                                    False, False, lean_allmap=lean)
+                rast = GR(raster_settings=st_)
+                dL = torch.randn((7, h2, w2), device=dev)
+                if lean:
+                    dL[5:7] = 0
+
+                def fb():
+                    for t in leaves:
+                        t.grad = None
+                    _, am = rast(means3D=leaves[0], means2D=torch.zeros_like(leaves[0]), opacities=leaves[1],
+                                 scales=leaves[2], rotations=leaves[3], cov3D_precomp=None)
+                    am.backward(dL)
+
+                def fwd_only():
+                    with torch.no_grad():
+                        rast(means3D=leaves[0], means2D=leaves[0], opacities=leaves[1], scales=leaves[2],
+                             rotations=leaves[3], cov3D_precomp=None)
+                res["rasterizer_fwd_ms"] = round(timed(fwd_only, warm, iters), 4)
+                res["rasterizer_fwd_bwd_ms"] = round(timed(fb, warm, iters), 4)
+                lib.sls_timing_enable(1)
+                for _ in range(10):
+                    fb()
+                torch.cuda.synchronize(dev)
+                res["kernels_us"] = {k: round(ms / c * 1e3, 2) for k, (ms, c) in collect().items()}
+                lib.sls_timing_enable(0)
+                del mdl, leaves
+                # (ii) a whole iteration of Mapper.optimize on one keyframe (render() builds its settings itself, as
+                # gaussian_renderer/__init__.py does: the lean kernels are chosen by the process default)
+                os.environ["SLS_LEAN_ALLMAP"] = "1" if lean else "0"
+                try:
+                    for name, fn in (("iteration_torch_glue_ms", lambda m: float(optimize_step(m, cam2, cfg))),
+                                     ("iteration_hip_consumer_ms", lambda m: float(optimize_step_fused(m, cam2, cfg)))):
+                        mdl = SurfelModel.from_activated(sc2["means"], sc2["scales"], sc2["rots"], sc2["opac"], device=str(dev))
+                        mdl.training_setup(fused=True)
+                        res[name] = round(timed(lambda: fn(mdl), warm, iters), 4)
+                        del mdl
+                finally:
+                    os.environ.pop("SLS_LEAN_ALLMAP", None)
+                res["Msplats_per_s_torch_glue"] = round(n2 / (res["iteration_torch_glue_ms"] * 1e-3) / 1e6, 1)
+                return res
+            return {"all_planes": one(False), "lean_allmap": one(True)}
         log("extras: real sizes done")
         extras["dropin"] = {f"{N}_{H}x{W}": dropin(N, H, W, 50, 10), "50000_64x1024": dropin(50_000, 64, 1024, 100, 20),
                             "note": "the path an unmodified slam/mapper.py runs: GaussianRasterizer under torch autograd "
@@ -623,7 +594,10 @@ def main():
                                     "keyframe; rasterizer_*: the rasterizer alone (dL/dallmap given); iteration_torch_glue: "
                                     "render() post-processing + mapper loss as torch ops + FusedAdam + loss.item(); "
                                     "iteration_hip_consumer: the same with sls_consumer_fwd_bwd instead of the torch glue; "
-                                    "kernels_us: HIP-event averages of the library's kernels in rasterizer_fwd_bwd.  "
+                                    "kernels_us: HIP-event averages of the library's kernels in rasterizer_fwd_bwd (every launch "
+                                    "bracketed: a few us above rocprof's); all_planes: the seven-plane contract; lean_allmap: "
+                                    "SLS_LEAN_ALLMAP=1 / settings.lean_allmap — planes 5, 6 not tracked, the kernels of "
+                                    "sls_mapping_step.  "
                                     "Compare with extras.single_keyframe (sls_mapping_step on one keyframe)"}
         extras["note"] = ("same scene, size and keyframe sampling as the headline unless said otherwise; single_keyframe: one "
                           "keyframe re-rendered every iteration; full_sort: depth order sorted from scratch every "

@@ -61,7 +61,12 @@ typedef struct SlsCamera {
     float fx, fy, cx, cy;   /* K = projmatrix[:3,:3]^T : u = fx*az+cx, v = fy*el+cy */
     float scale_modifier;
     float near_cut, far_cut;
-    float pad;
+    uint32_t flags;         /* SLS_CAM_LEAN_ALLMAP (bit 0): the caller neither reads allmap's median / distortion planes
+                             * (5, 6) nor sends a gradient into them — true for the reference's mapper and tracker, which
+                             * run at depth_ratio = 0 and use rend_dist only when meshing
+                             * (gaussian_renderer/__init__.py:65-86, scene/postprocessing.py:167-170).  The staged forward
+                             * then writes zeros there and sls_backward ignores dL/dallmap[5:7]: the kernels
+                             * sls_mapping_step runs.  0 (set by sls_camera_from_matrices): all seven planes. */
     float Rvw[9];           /* row-major: p_view = Rvw * p_world + tvw          */
     float tvw[3];
     float pix_offset[2];    /* D1: pixel (c, r) has image coordinate (c + pix_offset[0], r + pix_offset[1]) in
@@ -73,6 +78,7 @@ typedef struct SlsCamera {
                              * the rasterizer works with the principal point (cx - pix_offset[0],
                              * cy - pix_offset[1]), each rounded once in float. */
 } SlsCamera;
+#define SLS_CAM_LEAN_ALLMAP 1u
 
 const char *sls_last_error(void);
 int sls_version(void);

@@ -20,7 +20,7 @@ class SlsCamera(C.Structure):
     _fields_ = [
         ("H", C.c_int32), ("W", C.c_int32), ("wrap", C.c_int32), ("tile_cull_min", C.c_int32),
         ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-        ("scale_modifier", C.c_float), ("near_cut", C.c_float), ("far_cut", C.c_float), ("pad", C.c_float),
+        ("scale_modifier", C.c_float), ("near_cut", C.c_float), ("far_cut", C.c_float), ("flags", C.c_uint32),
         ("Rvw", C.c_float * 9), ("tvw", C.c_float * 3),
         ("pix_offset", C.c_float * 2),
     ]

@@ -218,7 +218,7 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     *sorted_stride = bmask ? 2 : 1;
     if (block_masks_shape) *block_masks_shape = block_masks ? (int)debug_state().fwd_variant : 0;
     return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                             tile_consumed, st, false, block_masks, false, nullptr, bmask);
+                             tile_consumed, st, false, block_masks, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, bmask);
 }
 
 int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
@@ -246,8 +246,8 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
         SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   grec, st, block_masks_shape ? block_masks : nullptr, false, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr, vals_stride, block_masks_shape);
+                                   grec, st, block_masks_shape ? block_masks : nullptr, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, vals_stride, block_masks_shape);
         if (rc) return rc;
     }
     return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, grec, dL_dmeans3D,
@@ -284,7 +284,8 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
         SLS_REQUIRE(rec && ranges && vals_sorted && col_cs && row_cs && pix_state && pix_contrib && dL_dallmap,
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
-                                   nullptr, st, block_masks_shape ? block_masks : nullptr, false, nullptr, nullptr, mx, acc,
+                                   nullptr, st, block_masks_shape ? block_masks : nullptr,
+                                   (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, nullptr, mx, acc,
                                    nullptr, vals_stride, block_masks_shape);
         if (rc) return rc;
     }

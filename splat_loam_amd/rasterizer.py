@@ -38,6 +38,10 @@ class GaussianRasterizationSettings(NamedTuple):
     pix_offset: Optional[tuple] = None
     # extension: threshold of D10's tile-level footprint test (SlsCamera.tile_cull_min: 0 default, 1 off, k >= 2)
     tile_cull_min: Optional[int] = None
+    # extension: True = the caller neither reads allmap's median / distortion planes (5, 6) nor sends a gradient into
+    # them (the reference's mapper and tracker at depth_ratio = 0): they come back as zeros and the tile kernels do
+    # not track them — the kernels sls_mapping_step runs.  None -> the process default (SLS_LEAN_ALLMAP=1), False
+    lean_allmap: Optional[bool] = None
 
 
 _PIX_OFFSET = None
@@ -99,8 +103,11 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
     tcm = getattr(settings, "tile_cull_min", None)
     if tcm is None:        # A/B switches: SLS_NO_TILE_CULL=1 — D10 off (whole rectangles); SLS_TILE_CULL_MIN=k — threshold
         tcm = 1 if os.environ.get("SLS_NO_TILE_CULL", "0") == "1" else int(os.environ.get("SLS_TILE_CULL_MIN", "0"))
+    lean = getattr(settings, "lean_allmap", None)
+    if lean is None:
+        lean = os.environ.get("SLS_LEAN_ALLMAP", "0") == "1"
     key = (v.data_ptr(), v._version, p.data_ptr(), p._version, int(settings.image_height),
-           int(settings.image_width), float(settings.scale_modifier), off, int(tcm), str(device))
+           int(settings.image_width), float(settings.scale_modifier), off, int(tcm), bool(lean), str(device))
     hit = _CAM_CACHE.get(key)
     if hit is not None:
         _CAM_CACHE.move_to_end(key)
@@ -116,6 +123,7 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
                                                    C.byref(e.cam)), "sls_camera_from_matrices")
     e.cam.pix_offset[0], e.cam.pix_offset[1] = off
     e.cam.tile_cull_min = int(tcm)
+    e.cam.flags = 1 if lean else 0            # SLS_CAM_LEAN_ALLMAP
     e.col_cs, e.row_cs = _ray_tables(e.cam, device)
     e.view_ref, e.proj_ref = v, p
     _CAM_CACHE[key] = e

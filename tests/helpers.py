@@ -20,14 +20,14 @@ def scene_and_camera(N, H, W, seed=0, pose=None, hfov_deg=360.0, **kw):
     return sc, view, proj
 
 
-def hip_forward(device, sc, view, proj, H, W, scale_modifier=1.0, pix_offset=None, tile_cull_min=None, list_pairs=None):
+def hip_forward(device, sc, view, proj, H, W, scale_modifier=1.0, pix_offset=None, tile_cull_min=None, list_pairs=None, lean_allmap=None):
     """The drop-in interface's forward (sls_forward_stage1/2) as GaussianRasterizer runs it, plus the 64-bit keys.
     list_pairs: None = the production rule (dense forward rounds on (surfel, block mask) pairs where the lists are
     long), 1 = pairs whenever possible, 2 = plain lists."""
     settings = GaussianRasterizationSettings(
         image_height=H, image_width=W, scale_modifier=scale_modifier,
         viewmatrix=torch.tensor(view, device=device), projmatrix=torch.tensor(proj, device=device),
-        prefiltered=False, debug=True, pix_offset=pix_offset, tile_cull_min=tile_cull_min)
+        prefiltered=False, debug=True, pix_offset=pix_offset, tile_cull_min=tile_cull_min, lean_allmap=lean_allmap)
     t = {k: torch.tensor(sc[k], device=device) for k in ("means", "scales", "rots", "opac")}
     st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"], want_keys=True, list_pairs=list_pairs)
     torch.cuda.synchronize()
