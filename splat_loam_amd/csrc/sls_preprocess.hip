@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) {
         if (af.reg_accum) {   // the regulariser was summed in the workspace: publish it, leave zero for the next iteration
-            reinterpret_cast<float *>(af.status_src)[6] = *af.reg_accum;
+            af.status_src[6] = __float_as_uint(*af.reg_accum);     // (same type as the mirror's reads below: no aliasing games)
             *af.reg_accum = 0.0f;
         }
         if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM collective

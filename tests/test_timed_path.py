@@ -95,14 +95,27 @@ def test_engine_gradients_match_checker_chain_c3(device, oracle32):
     oracle32.set_threads(oracle32.max_threads())
     otf.BACKWARD_THREADS = oracle32.max_threads()
     try:
-        eng = _check_engine_against_checker_chain(device, "c3_500k_64x2048", 500000, 64, 2048, {}, 0, seed=0)
+        eng = _check_engine_against_checker_chain(device, "c3_500k_64x2048", 500000, 64, 2048, {}, 0, seed=0,
+                                                  mask_fragile=oracle32, repeats=3)
     finally:
         otf.BACKWARD_THREADS = 1
     # the automatic rule did choose the dense kernels: capacity >= 1500 instances per tile
     assert eng.capacity >= 1500 * (64 // 16) * (2048 // 16)
 
 
-def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed):
+def _fragile_neighbourhood(oracle, raw, view, proj, H, W):
+    """Pixels whose image is fragile in the checker (a discrete decision within 1e-4 of its threshold: compared
+    loosely by every forward test) and their 4-neighbours (the normal term's stencil reads them)."""
+    from splat_loam_amd import _abi
+    t = {k: torch.tensor(v) for k, v in raw.items()}
+    cam = oracle.camera(H, W, view, proj, tile=_abi.tile_size())
+    ost = oracle.forward(cam, raw["xyz"], torch.exp(t["scaling"]).numpy(), torch.nn.functional.normalize(t["rotation"]).numpy(),
+                         torch.sigmoid(t["opacity"]).numpy())
+    f = ost["fwd"]["fragile"]
+    return f | np.roll(f, 1, 0) | np.roll(f, -1, 0) | np.roll(f, 1, 1) | np.roll(f, -1, 1)
+
+
+def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1):
     """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
     chain.  Two comparisons:
       * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
@@ -118,9 +131,27 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
     pose = synth.keyframe_poses(2)[1]
     view, proj = synth.camera_matrices(sc["K"], pose)
     cfg = MappingConfig()
-    st, g, am, eng, model, cam = _engine_once(device, raw, sc["K"], pose, depth, valid, cfg, block_masks)
+    if mask_fragile is not None:
+        # at full size a few hundred pixels are fragile: the two sides may take a different discrete decision there, and
+        # in the own-allmap comparison each then differentiates a different function of those pixels.  They (and the
+        # pixels whose normal stencil reads them) are taken out of the loss on BOTH sides, as every forward / backward
+        # parity test zeroes dL/dallmap there.
+        drop = _fragile_neighbourhood(mask_fragile, raw, view, proj, H, W)
+        valid[0, drop] = 0
+        print(f"\n[{name}] {int(drop.sum())} of {H * W} pixels (fragile + their stencil neighbours) taken out of the loss")
+    runs = [_engine_once(device, raw, sc["K"], pose, depth, valid, cfg, block_masks) for _ in range(repeats)]
+    am = runs[0][2]
+    for r in runs[1:]:
+        assert np.array_equal(r[2], am), "the forward has no atomics: every run renders the same image"
     own = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg)
     same = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am)
+    # (float atomics: the gradients vary from run to run — every run has to meet the bar)
+    for k, (st, g, _, eng, model, cam) in enumerate(runs):
+        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same)
+    return runs[0][3]
+
+
+def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same):
     # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image
     for c in range(5):
         scale = max(np.abs(own["allmap"][c]).max(), 1e-12)
@@ -153,7 +184,6 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
         sure = np.abs(gg) > 1e-6 * np.abs(gg).max()
         step = p.detach().cpu().numpy() - raw[k]
         assert np.allclose(step[sure], (-lrs[k] * np.sign(gg))[sure], rtol=1e-3, atol=1e-9), k
-    return eng
 
 
 def test_g5_reference_trajectory_through_engine(device):
