@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "sls_consumer_dev.hpp"
+#include "sls_bin.hpp"
 
 namespace sls {
 
@@ -17,7 +18,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr,
                           const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr,
                           int32_t *erec = nullptr, const uint32_t *resort_prev_order = nullptr,
-                          uint64_t *resort_comp = nullptr, uint32_t *sbox = nullptr);
+                          uint64_t *resort_comp = nullptr, uint32_t *sbox = nullptr, int erec_box = 0);
 uint64_t *resort_comp_buffer(int N, void *scratch);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
@@ -27,15 +28,6 @@ int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int
                           hipStream_t st, const AdamFuse *fuse = nullptr);
 size_t sort_scratch_bytes(uint64_t cap);
 size_t order_scratch_bytes(int N);
-int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
-                            uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
-                            hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr,
-                            struct ScanHandoff *handoff = nullptr, bool window_sort_done = false);
-struct ScanHandoff {
-    const uint32_t *block_sums;
-    int resort_windows;
-    const uint64_t *resort_edges;
-};
 int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_t cap, const uint32_t *order,
                     const int32_t *rect, const uint32_t *tiles, const uint64_t *tile_mask, const int32_t *erec,
                     const float *depth, const uint32_t *offsets,
@@ -69,7 +61,7 @@ int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double be
 // workspace of sls_mapping_step: one caller-owned buffer, carved here
 // ---------------------------------------------------------------------------
 struct MapWs {
-    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; int32_t *erec; uint32_t *sbox; float *depth; uint32_t *order; uint32_t *offsets;
+    float *rec; int32_t *radii; int32_t *rect; uint32_t *tiles; uint64_t *tmask; int32_t *erec; int32_t *serec; uint32_t *sbox; float *depth; uint32_t *order; uint32_t *offsets;
     void *order_scratch; size_t order_scratch_bytes;
     uint32_t *tkeys, *vals, *tkeys_tmp, *vals_tmp; void *sort_scratch; size_t sort_scratch_bytes;
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
@@ -95,6 +87,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.tiles = (uint32_t *)take(n * 4);
     w.tmask = (uint64_t *)take(n * 8);
     w.erec = (int32_t *)take(n * 16);
+    w.serec = (int32_t *)take(n * 16);         // direct binning: the emission records by depth position
     w.sbox = (uint32_t *)take(n * 4);          // block box per surfel (sls_common.hpp: make_block_box)
     w.depth = (float *)take(n * 4);
     w.order = (uint32_t *)take(n * 4);
@@ -207,11 +200,24 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     // runs its dense rounds — the kernels of sls_mapping_step, under the same long-list rule (R is exact here)
     const uint2 *bmask = nullptr;
     const bool default_kernels = debug_state().fwd_variant == 3;
-    int rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched,
+    const uint32_t *boxes = (default_kernels && !keys64_out) ? block_box : nullptr;
+    int rc;
+    if (!keys64_out && R > 0 && bin_direct_possible(dc, N, (uint32_t)R)) {
+        // direct binning (sls_sort.hip), as in sls_mapping_step; the records are gathered from rect / block_box
+        *sorted_in_tmp = 0;
+        if (sort_scratch_bytes_ < sort_scratch_bytes(R)) {
+            set_error("sort scratch too small: %zu < %zu", sort_scratch_bytes_, sort_scratch_bytes(R));
+            return SLS_E_SCRATCH;
+        }
+        const DirectBin db = make_direct_bin(dc, N, sort_scratch, nullptr, false);
+        rc = launch_bin_direct(dc, N, (uint32_t)R, db, false, order, nullptr, rect, boxes, sort_scratch, vals, ranges,
+                               nullptr, nullptr, 0, nullptr, &bmask, list_pairs, st);
+    } else {
+        rc = launch_bin_sort(dc, N, total_dev, (uint32_t)R, order, rect, tiles_touched,
                              dc.tile_cull ? tile_mask : nullptr, nullptr, depth, offsets, tkeys, vals,
                              tkeys_tmp, vals_tmp, sort_scratch, sort_scratch_bytes_, sorted_in_tmp, ranges,
-                             keys64_out, nullptr, st, nullptr, nullptr,
-                             (default_kernels && !keys64_out) ? block_box : nullptr, &bmask, list_pairs);
+                             keys64_out, nullptr, st, nullptr, nullptr, boxes, &bmask, list_pairs);
+    }
     if (rc) return rc;
     const uint32_t *sorted_vals = *sorted_in_tmp ? vals_tmp : vals;
     *sorted_list = bmask ? (const uint32_t *)bmask : sorted_vals;
@@ -360,27 +366,38 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     // preprocess launch — it needs nothing the preprocess produces (SLS_NO_MERGED_SORT=1: two launches, for A/B runs)
     static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
     const bool merged_sort = cfg->reuse_depth_order >= 1 && !no_merge;
+    // Direct binning (sls_sort.hip) where it applies: no unsorted instance array, no scan of tiles_touched; the preprocess
+    // then leaves the emission records in the form its first kernel gathers (rectangle + block box)
+    const bool direct = bin_direct_possible(dc, N, cap);
     int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                    scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
                                    okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
                                    merged_sort ? order : nullptr,
-                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox);
+                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0);
     if (rc) return rc;
-    ScanHandoff handoff = { nullptr, 0, nullptr };   // the emission finishes the scan of tiles_touched
+    ScanHandoff handoff = { nullptr, 0, nullptr, 0 };   // the binning finishes (or does not need) the scan of tiles_touched
+    DirectBin db;
+    if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (int4 *)w.serec, cfg->reuse_depth_order >= 1);
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
-                                 merged_sort);
+                                 merged_sort, direct ? &db : nullptr, (const int4 *)w.erec, dc.GX);
     if (rc) return rc;
     int in_tmp = 0;
     const uint2 *bmask = nullptr;
-    rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
-                         (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
-                         w.offsets, w.tkeys, w.vals,
-                         w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
-                         &status_dev->overflow, st, &handoff, &status_dev->R,
-                         // (pairs instead of values only if both tile kernels are the default 8x2 ones: no other reads them)
-                         (debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3) ? w.sbox : nullptr, &bmask,
-                         cfg->block_masks);
+    // (pairs instead of values only if both tile kernels are the default 8x2 ones: no other reads them)
+    const bool pairs_ok = debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3;
+    if (direct) {
+        rc = launch_bin_direct(dc, N, cap, db, handoff.counted != 0, order, w.erec, nullptr, nullptr, w.sort_scratch, w.vals,
+                               w.ranges, &status_dev->R, &status_dev->overflow, handoff.resort_windows,
+                               handoff.resort_edges, pairs_ok ? &bmask : nullptr, cfg->block_masks, st);
+    } else {
+        rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
+                             (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
+                             w.offsets, w.tkeys, w.vals,
+                             w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
+                             &status_dev->overflow, st, &handoff, &status_dev->R,
+                             pairs_ok ? w.sbox : nullptr, &bmask, cfg->block_masks);
+    }
     if (rc) return rc;
     // (with the pairs the plain value arrays are not written: the list IS the pairs, two words apart)
     const uint32_t *sorted_vals = bmask ? (const uint32_t *)bmask : (in_tmp ? w.vals_tmp : w.vals);

@@ -183,6 +183,7 @@ struct PreFwdArgs {
     float4 *rec; int *radii; int4 *rect; uint32_t *tiles; float *depth; uint32_t *order_keys, *order_vals, *n_dev;
     const float2 *col_cs, *row_cs; uint64_t *tile_mask; int4 *erec;
     uint32_t *sbox;   // optional: the surfels' block boxes (make_block_box) for the tile sort's block masks
+    int erec_box;     // 1: erec = {rectangle (2 words), block box, tile count} — what the direct binning gathers (no D10 mask)
 };
 constexpr int kPreCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
 constexpr int kPreSliceBytes = kPreCullBytes > 64 * kRec4 * 16 ? kPreCullBytes : 64 * kRec4 * 16;
@@ -395,7 +396,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
         if (pa.sbox) pa.sbox[i] = my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u;
         if (tile_mask) tile_mask[i] = my_mask;
         // what the emission reads, in ONE 16-byte gather: the rectangle (16-bit fields) and the mask
-        if (erec) erec[i] = make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
+        // (direct binning, sls_sort.hip: the block box and the tile count ride in the mask's place — D10 is off there)
+        if (erec) erec[i] = pa.erec_box
+            ? make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16),
+                        (int)(my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u), (int)my_tiles)
+            : make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
     }
     {   // the 80-byte records leave through LDS so that every store instruction writes 1 KB of
         // consecutive addresses (a direct store would touch 40 cache lines per instruction)
@@ -670,7 +675,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear,
                           const float *col_cs, const float *row_cs, uint64_t *tile_mask, int32_t *erec,
-                          const uint32_t *resort_prev_order, uint64_t *resort_comp, uint32_t *sbox)
+                          const uint32_t *resort_prev_order, uint64_t *resort_comp, uint32_t *sbox, int erec_box)
 {
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out; ra.status_clear = status_clear;
@@ -682,6 +687,7 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
     pa.tile_mask = (col_cs && row_cs) ? tile_mask : nullptr;
     pa.erec = (cam.GX < 65536 && cam.GY < 65536) ? (int4 *)erec : nullptr;
     pa.sbox = block_box_fits(cam.GX * kTileW, cam.H) ? sbox : nullptr;
+    pa.erec_box = (erec_box && pa.erec && block_box_fits(cam.GX * kTileW, cam.H)) ? 1 : 0;
     ScopedTimer tm(T_PREPROCESS_FWD, st);
     if (resort_prev_order && resort_comp) {
         // merged with the repair's window sort (which overwrites the sort's identity permutation: not written here)

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include "sls_common.hpp"
 #include "sls_resort.hpp"
+#include "sls_bin.hpp"
 
 namespace sls {
 
@@ -55,13 +56,6 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *count_ptr, uint32
     return c < cap ? c : cap;
 }
 
-// What the depth-order stage hands to an emission that finishes the scan of tiles_touched itself
-// (block_sums null: the emission reads precomputed offsets)
-struct ScanHandoff {
-    const uint32_t *block_sums;     // sums of tiles_touched over 256-blocks of depth-order positions
-    int resort_windows;             // > 0: the order was repaired, check these window edges (resort_verify)
-    const uint64_t *resort_edges;
-};
 __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restrict__ edges, uint32_t *__restrict__ flag);
 
 // The tile sort's list with block masks (launch_bin_sort, the mapping iteration): per instance, in list order, the
@@ -90,6 +84,47 @@ __device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32
     const int d1 = d0 + 1 >= a.NC ? d0 + 1 - a.NC : d0 + 1;
     const uint32_t xm = (d0 <= bc_n ? 0x5555u : 0u) | (d1 <= bc_n ? 0xAAAAu : 0u);
     return ym & xm;
+}
+
+// ---------------------------------------------------------------------------
+// Direct binning (round 4): the tile instances are never materialised unsorted.
+//
+// The list order inside a tile is the depth order of its surfels, so an instance's place in the sorted list is
+//     base[tile] + (instances of that tile emitted by earlier CHUNKS of depth positions) + (its rank inside its chunk),
+// all of which follow from a count table cnt[tile][chunk] over chunks of 1024 depth positions:
+//   1. the kernel that leaves the depth order — the repair's merge (resort_merge_kernel<true>), or gather_count_kernel
+//      after a from-scratch sort — gathers, per position, the surfel's emission record {rectangle, block box}, writes it
+//      to an array indexed by POSITION (the third kernel reads it coalesced) and counts its chunk's tiles in LDS:
+//      one column of the table;
+//   2. sort_rowscan_kernel: exclusive scan of every tile's row + the tile totals;
+//   3. bin_direct_kernel, one workgroup per chunk: digit bases (= tile ranges, R), per-wave counts -> cursors, then every
+//      wave deals its instances out 64 at a time (owner by binary search in the wave's scan, tile from the rectangle),
+//      ranks them with the BITS ballots of the radix scatter and stores (surfel[, block mask]) at the final position.
+// Against emission + histogram + row scan + scatter: two launches and the unsorted instance array (written once, read
+// twice) less; the scattered 16-byte gathers of the emission move into the latency-bound merge, which made a 4-byte
+// gather per position anyway.  Tiles <= 512 (every size the reference's mapper meets and BASELINE config 3), D10 off;
+// anything else takes the emission + radix pass below.
+// ---------------------------------------------------------------------------
+// the emission record of surfel g: rectangle in two words (zeros: nothing emitted), block box, (tile count)
+__device__ __forceinline__ int4 load_emit_record(const int4 *__restrict__ erec_box, const int4 *__restrict__ rect,
+                                                 const uint32_t *__restrict__ sbox, uint32_t g)
+{
+    if (erec_box) return erec_box[g];
+    const int4 rc = rect[g];                               // {txlo, ncols, tylo, nrows}
+    return make_int4(rc.x | (rc.z << 16), rc.y | (rc.w << 16), sbox ? (int)sbox[g] : 0, 0);
+}
+// one LDS count per tile of the rectangle (row-major, x wrapping modulo the grid width: D5 / D9)
+__device__ __forceinline__ void count_rect_tiles(int ex, int ey, int GX, uint32_t *s_hist)
+{
+    const int txlo = ex & 0xFFFF, tylo = (int)((uint32_t)ex >> 16), ncols = ey & 0xFFFF, nrows = (int)((uint32_t)ey >> 16);
+    for (int y = 0; y < nrows; ++y) {
+        const int row = (tylo + y) * GX;
+        for (int k = 0; k < ncols; ++k) {
+            int tx = txlo + k;
+            if (tx >= GX) tx -= GX;
+            atomicAdd(&s_hist[row + tx], 1u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -609,15 +644,22 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_aligned_kernel(in
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
 // Also produces level 1 of the scan of tiles_touched (the sums of the four aligned 256-blocks a
 // window covers), which saves the gather_block_sums launch.
+template <bool DIRECT>
 __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
                                                                       uint32_t *__restrict__ order,
                                                                       uint64_t *__restrict__ edges,
                                                                       const uint32_t *__restrict__ tiles,
-                                                                      uint32_t *__restrict__ block_sums)
+                                                                      uint32_t *__restrict__ block_sums, int GX,
+                                                                      const int4 *__restrict__ erec_box, DirectBin db)
 {
+    // DIRECT: instead of level 1 of the scan, step 1 of the direct binning (above): the window is a chunk
     static_assert(kResortWindow == 1024 && kResortThreads == 512, "a 256-block of positions = two waves of pairs");
     __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
     __shared__ uint32_t s_part[4][2];          // [256-block of the window][wave inside it]
+    __shared__ uint32_t s_hist[DIRECT ? kDirectMaxBins : 1];
+    if (DIRECT) {
+        for (int d = threadIdx.x; d < db.bins; d += kResortThreads) s_hist[d] = 0u;   // (the network's barriers come before its use)
+    }
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2, o0 = 2 * (int)threadIdx.x;
     uint64_t e[2];
 #pragma unroll
@@ -628,18 +670,38 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     }
     bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
     uint32_t v = 0;
+    if (DIRECT) {
+        int4 er[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pos = base + o0 + q;
-        const bool real = pos >= 0 && pos < N;
-        const uint32_t g = real ? (uint32_t)e[q] : 0u;
-        const uint32_t tv = tiles[g];                 // (surfel 0 for the padding: a valid address, masked below)
-        v += real ? tv : 0u;
-        if (real) order[pos] = g;
+        for (int q = 0; q < 2; ++q) {
+            const int pos = base + o0 + q;
+            const bool real = pos >= 0 && pos < N;
+            const uint32_t g = real ? (uint32_t)e[q] : 0u;
+            er[q] = erec_box[g];                          // (surfel 0 for the padding: a valid address, masked below)
+            if (!real) er[q].x = er[q].y = 0;
+            er[q].w = (int)g;
+            if (real) order[pos] = g;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pos = base + o0 + q;
+            if (pos >= 0 && pos < N) db.serec[pos] = er[q];
+            count_rect_tiles(er[q].x, er[q].y, GX, s_hist);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pos = base + o0 + q;
+            const bool real = pos >= 0 && pos < N;
+            const uint32_t g = real ? (uint32_t)e[q] : 0u;
+            const uint32_t tv = tiles[g];                 // (surfel 0 for the padding: a valid address, masked below)
+            v += real ? tv : 0u;
+            if (real) order[pos] = g;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 7][(threadIdx.x >> 6) & 1] = v;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 7][(threadIdx.x >> 6) & 1] = v;
     // smallest / largest real element of the window (it holds at least one)
     const int lo = base < 0 ? -base : 0, hi = min(kResortWindow, N - base) - 1;
 #pragma unroll
@@ -648,11 +710,34 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         if (o0 + q == hi) edges[2 * blockIdx.x + 1] = e[q];
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (DIRECT) {
+        for (int d = threadIdx.x; d < db.bins; d += kResortThreads) db.cnt[(size_t)d * db.nchunks + blockIdx.x] = s_hist[d];
+    } else if (threadIdx.x < 4) {
         const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
         if (base + (int)threadIdx.x * 256 >= 0 && blk * 256 < N)
             block_sums[blk] = s_part[threadIdx.x][0] + s_part[threadIdx.x][1];
     }
+}
+
+// step 1 of the direct binning after a from-scratch depth sort (and in the staged API): chunks of 1024 positions
+__global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int GX, const uint32_t *__restrict__ order,
+                                                                    const int4 *__restrict__ erec_box,
+                                                                    const int4 *__restrict__ rect,
+                                                                    const uint32_t *__restrict__ sbox, DirectBin db)
+{
+    __shared__ uint32_t s_hist[kDirectMaxBins];
+    if ((int)threadIdx.x < db.bins) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int pos = blockIdx.x * kDirectChunk + (int)threadIdx.x;
+    if (pos < N) {
+        const uint32_t g = order[pos];
+        int4 er = load_emit_record(erec_box, rect, sbox, g);
+        er.w = (int)g;
+        if (db.serec) db.serec[pos] = er;
+        count_rect_tiles(er.x, er.y, GX, s_hist);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < db.bins) db.cnt[(size_t)threadIdx.x * db.nchunks + blockIdx.x] = s_hist[threadIdx.x];
 }
 
 // step C, run by block 0 of the scan's first kernel
@@ -660,6 +745,129 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
 {
     for (int b = threadIdx.x; b + 1 < nwin; b += 256)
         if (edges[2 * b + 1] >= edges[2 * (b + 1)]) atomicOr(flag, kResortFailed);
+}
+
+// step 3 of the direct binning: one workgroup (16 waves) per chunk of 1024 depth positions
+template <int BITS, bool PAIRS>
+__global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX, DirectBin db,
+                                                                  const uint32_t *__restrict__ order,
+                                                                  const int4 *__restrict__ erec_box,
+                                                                  const int4 *__restrict__ rect,
+                                                                  const uint32_t *__restrict__ sbox, uint32_t cap,
+                                                                  uint32_t *__restrict__ vals_out, BlockMaskArgs bm,
+                                                                  uint2 *__restrict__ ranges_out, int nranges,
+                                                                  uint32_t *__restrict__ total_out,
+                                                                  uint32_t *__restrict__ overflow, int resort_windows,
+                                                                  const uint64_t *__restrict__ resort_edges,
+                                                                  uint32_t *__restrict__ fail_flag)
+{
+    constexpr int BINS = 1 << BITS, WAVES = kDirectChunk / 64;
+    static_assert(BINS <= kDirectMaxBins && BINS <= kDirectChunk, "one thread per tile");
+    __shared__ uint32_t s_cur[WAVES * BINS];     // per wave and tile: first the instance counts, then the running cursors
+    __shared__ uint32_t s_pref[WAVES][64];       // per wave: exclusive scan of its lanes' instance counts
+    __shared__ uint32_t s_part[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (resort_windows > 0 && blockIdx.x == 0 && tid < 256) resort_verify(resort_windows, resort_edges, fail_flag);
+    // everything the workgroup needs from memory is requested up front: its positions' records, its column of the
+    // count table, the tile totals
+    const int pos = db.pos0 + (int)blockIdx.x * kDirectChunk + tid;
+    const bool real = pos >= 0 && pos < N;
+    int4 er = make_int4(0, 0, 0, 0);
+    if (db.serec) {
+        if (real) er = db.serec[pos];
+    } else if (real) {
+        const uint32_t g = order[pos];
+        er = load_emit_record(erec_box, rect, sbox, g);
+        er.w = (int)g;
+    }
+    uint32_t tot = 0, ccol = 0;
+    if (tid < BINS) {
+        tot = db.totals[tid];
+        ccol = db.cnt[(size_t)tid * db.nchunks + blockIdx.x];
+    }
+    for (int i = tid; i < WAVES * BINS; i += kDirectChunk) s_cur[i] = 0u;
+    const uint32_t t = (uint32_t)((er.y & 0xFFFF) * (int)((uint32_t)er.y >> 16));
+    uint32_t incl = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    const uint32_t S = (uint32_t)__shfl((int)incl, 63, 64);
+    s_pref[w][lane] = incl - t;
+    __syncthreads();
+    // per-wave counts (the order inside a wave does not matter for counting: every lane walks its own rectangle)
+    count_rect_tiles(er.x, er.y, GX, s_cur + w * BINS);
+    // digit bases: exclusive scan of the tile totals
+    uint32_t dinc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(dinc, off, 64);
+        if (lane >= off) dinc += u;
+    }
+    if (lane == 63) s_part[w] = dinc;
+    __syncthreads();
+    if (tid < BINS) {
+        uint32_t wp = 0;
+        for (int k = 0; k < w; ++k) wp += s_part[k];
+        const uint32_t dbase = wp + dinc - tot;
+        if (blockIdx.x == 0) {
+            // the digit bases ARE the tile ranges (A5), clipped to the buffers' capacity
+            if (tid < nranges) ranges_out[tid] = tot ? make_uint2(min(dbase, cap), min(dbase + tot, cap)) : make_uint2(0u, 0u);
+            if (tid == BINS - 1) {
+                const uint32_t R = dbase + tot;
+                if (total_out) *total_out = R;
+                if (R > cap && overflow) atomicOr(overflow, 1u);     // too small: flagged, every slot below cap still filled
+            }
+        }
+        uint32_t run = dbase + ccol;
+#pragma unroll 4
+        for (int k = 0; k < WAVES; ++k) {
+            const uint32_t c = s_cur[k * BINS + tid];
+            s_cur[k * BINS + tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // the wave's S instances, 64 at a time in emission order (lane-major, then the rectangle row-major)
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t *const cur = s_cur + w * BINS;
+    const uint32_t *const pref = s_pref[w];
+    for (uint32_t q0 = 0; q0 < S; q0 += 64u) {
+        const uint32_t q = q0 + (uint32_t)lane;
+        const bool valid = q < S;
+        // owner: the last lane whose exclusive offset is <= q (lanes without instances share their successor's offset)
+        int own = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) own += (pref[own + step] <= q) ? step : 0;
+        const uint32_t k = q - pref[own];
+        const int ox = __shfl(er.x, own, 64), oy = __shfl(er.y, own, 64), ob = __shfl(er.z, own, 64), og = __shfl(er.w, own, 64);
+        const uint32_t onc = (uint32_t)max(oy & 0xFFFF, 1);
+        const uint32_t ky = k / onc, kx = k - ky * onc;
+        int tx = (ox & 0xFFFF) + (int)kx;
+        if (tx >= GX) tx -= GX;
+        const uint32_t tile = valid ? (uint32_t)(((int)((uint32_t)ox >> 16) + (int)ky) * GX + tx) : 0u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (tile >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t count = (uint32_t)__popcll(peers);
+        uint32_t p = 0;
+        if (valid) p = cur[tile] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            if (p < cap) {
+                if (PAIRS) bm.out[p] = make_uint2((uint32_t)og, block_mask_of(bm, tile, (uint32_t)ob));
+                else vals_out[p] = (uint32_t)og;
+            }
+            if (rank == count - 1) cur[tile] = p + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // A2 on the depth-ordered surfels, level 1: per-block sums of tiles[order[i]]
@@ -900,8 +1108,10 @@ uint64_t *resort_comp_buffer(int N, void *scratch)
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
                             hipStream_t st, int reuse_order, uint32_t *fail_flag, ScanHandoff *handoff,
-                            bool window_sort_done)
+                            bool window_sort_done, const DirectBin *direct, const int4 *erec_box, int GX)
 {
+    // direct (+ handoff): the direct binning follows — the repair's last merge fills the count table (handoff->counted),
+    // no scan of tiles_touched is needed at all
     if (scratch_bytes < order_scratch_bytes(N)) {
         set_error("depth-order scratch too small: %zu < %zu", scratch_bytes, order_scratch_bytes(N));
         return SLS_E_SCRATCH;
@@ -934,16 +1144,34 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
                                (const uint32_t *)keys, comp);
             SLS_LAUNCH_CHECK("resort_sort_kernel");
         }
-        hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order, edges,
-                           tiles, block_sums);
+        const DirectBin no_db = { nullptr, nullptr, nullptr, 0, 0, 0 };
+        const bool count_here = direct != nullptr && handoff != nullptr;
+        // (the LAST merge counts: after it the order is final)
+#define SLS_MERGE(last_)                                                                                                     \
+        do {                                                                                                                 \
+            if (count_here && (last_))                                                                                       \
+                hipLaunchKernelGGL(resort_merge_kernel<true>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
+                                   order, edges, tiles, block_sums, GX, erec_box, *direct);                                  \
+            else                                                                                                             \
+                hipLaunchKernelGGL(resort_merge_kernel<false>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
+                                   order, edges, tiles, block_sums, GX, erec_box, no_db);                                    \
+        } while (0)
+        SLS_MERGE(reuse_order <= 1);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
         for (int round = 1; round < reuse_order; ++round) {   // (reuse_order = 2: one more round, twice the reach)
             hipLaunchKernelGGL(resort_merge_aligned_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
                                (const uint32_t *)keys, comp);
             SLS_LAUNCH_CHECK("resort_merge_aligned_kernel");
-            hipLaunchKernelGGL(resort_merge_kernel, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, order,
-                               edges, tiles, block_sums);
+            SLS_MERGE(round + 1 == reuse_order);
             SLS_LAUNCH_CHECK("resort_merge_kernel");
+        }
+#undef SLS_MERGE
+        if (count_here) {
+            if (direct->nchunks != nB || direct->pos0 != -kResortWindow / 2) {
+                set_error("internal: the direct binning's chunks are not the repair's windows");
+                return SLS_E_ARG;
+            }
+            handoff->counted = 1;
         }
         resort_windows = nB;
         resort_edges = edges;
@@ -956,6 +1184,13 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
             set_error("internal: depth order ended in the wrong buffer");
             return SLS_E_ARG;
         }
+    }
+    if (handoff && direct && resort_windows == 0) {      // from scratch + direct binning: nothing to scan
+        handoff->block_sums = nullptr;
+        handoff->resort_windows = 0;
+        handoff->resort_edges = nullptr;
+        handoff->counted = 0;
+        return SLS_OK;
     }
     if (handoff && resort_windows > 0) {   // the emission finishes the scan and checks the repaired order
         handoff->block_sums = block_sums;
@@ -1044,7 +1279,7 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
         ScopedTimer tm(T_EMIT_KEYS, st);
 #define SLS_EMIT(EB_) hipLaunchKernelGGL(emit_tiles_kernel<EB_>, dim3(nemit), dim3(EB_), 0, st, N, cam.GX, order,                 \
                            (const int4 *)rect, tiles, tile_mask, (const int4 *)erec, offsets, cap, tkeys, packed ? (uint32_t *)nullptr : vals, overflow, \
-                           packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr }, total_out,  \
+                           packed ? idx_bits : 0, handoff ? *handoff : ScanHandoff{ nullptr, 0, nullptr, 0 }, total_out,  \
                            overflow, emit_hist ? cnt : (uint32_t *)nullptr, bins, emit_hist ? chunk_start : (uint32_t *)nullptr, \
                            sbox, wide)
         SLS_EMIT(eb);
@@ -1085,6 +1320,80 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
                            (const uint32_t *)(which ? tkeys_tmp : tkeys), (const uint32_t *)(which ? vals_tmp : vals),
                            count_ptr, cap, depth, (uint2 *)ranges, keys64_out);
         SLS_LAUNCH_CHECK("tile_ranges_kernel");
+    }
+    return SLS_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Direct binning, host side.
+// ---------------------------------------------------------------------------
+static int direct_bins(const DevCam &cam)
+{
+    const int tb = bits_for((uint32_t)(cam.GX * cam.GY - 1));
+    return 1 << (tb < 8 ? 8 : tb);
+}
+// Can the direct binning serve this camera / size / capacity?  (tiles <= 512, D10 off, 16-bit rectangle fields, the
+// count table inside the sort's scratch; SLS_NO_DIRECT_BIN=1: never — the emission + radix pass, for A/B runs)
+bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap)
+{
+    static const bool off = getenv("SLS_NO_DIRECT_BIN") != nullptr && getenv("SLS_NO_DIRECT_BIN")[0] == '1';
+    if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX >= 65536 || cam.GY >= 65536) return false;
+    if (cam.GX * cam.GY > kDirectMaxBins) return false;
+    const size_t bins = (size_t)direct_bins(cam), nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
+    return (bins * nchunks + bins) * sizeof(uint32_t) <= sort_core_bytes(cap);
+}
+// the table's place in the sort's scratch; repaired: the chunks are the repair's shifted windows
+DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, int4 *serec, bool repaired)
+{
+    DirectBin db;
+    db.bins = direct_bins(cam);
+    db.nchunks = repaired ? (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow : (N + kDirectChunk - 1) / kDirectChunk;
+    db.pos0 = repaired ? -kResortWindow / 2 : 0;
+    db.cnt = (uint32_t *)sort_scratch;
+    db.totals = db.cnt + (size_t)db.bins * db.nchunks;
+    db.serec = serec;
+    return db;
+}
+
+// order (+ erec_box, or rect + sbox) -> sorted list (vals_out, or (surfel, block mask) pairs in *bmask_out), ranges, R.
+// counted: the count table was filled by the repair's merge (launch_depth_order_scan).
+int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &db, bool counted, const uint32_t *order,
+                      const int32_t *erec_box, const int32_t *rect, const uint32_t *sbox, void *scratch, uint32_t *vals_out,
+                      uint32_t *ranges, uint32_t *total_out, uint32_t *overflow, int resort_windows,
+                      const uint64_t *resort_edges, const uint2 **bmask_out, int bmask_mode, hipStream_t st)
+{
+    const int T = cam.GX * cam.GY;
+    if (bmask_out) *bmask_out = nullptr;
+    if (!counted) {
+        ScopedTimer tm(T_EMIT_KEYS, st);
+        hipLaunchKernelGGL(gather_count_kernel, dim3(db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, order,
+                           (const int4 *)erec_box, (const int4 *)rect, sbox, db);
+        SLS_LAUNCH_CHECK("gather_count_kernel");
+    }
+    {
+        ScopedTimer tm(T_SORT_ROWSCAN, st);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(db.bins), dim3(256), 0, st, db.cnt, (const uint32_t *)nullptr, cap,
+                           db.nchunks, db.totals, db.nchunks);
+        SLS_LAUNCH_CHECK("sort_rowscan_kernel");
+    }
+    // (surfel, block mask) pairs under the rule of launch_bin_sort: long lists (or always / never)
+    const bool long_lists = bmask_mode == 1 || (bmask_mode == 0 && (uint64_t)cap >= 1500ull * (uint64_t)T);
+    const bool have_box = erec_box != nullptr || sbox != nullptr;
+    BlockMaskArgs bm = { nullptr, cam.GX, 1.0f / (float)cam.GX, (cam.GX * kTileW) / 8 };
+    if (bmask_out && have_box && long_lists && kTileW == 16 && kTileH == 16 && block_box_fits(cam.GX * kTileW, cam.H)) {
+        bm.out = sort_bmask_buffer(scratch, cap);
+        *bmask_out = bm.out;
+    }
+    {
+        ScopedTimer tm(T_SORT_SCATTER, st);
+#define SLS_DIRECT(B_, P_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_>), dim3(db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, db, \
+                               order, (const int4 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
+                               total_out, overflow, resort_windows, resort_edges, overflow)
+        if (db.bins == 256) { if (bm.out) SLS_DIRECT(8, true); else SLS_DIRECT(8, false); }
+        else { if (bm.out) SLS_DIRECT(9, true); else SLS_DIRECT(9, false); }
+#undef SLS_DIRECT
+        SLS_LAUNCH_CHECK("bin_direct_kernel");
     }
     return SLS_OK;
 }
