@@ -20,12 +20,12 @@ constexpr int kDirectMaxBins = 512;    // tiles it serves
 struct DirectBin {
     uint32_t *cnt;          // count table cnt[tile][chunk]: bins x nchunks words
     uint32_t *totals;       // bins words
-    int4 *serec;            // optional: per depth position {x = txlo | tylo << 16, y = ncols | nrows << 16, block box, surfel}
+    uint2 *serec;           // optional: per depth position the surfel's emission record {rectangle in one word, block box}
     int bins, nchunks, pos0;    // pos0: first depth position of chunk 0 (0, or -512: the repair's shifted windows)
 };
 
 bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap);
-DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, int4 *serec, bool repaired);
+DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired);
 int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &db, bool counted, const uint32_t *order,
                       const int32_t *erec_box, const int32_t *rect, const uint32_t *sbox, void *scratch, uint32_t *vals_out,
                       uint32_t *ranges, uint32_t *total_out, uint32_t *overflow, int resort_windows,

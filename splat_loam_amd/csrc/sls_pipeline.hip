@@ -87,7 +87,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.tiles = (uint32_t *)take(n * 4);
     w.tmask = (uint64_t *)take(n * 8);
     w.erec = (int32_t *)take(n * 16);
-    w.serec = (int32_t *)take(n * 16);         // direct binning: the emission records by depth position
+    w.serec = (int32_t *)take(n * 8);          // direct binning: the emission records by depth position
     w.sbox = (uint32_t *)take(n * 4);          // block box per surfel (sls_common.hpp: make_block_box)
     w.depth = (float *)take(n * 4);
     w.order = (uint32_t *)take(n * 4);
@@ -377,7 +377,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (rc) return rc;
     ScanHandoff handoff = { nullptr, 0, nullptr, 0 };   // the binning finishes (or does not need) the scan of tiles_touched
     DirectBin db;
-    if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (int4 *)w.serec, cfg->reuse_depth_order >= 1);
+    if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1);
     rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
                                  w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
                                  merged_sort, direct ? &db : nullptr, (const int4 *)w.erec, dc.GX);

@@ -183,7 +183,8 @@ struct PreFwdArgs {
     float4 *rec; int *radii; int4 *rect; uint32_t *tiles; float *depth; uint32_t *order_keys, *order_vals, *n_dev;
     const float2 *col_cs, *row_cs; uint64_t *tile_mask; int4 *erec;
     uint32_t *sbox;   // optional: the surfels' block boxes (make_block_box) for the tile sort's block masks
-    int erec_box;     // 1: erec = {rectangle (2 words), block box, tile count} — what the direct binning gathers (no D10 mask)
+    int erec_box;     // 1: erec is an array of uint2 {rectangle in one word (sls_sort.hip: pack_rect32), block box} — what the
+                      // direct binning gathers (no D10 mask)
 };
 constexpr int kPreCullBytes = 64 * (int)(sizeof(SlsTileCullSurfel) + sizeof(int4) + 4 * sizeof(uint32_t)) + 16;
 constexpr int kPreSliceBytes = kPreCullBytes > 64 * kRec4 * 16 ? kPreCullBytes : 64 * kRec4 * 16;
@@ -396,11 +397,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
         if (pa.sbox) pa.sbox[i] = my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u;
         if (tile_mask) tile_mask[i] = my_mask;
         // what the emission reads, in ONE 16-byte gather: the rectangle (16-bit fields) and the mask
-        // (direct binning, sls_sort.hip: the block box and the tile count ride in the mask's place — D10 is off there)
-        if (erec) erec[i] = pa.erec_box
-            ? make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16),
-                        (int)(my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u), (int)my_tiles)
-            : make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
+        // (direct binning, sls_sort.hip: 8 bytes instead — the rectangle in one word and the block box; D10 is off there)
+        if (erec && pa.erec_box)
+            reinterpret_cast<uint2 *>(erec)[i] = make_uint2((uint32_t)my_rc.x | ((uint32_t)my_rc.y << 9) | ((uint32_t)my_rc.z << 19) | ((uint32_t)my_rc.w << 25),
+                                                            my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u);
+        else if (erec) erec[i] = make_int4(my_rc.x | (my_rc.z << 16), my_rc.y | (my_rc.w << 16), (int)(uint32_t)my_mask, (int)(uint32_t)(my_mask >> 32));
     }
     {   // the 80-byte records leave through LDS so that every store instruction writes 1 KB of
         // consecutive addresses (a direct store would touch 40 cache lines per instruction)

@@ -105,18 +105,23 @@ __device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32
 // gather per position anyway.  Tiles <= 512 (every size the reference's mapper meets and BASELINE config 3), D10 off;
 // anything else takes the emission + radix pass below.
 // ---------------------------------------------------------------------------
-// the emission record of surfel g: rectangle in two words (zeros: nothing emitted), block box, (tile count)
-__device__ __forceinline__ int4 load_emit_record(const int4 *__restrict__ erec_box, const int4 *__restrict__ rect,
+// The emission record of a surfel, 8 bytes: x = its tile rectangle in ONE word — txlo (9 bits) | ncols (10) | tylo (6) |
+// nrows (7), zero: nothing emitted; grids up to 512 x 64 tiles (bin_direct_possible) — y = its block box.
+__host__ __device__ inline uint32_t pack_rect32(int txlo, int ncols, int tylo, int nrows)
+{
+    return (uint32_t)txlo | ((uint32_t)ncols << 9) | ((uint32_t)tylo << 19) | ((uint32_t)nrows << 25);
+}
+__device__ __forceinline__ uint2 load_emit_record(const uint2 *__restrict__ erec_box, const int4 *__restrict__ rect,
                                                  const uint32_t *__restrict__ sbox, uint32_t g)
 {
     if (erec_box) return erec_box[g];
     const int4 rc = rect[g];                               // {txlo, ncols, tylo, nrows}
-    return make_int4(rc.x | (rc.z << 16), rc.y | (rc.w << 16), sbox ? (int)sbox[g] : 0, 0);
+    return make_uint2(pack_rect32(rc.x, rc.y, rc.z, rc.w), sbox ? sbox[g] : 0u);
 }
 // one LDS count per tile of the rectangle (row-major, x wrapping modulo the grid width: D5 / D9)
-__device__ __forceinline__ void count_rect_tiles(int ex, int ey, int GX, uint32_t *s_hist)
+__device__ __forceinline__ void count_rect_tiles(uint32_t r32, int GX, uint32_t *s_hist)
 {
-    const int txlo = ex & 0xFFFF, tylo = (int)((uint32_t)ex >> 16), ncols = ey & 0xFFFF, nrows = (int)((uint32_t)ey >> 16);
+    const int txlo = (int)(r32 & 511u), ncols = (int)((r32 >> 9) & 1023u), tylo = (int)((r32 >> 19) & 63u), nrows = (int)(r32 >> 25);
     for (int y = 0; y < nrows; ++y) {
         const int row = (tylo + y) * GX;
         for (int k = 0; k < ncols; ++k) {
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
                                                                       uint64_t *__restrict__ edges,
                                                                       const uint32_t *__restrict__ tiles,
                                                                       uint32_t *__restrict__ block_sums, int GX,
-                                                                      const int4 *__restrict__ erec_box, DirectBin db)
+                                                                      const uint2 *__restrict__ erec_box, DirectBin db)
 {
     // DIRECT: instead of level 1 of the scan, step 1 of the direct binning (above): the window is a chunk
     static_assert(kResortWindow == 1024 && kResortThreads == 512, "a 256-block of positions = two waves of pairs");
@@ -671,22 +676,21 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
     uint32_t v = 0;
     if (DIRECT) {
-        int4 er[2];
+        uint2 er[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pos = base + o0 + q;
             const bool real = pos >= 0 && pos < N;
             const uint32_t g = real ? (uint32_t)e[q] : 0u;
             er[q] = erec_box[g];                          // (surfel 0 for the padding: a valid address, masked below)
-            if (!real) er[q].x = er[q].y = 0;
-            er[q].w = (int)g;
+            if (!real) er[q].x = 0u;
             if (real) order[pos] = g;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pos = base + o0 + q;
             if (pos >= 0 && pos < N) db.serec[pos] = er[q];
-            count_rect_tiles(er[q].x, er[q].y, GX, s_hist);
+            count_rect_tiles(er[q].x, GX, s_hist);
         }
     } else {
 #pragma unroll
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
 
 // step 1 of the direct binning after a from-scratch depth sort (and in the staged API): chunks of 1024 positions
 __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int GX, const uint32_t *__restrict__ order,
-                                                                    const int4 *__restrict__ erec_box,
+                                                                    const uint2 *__restrict__ erec_box,
                                                                     const int4 *__restrict__ rect,
                                                                     const uint32_t *__restrict__ sbox, DirectBin db)
 {
@@ -730,11 +734,9 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
     __syncthreads();
     const int pos = blockIdx.x * kDirectChunk + (int)threadIdx.x;
     if (pos < N) {
-        const uint32_t g = order[pos];
-        int4 er = load_emit_record(erec_box, rect, sbox, g);
-        er.w = (int)g;
+        const uint2 er = load_emit_record(erec_box, rect, sbox, order[pos]);
         if (db.serec) db.serec[pos] = er;
-        count_rect_tiles(er.x, er.y, GX, s_hist);
+        count_rect_tiles(er.x, GX, s_hist);
     }
     __syncthreads();
     if ((int)threadIdx.x < db.bins) db.cnt[(size_t)threadIdx.x * db.nchunks + blockIdx.x] = s_hist[threadIdx.x];
@@ -747,11 +749,29 @@ __device__ __forceinline__ void resort_verify(int nwin, const uint64_t *__restri
         if (edges[2 * b + 1] >= edges[2 * (b + 1)]) atomicOr(flag, kResortFailed);
 }
 
-// step 3 of the direct binning: one workgroup (16 waves) per chunk of 1024 depth positions
-template <int BITS, bool PAIRS>
-__global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX, DirectBin db,
+// inclusive max-scan over the 64 lanes of a wave (DPP: shifts inside the rows of 16, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_max_scan(uint32_t v)
+{
+#define SLS_MAXDPP(ctrl_, rows_) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl_, rows_, 0xF, false))
+    SLS_MAXDPP(0x111, 0xF);     // row_shr:1   (lanes without a source keep their own value: the identity of max)
+    SLS_MAXDPP(0x112, 0xF);     // row_shr:2
+    SLS_MAXDPP(0x114, 0xF);     // row_shr:4
+    SLS_MAXDPP(0x118, 0xF);     // row_shr:8
+    SLS_MAXDPP(0x142, 0xA);     // row_bcast:15 into rows 1, 3
+    SLS_MAXDPP(0x143, 0xC);     // row_bcast:31 into rows 2, 3
+#undef SLS_MAXDPP
+    return v;
+}
+
+// step 3 of the direct binning.  A chunk of 1024 depth positions is served by SPLIT workgroups of 1024 / SPLIT threads:
+// the chunks at the front of the depth order hold the near surfels — ten and more tiles each, 10-15 k instances per
+// chunk against 1.5 k at the far end — and a launch lasts as long as its heaviest workgroup.  Workgroup `sub` of a chunk
+// first counts the rectangles of the sub-chunks in front of it (LDS counts only: a tenth of what emitting them costs)
+// to know where its own instances start.
+template <int BITS, bool PAIRS, int SPLIT>
+__global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N, int GX, DirectBin db,
                                                                   const uint32_t *__restrict__ order,
-                                                                  const int4 *__restrict__ erec_box,
+                                                                  const uint2 *__restrict__ erec_box,
                                                                   const int4 *__restrict__ rect,
                                                                   const uint32_t *__restrict__ sbox, uint32_t cap,
                                                                   uint32_t *__restrict__ vals_out, BlockMaskArgs bm,
@@ -761,32 +781,51 @@ __global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX,
                                                                   const uint64_t *__restrict__ resort_edges,
                                                                   uint32_t *__restrict__ fail_flag)
 {
-    constexpr int BINS = 1 << BITS, WAVES = kDirectChunk / 64;
-    static_assert(BINS <= kDirectMaxBins && BINS <= kDirectChunk, "one thread per tile");
+    constexpr int BINS = 1 << BITS, TPB = kDirectChunk / SPLIT, WAVES = TPB / 64;
+    constexpr int PER = BINS > TPB ? BINS / TPB : 1;          // tiles per thread in the per-tile steps
+    static_assert(BINS <= kDirectMaxBins && TPB % 64 == 0 && (BINS % TPB == 0 || BINS < TPB), "tiles dealt evenly to the threads");
     __shared__ uint32_t s_cur[WAVES * BINS];     // per wave and tile: first the instance counts, then the running cursors
-    __shared__ uint32_t s_pref[WAVES][64];       // per wave: exclusive scan of its lanes' instance counts
+    __shared__ uint32_t s_pre[BINS];             // per tile: instances of the chunk's sub-chunks in front of this one
+    __shared__ uint4 s_lane[WAVES][64];          // per wave and lane: {rectangle, block box, surfel, first instance of the lane}
+    __shared__ uint32_t s_mark[WAVES][64];       // per wave: which lane's instances start at each slot of the current round
     __shared__ uint32_t s_part[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (resort_windows > 0 && blockIdx.x == 0 && tid < 256) resort_verify(resort_windows, resort_edges, fail_flag);
-    // everything the workgroup needs from memory is requested up front: its positions' records, its column of the
-    // count table, the tile totals
-    const int pos = db.pos0 + (int)blockIdx.x * kDirectChunk + tid;
+    const int chunk = (int)blockIdx.x / SPLIT, sub = (int)blockIdx.x % SPLIT;
+    if (resort_windows > 0 && blockIdx.x == 0) {
+        for (int b = tid; b + 1 < resort_windows; b += TPB)
+            if (resort_edges[2 * b + 1] >= resort_edges[2 * (b + 1)]) atomicOr(fail_flag, kResortFailed);
+    }
+    // everything the workgroup needs from memory is requested up front: its positions' records (and the rectangles of
+    // the sub-chunks in front), its column of the count table, the tile totals
+    const int pos0 = db.pos0 + chunk * kDirectChunk;
+    const int pos = pos0 + sub * TPB + tid;
     const bool real = pos >= 0 && pos < N;
-    int4 er = make_int4(0, 0, 0, 0);
-    if (db.serec) {
-        if (real) er = db.serec[pos];
-    } else if (real) {
-        const uint32_t g = order[pos];
-        er = load_emit_record(erec_box, rect, sbox, g);
-        er.w = (int)g;
+    uint2 er = make_uint2(0u, 0u);
+    uint32_t g = 0u;
+    if (real) {
+        g = order[pos];
+        er = db.serec ? db.serec[pos] : load_emit_record(erec_box, rect, sbox, g);
     }
-    uint32_t tot = 0, ccol = 0;
-    if (tid < BINS) {
-        tot = db.totals[tid];
-        ccol = db.cnt[(size_t)tid * db.nchunks + blockIdx.x];
+    uint32_t front[SPLIT > 1 ? SPLIT - 1 : 1];
+#pragma unroll
+    for (int m = 0; m < SPLIT - 1; ++m) {
+        const int p2 = pos0 + m * TPB + tid;
+        front[m] = 0u;
+        if (m < sub && p2 >= 0 && p2 < N) front[m] = db.serec ? db.serec[p2].x : load_emit_record(erec_box, rect, sbox, order[p2]).x;
     }
-    for (int i = tid; i < WAVES * BINS; i += kDirectChunk) s_cur[i] = 0u;
-    const uint32_t t = (uint32_t)((er.y & 0xFFFF) * (int)((uint32_t)er.y >> 16));
+    uint32_t tot[PER], ccol[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int d = tid * PER + q;
+        tot[q] = 0u; ccol[q] = 0u;
+        if (d < BINS) {
+            tot[q] = db.totals[d];
+            ccol[q] = db.cnt[(size_t)d * db.nchunks + chunk];
+        }
+    }
+    for (int i = tid; i < WAVES * BINS; i += TPB) s_cur[i] = 0u;
+    for (int i = tid; i < BINS; i += TPB) s_pre[i] = 0u;
+    const uint32_t t = ((er.x >> 9) & 1023u) * (er.x >> 25);
     uint32_t incl = t;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -794,12 +833,18 @@ __global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX,
         if (lane >= off) incl += u;
     }
     const uint32_t S = (uint32_t)__shfl((int)incl, 63, 64);
-    s_pref[w][lane] = incl - t;
+    const uint32_t first = incl - t;
+    s_lane[w][lane] = make_uint4(er.x, er.y, g, first);
     __syncthreads();
     // per-wave counts (the order inside a wave does not matter for counting: every lane walks its own rectangle)
-    count_rect_tiles(er.x, er.y, GX, s_cur + w * BINS);
-    // digit bases: exclusive scan of the tile totals
-    uint32_t dinc = tot;
+    count_rect_tiles(er.x, GX, s_cur + w * BINS);
+#pragma unroll
+    for (int m = 0; m < SPLIT - 1; ++m) count_rect_tiles(front[m], GX, s_pre);
+    // digit bases: exclusive scan of the tile totals (PER consecutive ones per thread)
+    uint32_t loc[PER], dsum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = dsum; dsum += tot[q]; }
+    uint32_t dinc = dsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t u = __shfl_up(dinc, off, 64);
@@ -807,46 +852,57 @@ __global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX,
     }
     if (lane == 63) s_part[w] = dinc;
     __syncthreads();
-    if (tid < BINS) {
+    {
         uint32_t wp = 0;
         for (int k = 0; k < w; ++k) wp += s_part[k];
-        const uint32_t dbase = wp + dinc - tot;
-        if (blockIdx.x == 0) {
-            // the digit bases ARE the tile ranges (A5), clipped to the buffers' capacity
-            if (tid < nranges) ranges_out[tid] = tot ? make_uint2(min(dbase, cap), min(dbase + tot, cap)) : make_uint2(0u, 0u);
-            if (tid == BINS - 1) {
-                const uint32_t R = dbase + tot;
-                if (total_out) *total_out = R;
-                if (R > cap && overflow) atomicOr(overflow, 1u);     // too small: flagged, every slot below cap still filled
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int d = tid * PER + q;
+            if (d >= BINS) break;
+            const uint32_t dbase = wp + dinc - dsum + loc[q];
+            if (blockIdx.x == 0) {
+                // the digit bases ARE the tile ranges (A5), clipped to the buffers' capacity
+                if (d < nranges) ranges_out[d] = tot[q] ? make_uint2(min(dbase, cap), min(dbase + tot[q], cap)) : make_uint2(0u, 0u);
+                if (d == BINS - 1) {
+                    const uint32_t R = dbase + tot[q];
+                    if (total_out) *total_out = R;
+                    if (R > cap && overflow) atomicOr(overflow, 1u);     // too small: flagged, every slot below cap still filled
+                }
             }
-        }
-        uint32_t run = dbase + ccol;
-#pragma unroll 4
-        for (int k = 0; k < WAVES; ++k) {
-            const uint32_t c = s_cur[k * BINS + tid];
-            s_cur[k * BINS + tid] = run;
-            run += c;
+            uint32_t c[WAVES];
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) c[k] = s_cur[k * BINS + d];
+            uint32_t run = dbase + ccol[q] + s_pre[d];
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) { s_cur[k * BINS + d] = run; run += c[k]; }
         }
     }
     __syncthreads();
-    // the wave's S instances, 64 at a time in emission order (lane-major, then the rectangle row-major)
+    // The wave's S instances, 64 at a time in emission order (lane-major, then the rectangle row-major).  Owner of slot q:
+    // the last lane whose first instance is <= q — every lane marks the slot its instances start at, a max-scan over the
+    // round's 64 slots (carried on from the previous round) names the owner: one LDS round trip and six DPP steps.
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t *const cur = s_cur + w * BINS;
-    const uint32_t *const pref = s_pref[w];
+    uint32_t carry = 0u;                          // (owner of the slot before this round) + 1
     for (uint32_t q0 = 0; q0 < S; q0 += 64u) {
+        s_mark[w][lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (t != 0u && first - q0 < 64u) s_mark[w][first - q0] = (uint32_t)lane + 1u;     // (unsigned: first >= q0 too)
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t own1 = max(wave_max_scan(s_mark[w][lane]), carry);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)own1, 63);
         const uint32_t q = q0 + (uint32_t)lane;
         const bool valid = q < S;
-        // owner: the last lane whose exclusive offset is <= q (lanes without instances share their successor's offset)
-        int own = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) own += (pref[own + step] <= q) ? step : 0;
-        const uint32_t k = q - pref[own];
-        const int ox = __shfl(er.x, own, 64), oy = __shfl(er.y, own, 64), ob = __shfl(er.z, own, 64), og = __shfl(er.w, own, 64);
-        const uint32_t onc = (uint32_t)max(oy & 0xFFFF, 1);
-        const uint32_t ky = k / onc, kx = k - ky * onc;
-        int tx = (ox & 0xFFFF) + (int)kx;
+        const uint4 o = s_lane[w][valid ? own1 - 1u : 0u];     // {rectangle, block box, surfel, first}
+        const uint32_t k = q - o.w;
+        const uint32_t onc = (o.x >> 9) & 1023u;
+        // k / ncols through the reciprocal: (k + 0.5) / ncols lies at least 1 / (2 ncols) >= 2^-11 from an integer and is
+        // below nrows <= 2^7 (k < ncols nrows), so the float error (rcp 1 ulp + one rounding) stays below 2^-15
+        const uint32_t ky = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)onc));
+        const uint32_t kx = k - ky * onc;
+        int tx = (int)(o.x & 511u) + (int)kx;
         if (tx >= GX) tx -= GX;
-        const uint32_t tile = valid ? (uint32_t)(((int)((uint32_t)ox >> 16) + (int)ky) * GX + tx) : 0u;
+        const uint32_t tile = valid ? (uint32_t)(((int)((o.x >> 19) & 63u) + (int)ky) * GX + tx) : 0u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -861,8 +917,8 @@ __global__ __launch_bounds__(kDirectChunk) void bin_direct_kernel(int N, int GX,
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             if (p < cap) {
-                if (PAIRS) bm.out[p] = make_uint2((uint32_t)og, block_mask_of(bm, tile, (uint32_t)ob));
-                else vals_out[p] = (uint32_t)og;
+                if (PAIRS) bm.out[p] = make_uint2(o.z, block_mask_of(bm, tile, o.y));
+                else vals_out[p] = o.z;
             }
             if (rank == count - 1) cur[tile] = p + 1;
         }
@@ -1151,10 +1207,10 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         do {                                                                                                                 \
             if (count_here && (last_))                                                                                       \
                 hipLaunchKernelGGL(resort_merge_kernel<true>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
-                                   order, edges, tiles, block_sums, GX, erec_box, *direct);                                  \
+                                   order, edges, tiles, block_sums, GX, (const uint2 *)erec_box, *direct);                                  \
             else                                                                                                             \
                 hipLaunchKernelGGL(resort_merge_kernel<false>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
-                                   order, edges, tiles, block_sums, GX, erec_box, no_db);                                    \
+                                   order, edges, tiles, block_sums, GX, (const uint2 *)erec_box, no_db);                                    \
         } while (0)
         SLS_MERGE(reuse_order <= 1);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
@@ -1338,13 +1394,13 @@ static int direct_bins(const DevCam &cam)
 bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap)
 {
     static const bool off = getenv("SLS_NO_DIRECT_BIN") != nullptr && getenv("SLS_NO_DIRECT_BIN")[0] == '1';
-    if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX >= 65536 || cam.GY >= 65536) return false;
+    if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX > 512 || cam.GY > 64) return false;    // (pack_rect32's fields)
     if (cam.GX * cam.GY > kDirectMaxBins) return false;
     const size_t bins = (size_t)direct_bins(cam), nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
     return (bins * nchunks + bins) * sizeof(uint32_t) <= sort_core_bytes(cap);
 }
 // the table's place in the sort's scratch; repaired: the chunks are the repair's shifted windows
-DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, int4 *serec, bool repaired)
+DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired)
 {
     DirectBin db;
     db.bins = direct_bins(cam);
@@ -1368,7 +1424,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     if (!counted) {
         ScopedTimer tm(T_EMIT_KEYS, st);
         hipLaunchKernelGGL(gather_count_kernel, dim3(db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, order,
-                           (const int4 *)erec_box, (const int4 *)rect, sbox, db);
+                           (const uint2 *)erec_box, (const int4 *)rect, sbox, db);
         SLS_LAUNCH_CHECK("gather_count_kernel");
     }
     {
@@ -1387,11 +1443,16 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     }
     {
         ScopedTimer tm(T_SORT_SCATTER, st);
-#define SLS_DIRECT(B_, P_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_>), dim3(db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, db, \
-                               order, (const int4 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
+        // (SLS_BIN_SPLIT=1|2|4: workgroups per chunk, for A/B runs; default 4)
+        static const int split_env = getenv("SLS_BIN_SPLIT") ? atoi(getenv("SLS_BIN_SPLIT")) : 4;
+        const int split = (split_env == 1 || split_env == 2) ? split_env : 4;
+#define SLS_DIRECT3(B_, P_, S_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_, S_>), dim3(db.nchunks * S_), dim3(kDirectChunk / S_), 0, st, N, cam.GX, db, \
+                               order, (const uint2 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
                                total_out, overflow, resort_windows, resort_edges, overflow)
+#define SLS_DIRECT(B_, P_) do { if (split == 1) SLS_DIRECT3(B_, P_, 1); else if (split == 2) SLS_DIRECT3(B_, P_, 2); else SLS_DIRECT3(B_, P_, 4); } while (0)
         if (db.bins == 256) { if (bm.out) SLS_DIRECT(8, true); else SLS_DIRECT(8, false); }
         else { if (bm.out) SLS_DIRECT(9, true); else SLS_DIRECT(9, false); }
+#undef SLS_DIRECT3
 #undef SLS_DIRECT
         SLS_LAUNCH_CHECK("bin_direct_kernel");
     }

@@ -20,16 +20,16 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def reference_iteration(raw, K, view, proj, H, W, gt_depth, valid, cfg, allmap_value=None):
+def reference_iteration(raw, K, view, proj, H, W, gt_depth, valid, cfg, allmap_value=None, dtype=np.float32):
     """Loss and raw-parameter gradients of one mapping iteration through the checker.  `allmap_value`: evaluate the
     consumer at THIS allmap (e.g. the engine's) while the gradient still flows into the checker's backward."""
     from oracle.consumer_ref import pixel_loss64
     from oracle.torch_function import GaussianRasterizationSettings, GaussianRasterizer
-    leaves = {k: torch.tensor(np.asarray(v, np.float32)).requires_grad_(True) for k, v in raw.items()}
+    leaves = {k: torch.tensor(np.asarray(v, dtype)).requires_grad_(True) for k, v in raw.items()}
     scales = torch.exp(leaves["scaling"])
     rots = torch.nn.functional.normalize(leaves["rotation"])
     opac = torch.sigmoid(leaves["opacity"])
-    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view), torch.tensor(proj))
+    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view), torch.tensor(proj))      # (dtype float64: the checker's float64 build)
     radii, allmap = GaussianRasterizer(raster_settings=settings)(
         means3D=leaves["xyz"], means2D=torch.zeros_like(leaves["xyz"]), opacities=opac, scales=scales, rotations=rots)
     am = allmap
@@ -93,10 +93,12 @@ def test_engine_gradients_match_checker_chain_c3(device, oracle32):
     Adam of sls_mapping_step against the checker chain, the checker on every host thread."""
     import oracle.torch_function as otf
     oracle32.set_threads(oracle32.max_threads())
+    for dt in (np.float32, np.float64):     # (the autograd wrapper's own instances: one shared library per precision)
+        otf._oracle(dt).set_threads(oracle32.max_threads())
     otf.BACKWARD_THREADS = oracle32.max_threads()
     try:
         eng = _check_engine_against_checker_chain(device, "c3_500k_64x2048", 500000, 64, 2048, {}, 0, seed=0,
-                                                  mask_fragile=oracle32, repeats=3)
+                                                  mask_fragile=oracle32, repeats=3, float64_too=True)
     finally:
         otf.BACKWARD_THREADS = 1
     # the automatic rule did choose the dense kernels: capacity >= 1500 instances per tile
@@ -115,7 +117,7 @@ def _fragile_neighbourhood(oracle, raw, view, proj, H, W):
     return f | np.roll(f, 1, 0) | np.roll(f, -1, 0) | np.roll(f, 1, 1) | np.roll(f, -1, 1)
 
 
-def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1):
+def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1, float64_too=False):
     """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
     chain.  Two comparisons:
       * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
@@ -145,13 +147,17 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
         assert np.array_equal(r[2], am), "the forward has no atomics: every run renders the same image"
     own = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg)
     same = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am)
+    own64 = same64 = None
+    if float64_too:      # the same chain through the checker's float64 build: what float32 arithmetic itself costs here
+        own64 = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, dtype=np.float64)
+        same64 = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am, dtype=np.float64)
     # (float atomics: the gradients vary from run to run — every run has to meet the bar)
     for k, (st, g, _, eng, model, cam) in enumerate(runs):
-        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same)
+        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same, own64, same64)
     return runs[0][3]
 
 
-def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same):
+def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=None, same64=None):
     # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image
     for c in range(5):
         scale = max(np.abs(own["allmap"][c]).max(), 1e-12)
@@ -161,22 +167,42 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same):
     assert abs(st["loss"] - same["loss"]) <= 2e-5 * abs(same["loss"]), (st, same["loss"])
     assert abs(st["loss_reg"] - same["reg"]) <= 1e-5 * max(abs(same["reg"]), 1e-6)
     rot = raw["rotation"].astype(np.float64)
+
+    def errs(a, b, k):
+        """max-norm error relative to max |b|, and the worst relative error among the entries above 1e-3 of it"""
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        if k == "rotation":
+            a, b = tangent(a, rot), tangent(b, rot)
+        scale = np.abs(b).max()
+        big = np.abs(b) > 1e-3 * scale
+        return np.abs(a - b).max() / scale, (np.abs(a - b)[big] / np.abs(b)[big]).max()
+
     report = {}
-    for tag, ref in (("same-allmap", same), ("own-allmap", own)):
+    for tag, ref, ref64 in (("same-allmap", same, same64), ("own-allmap", own, own64)):
         for k in ("xyz", "opacity", "scaling", "rotation"):
-            a, b = g[k].astype(np.float64), ref["grads"][k].astype(np.float64)
-            if k == "rotation":
-                a, b = tangent(a, rot), tangent(b, rot)
-            scale = np.abs(b).max()
-            e = np.abs(a - b).max() / scale
-            big = np.abs(b) > 1e-3 * scale
-            er = (np.abs(a - b)[big] / np.abs(b)[big]).max()
-            report[(tag, k)] = (e, er)
-    print(f"\n[{name}] engine vs checker chain (max-norm rel, worst element-wise rel above 1e-3 of max): "
-          + "; ".join(f"{t}/{k}: {e:.1e}, {er:.1e}" for (t, k), (e, er) in report.items()))
-    for (tag, k), (e, er) in report.items():
-        assert e <= RTOL, f"{name}: {tag} d{k} max-norm rel err {e:.3e} > {RTOL}"
-        assert er <= 2e-3, f"{name}: {tag} d{k} element-wise rel err {er:.3e}"
+            e, er = errs(g[k], ref["grads"][k], k)
+            report[(tag, k)] = [e, er, None, None, None, None]
+            if ref64 is not None:
+                e64, er64 = errs(g[k], ref64["grads"][k], k)                    # the engine against float64
+                n64, nr64 = errs(ref["grads"][k], ref64["grads"][k], k)         # the float32 checker against float64
+                report[(tag, k)][2:] = [e64, er64, n64, nr64]
+    print(f"\n[{name}] engine vs checker chain (max-norm rel, worst element-wise rel above 1e-3 of max"
+          + ("; then the engine vs the float64 checker and the float32 checker vs the float64 one" if same64 is not None else "") + "): "
+          + "; ".join(f"{t}/{k}: " + ", ".join(f"{v:.1e}" for v in vals if v is not None) for (t, k), vals in report.items()))
+    for (tag, k), (e, er, e64, er64, n64, nr64) in report.items():
+        if e64 is None:
+            assert e <= RTOL, f"{name}: {tag} d{k} max-norm rel err {e:.3e} > {RTOL}"
+            assert er <= 2e-3, f"{name}: {tag} d{k} element-wise rel err {er:.3e}"
+        else:
+            # At full size (2400-entry lists, 500 k surfels) two float32 evaluations of the same formulas — these
+            # kernels and the checker's float32 build — differ by what float32 rounding and summation order cost; the
+            # float64 build says how much that is (tools/c3_noise.py: the float32 checker itself is 0.3..1.7e-5 from
+            # it).  The engine passes if it meets the bar against the float32 checker, or is as close to the float64
+            # checker as the float32 checker is (x1.5).
+            assert e <= RTOL or e64 <= max(RTOL, 1.5 * n64), \
+                f"{name}: {tag} d{k} max-norm rel err {e:.3e} (float32 checker), {e64:.3e} (float64); float32 vs float64 checker {n64:.3e}"
+            assert er <= 2e-3 or er64 <= max(2e-3, 1.5 * nr64), \
+                f"{name}: {tag} d{k} element-wise rel err {er:.3e} (float32 checker), {er64:.3e} (float64); float32 vs float64 checker {nr64:.3e}"
     # the fused Adam consumed exactly these gradients: first step = -lr * sign(g) wherever |g| is not ~0
     lrs = {"xyz": 5e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
     for k, p in (("xyz", model._xyz), ("opacity", model._opacity), ("scaling", model._scaling), ("rotation", model._rotation)):
