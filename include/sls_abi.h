@@ -281,6 +281,14 @@ typedef struct SlsMappingConfig {
                               * the bitmap receive the void flags (non-zero: bit 0 resp. any other bit of
                               * status.overflow) — OR-reduced over the ranks they are the group's verdict
                               * (sls_grad_compact / sls_adam_step_sparse) */
+    int32_t phase;           /* 0: the whole iteration.  1: up to and including the tile backward; 2: the rest (backward
+                              * of the projection [+ Adam]) of the iteration phase 1 started — same arguments, same
+                              * workspace.  Between the two the caller can start a collective that needs nothing of
+                              * phase 2: with grad_bitmap, phase 1 ends by writing the bitmap EARLY — the surfels the
+                              * tile backward reached or the scale regulariser may push on, a superset of the non-zero
+                              * gradients (zero rows change no sum) — so that the ranks' bitmaps can be all-gathered
+                              * while phase 2 runs (MappingEngine.overlap) */
+    int32_t reserved;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
@@ -409,6 +417,9 @@ int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double b
  *   all-reduce(compact[0 .. 10 * K_send), SUM)                   K_send <= capacity chosen by the host
  *   sls_adam_step_sparse(...)                                    Adam on every surfel, gradient from its slot or 0;
  *        skipped when the iteration is void; copies the status block to status_mirror (HOST-visible) if given.
+ *        `part`: 0 = every surfel in one launch; 1 = only the surfels OUTSIDE the union (their gradient is zero on
+ *        every rank: their update needs nothing from the collective, so this launch can run while the rows are being
+ *        reduced); 2 = only the union's surfels (after the reduction; mirrors the status) — 1 then 2 give the bits of 0.
  * word_prefix: DEVICE scratch of (N + 63) / 64 uint32. */
 size_t sls_grad_bitmap_words(int N);
 int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *union_bitmap, const float *grads_flat,
@@ -417,7 +428,7 @@ int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *un
 int sls_adam_step_sparse(int N, float *xyz, float *opacity_raw, float *scaling_raw, float *rotation_raw,
                          const uint64_t *union_bitmap, const uint32_t *word_prefix, const float *compact_reduced,
                          float *exp_avg, float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling,
-                         float lr_rotation, double beta1, double beta2, double eps, int64_t step,
+                         float lr_rotation, double beta1, double beta2, double eps, int64_t step, int part,
                          struct SlsMappingStatus *status_dev, struct SlsMappingStatus *status_mirror, void *stream);
 
 /* ---- simple-knn ---------------------------------------------------------

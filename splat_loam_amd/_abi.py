@@ -39,6 +39,7 @@ class SlsMappingConfig(C.Structure):
         ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
         ("deterministic", C.c_int32), ("block_masks", C.c_int32),
         ("grad_bitmap", C.c_void_p),
+        ("phase", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -104,7 +105,7 @@ _PROTOS = {
                                         C.c_int64, _VP, _VP, _VP, _VP]),
     "sls_grad_bitmap_words": (C.c_size_t, [C.c_int]),
     "sls_grad_compact": (C.c_int, [C.c_int, _VP, C.c_int, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
-    "sls_adam_step_sparse": (C.c_int, [C.c_int] + [_VP] * 9 + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, _VP, _VP, _VP]),
+    "sls_adam_step_sparse": (C.c_int, [C.c_int] + [_VP] * 9 + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, C.c_int, _VP, _VP, _VP]),
     "sls_projector_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sls_projector_prepare": (C.c_int, [C.c_int, C.c_int, _VP, C.c_size_t, _VP]),
     "sls_projector_intrinsics": (C.c_int, [C.c_int, _VP, C.c_int, C.c_int, C.c_float, _VP, _VP, C.c_size_t, _VP]),

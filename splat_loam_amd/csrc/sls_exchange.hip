@@ -96,6 +96,38 @@ __global__ __launch_bounds__(256) void exchange_compact_kernel(int N, const uint
     for (int k = 0; k < 4; ++k) o[6 + k] = grads[6 * n + 4 * (size_t)i + k];
 }
 
+// The bitmap EARLY (SlsMappingConfig.phase = 1): before the projection's backward has produced a single gradient, the
+// set of surfels that CAN get one is known — those the tile backward reached (its `touched` marks) and those whose larger
+// raw scale is within a margin of the regulariser's threshold (the backward decides that with its own exp(); the margin of
+// 1e-3 in log scale is four orders above its rounding).  A superset of the non-zero gradients: the extra rows are zeros.
+__global__ __launch_bounds__(256) void touched_bitmap_kernel(int N, const uint8_t *__restrict__ touched,
+                                                             const float2 *__restrict__ scaling_raw, float log_smax_margin,
+                                                             int reg_on, const uint32_t *__restrict__ status_block,
+                                                             uint64_t *__restrict__ bitmap, int nwords)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool on = false;
+    if (i < N) {
+        on = touched[i] != 0;
+        if (reg_on) { const float2 s = scaling_raw[i]; on = on || fmaxf(s.x, s.y) >= log_smax_margin; }
+    }
+    const uint64_t word = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && i < N) bitmap[i >> 6] = word;
+    if (i == 0) {      // this rank's verdict behind the bitmap (all of it is known since the binning)
+        const uint32_t bits = status_block[1];
+        bitmap[nwords] = (bits & 1u) ? 1ull : 0ull;
+        bitmap[nwords + 1] = (bits & ~1u) ? 1ull : 0ull;
+    }
+}
+int launch_touched_bitmap(int N, const uint8_t *touched, const float *scaling_raw, float smax, float pen,
+                          const uint32_t *status_block, uint64_t *bitmap, hipStream_t st)
+{
+    hipLaunchKernelGGL(touched_bitmap_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, touched, (const float2 *)scaling_raw,
+                       logf(fmaxf(smax, 1e-30f)) - 1e-3f, pen != 0.0f ? 1 : 0, status_block, bitmap, (N + 63) / 64);
+    SLS_LAUNCH_CHECK("touched_bitmap_kernel");
+    return SLS_OK;
+}
+
 struct SparseAdamArgs {
     float *xyz, *opacity, *scaling, *rotation;
     float *exp_avg, *exp_avg_sq;          // flat buckets [xyz 3N | opacity N | scaling 2N | rotation 4N]
@@ -105,14 +137,15 @@ struct SparseAdamArgs {
 
 // torch.optim.Adam on every surfel; the gradient comes from the reduced compact buffer (union surfels) or is zero.
 // Skipped as a whole when the group voided the iteration; the last kernel of the iteration: mirrors the status.
+// part: 0 = every surfel, 1 = only those outside the union (zero gradient on every rank), 2 = only the union's
 __global__ __launch_bounds__(256) void exchange_adam_kernel(int N, SparseAdamArgs a, const uint64_t *__restrict__ bitmap,
                                                             const uint32_t *__restrict__ word_prefix,
                                                             const float *__restrict__ compact,
                                                             const uint32_t *__restrict__ status_block,
-                                                            uint32_t *__restrict__ status_mirror)
+                                                            uint32_t *__restrict__ status_mirror, int part)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && status_mirror) mirror_status_block(status_block, status_mirror);
+    if (i == 0 && status_mirror && part != 1) mirror_status_block(status_block, status_mirror);
     if (status_block[1] != 0u) return;        // void: the verdict of the group or an exchange buffer too small
     if (i >= N) return;
     float g[10];
@@ -120,7 +153,9 @@ __global__ __launch_bounds__(256) void exchange_adam_kernel(int N, SparseAdamArg
     for (int k = 0; k < 10; ++k) g[k] = 0.0f;
     const uint64_t word = bitmap[i >> 6];
     const int b = i & 63;
-    if ((word >> b) & 1ull) {
+    const bool in_union = (word >> b) & 1ull;
+    if ((part == 1 && in_union) || (part == 2 && !in_union)) return;
+    if (in_union) {
         const uint32_t slot = word_prefix[i >> 6] + (uint32_t)__popcll(word & ((1ull << b) - 1ull));
         const float *s = compact + (size_t)slot * 10;
 #pragma unroll
@@ -181,9 +216,10 @@ int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *un
 int sls_adam_step_sparse(int N, float *xyz, float *opacity, float *scaling, float *rotation,
                          const uint64_t *union_bitmap, const uint32_t *word_prefix, const float *compact_reduced,
                          float *exp_avg, float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling,
-                         float lr_rotation, double beta1, double beta2, double eps, int64_t step,
+                         float lr_rotation, double beta1, double beta2, double eps, int64_t step, int part,
                          SlsMappingStatus *status_dev, SlsMappingStatus *status_mirror, void *stream)
 {
+    SLS_REQUIRE(part >= 0 && part <= 2, "part: 0 every surfel, 1 outside the union, 2 the union");
     SLS_REQUIRE(N > 0 && xyz && opacity && scaling && rotation && union_bitmap && word_prefix && compact_reduced &&
                     exp_avg && exp_avg_sq && status_dev,
                 "bad argument");
@@ -196,7 +232,7 @@ int sls_adam_step_sparse(int N, float *xyz, float *opacity, float *scaling, floa
     a.c = make_adam_coef(beta1, beta2, eps, step);
     ScopedTimer tm(T_ADAM, (hipStream_t)stream);
     hipLaunchKernelGGL(exchange_adam_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, a, union_bitmap,
-                       word_prefix, compact_reduced, (const uint32_t *)status_dev, (uint32_t *)status_mirror);
+                       word_prefix, compact_reduced, (const uint32_t *)status_dev, (uint32_t *)status_mirror, part);
     SLS_LAUNCH_CHECK("exchange_adam_kernel");
     return SLS_OK;
 }

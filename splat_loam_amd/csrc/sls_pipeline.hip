@@ -53,6 +53,8 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr,
                     int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr);
+int launch_touched_bitmap(int N, const uint8_t *touched, const float *scaling_raw, float smax, float pen,
+                          const uint32_t *status_block, uint64_t *bitmap, hipStream_t st);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
                 const uint32_t *skip_flag, hipStream_t stream, const float *void_flags = nullptr,
                 uint32_t *status_block = nullptr, uint32_t *status_mirror = nullptr);
@@ -331,6 +333,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_REQUIRE(R_capacity > 0 && R_capacity < (1ull << 32), "bad instance capacity");
     SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     // (every argument check before the first launch: an argument error must not leave half an iteration on the stream)
+    SLS_REQUIRE(cfg->phase >= 0 && cfg->phase <= 2, "phase: 0 whole iteration, 1 up to the tile backward, 2 the rest");
     SLS_REQUIRE(!cfg->grad_bitmap || (!cfg->apply_adam && !cfg->grad_chunk),
                 "the gradient bitmap belongs to apply_adam = 0 with the flat bucket");
     SLS_REQUIRE(!cfg->grad_chunk ||
@@ -348,89 +351,99 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     const DevCam dc = make_devcam(*cam);
     const uint32_t cap = (uint32_t)R_capacity;
     if (allmap_out) *allmap_out = w.allmap;
-    // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
-    if (!cfg->workspace_ready) {
-        // first use of this workspace: the gradient records must start from zero; afterwards the backward
-        // of the projection leaves them zeroed behind itself (no 64*N-byte memset per iteration)
-        ScopedTimer tm(T_GREC_MEMSET, st);
-        SLS_HIP_CHECK(hipMemsetAsync(w.reg_accum, 0, w.zero_bytes, st));
-    }
-
-    // ---- forward ---------------------------------------------------------------
-    uint32_t *okeys, *ovals, *n_dev;
-    // the depth order lives in the workspace, or in a caller-owned buffer (one per keyframe, so that every
-    // keyframe of a window can repair ITS order when the mapper samples keyframes at random)
-    uint32_t *order = cfg->depth_order ? cfg->depth_order : w.order;
-    depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
-    // Repairing the previous order: its first step (sorting windows of the old order by the new keys) rides in the
-    // preprocess launch — it needs nothing the preprocess produces (SLS_NO_MERGED_SORT=1: two launches, for A/B runs)
-    static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
-    const bool merged_sort = cfg->reuse_depth_order >= 1 && !no_merge;
-    // Direct binning (sls_sort.hip) where it applies: no unsorted instance array, no scan of tiles_touched; the preprocess
-    // then leaves the emission records in the form its first kernel gathers (rectangle + block box)
-    const bool direct = bin_direct_possible(dc, N, cap);
-    int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
-                                   scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                   okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
-                                   merged_sort ? order : nullptr,
-                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0);
-    if (rc) return rc;
-    ScanHandoff handoff = { nullptr, 0, nullptr, 0 };   // the binning finishes (or does not need) the scan of tiles_touched
-    DirectBin db;
-    if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1);
-    rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
-                                 w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
-                                 merged_sort, direct ? &db : nullptr, (const int4 *)w.erec, dc.GX);
-    if (rc) return rc;
-    int in_tmp = 0;
-    const uint2 *bmask = nullptr;
-    // (pairs instead of values only if both tile kernels are the default 8x2 ones: no other reads them)
-    const bool pairs_ok = debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3;
-    if (direct) {
-        rc = launch_bin_direct(dc, N, cap, db, handoff.counted != 0, order, w.erec, nullptr, nullptr, w.sort_scratch, w.vals,
-                               w.ranges, &status_dev->R, &status_dev->overflow, handoff.resort_windows,
-                               handoff.resort_edges, pairs_ok ? &bmask : nullptr, cfg->block_masks, st);
-    } else {
-        rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
-                             (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
-                             w.offsets, w.tkeys, w.vals,
-                             w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
-                             &status_dev->overflow, st, &handoff, &status_dev->R,
-                             pairs_ok ? w.sbox : nullptr, &bmask, cfg->block_masks);
-    }
-    if (rc) return rc;
-    // (with the pairs the plain value arrays are not written: the list IS the pairs, two words apart)
-    const uint32_t *sorted_vals = bmask ? (const uint32_t *)bmask : (in_tmp ? w.vals_tmp : w.vals);
-    const int vals_stride = bmask ? 2 : 1;
-    rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
-                           nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
-                           cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
-                           w.block_cost, bmask);
-    if (rc) return rc;
-    // ---- loss + dL/dallmap --------------------------------------------------------
-    // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
-    // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
-    const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
-    // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
-    // passenger workgroups of the consumer's launch): 8x2 kernels, XCD-interleaved tile mapping (T % 32 == 0)
-    const bool order_bwd = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
-                           (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
-    ConsumerArgs cargs;
-    rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
-                         cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
-                         w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr,
-                         order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order);
-    if (rc) return rc;
-    // ---- backward -----------------------------------------------------------------
     uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
     const bool det = cfg->deterministic != 0;
-    if (det) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
-    const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
-    rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
-                           w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
-                           fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
-                           vals_stride, (int)debug_state().fwd_variant);
-    if (rc) return rc;
+    // cfg->phase: 0 = the whole iteration; 1 = up to the tile backward (+ the early gradient bitmap); 2 = the rest
+    auto front = [&]() -> int {
+        // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
+        if (!cfg->workspace_ready) {
+            // first use of this workspace: the gradient records must start from zero; afterwards the backward
+            // of the projection leaves them zeroed behind itself (no 64*N-byte memset per iteration)
+            ScopedTimer tm(T_GREC_MEMSET, st);
+            SLS_HIP_CHECK(hipMemsetAsync(w.reg_accum, 0, w.zero_bytes, st));
+        }
+
+        // ---- forward ---------------------------------------------------------------
+        uint32_t *okeys, *ovals, *n_dev;
+        // the depth order lives in the workspace, or in a caller-owned buffer (one per keyframe, so that every
+        // keyframe of a window can repair ITS order when the mapper samples keyframes at random)
+        uint32_t *order = cfg->depth_order ? cfg->depth_order : w.order;
+        depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
+        // Repairing the previous order: its first step (sorting windows of the old order by the new keys) rides in the
+        // preprocess launch — it needs nothing the preprocess produces (SLS_NO_MERGED_SORT=1: two launches, for A/B runs)
+        static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
+        const bool merged_sort = cfg->reuse_depth_order >= 1 && !no_merge;
+        // Direct binning (sls_sort.hip) where it applies: no unsorted instance array, no scan of tiles_touched; the preprocess
+        // then leaves the emission records in the form its first kernel gathers (rectangle + block box)
+        const bool direct = bin_direct_possible(dc, N, cap);
+        int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
+                                       scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
+                                       okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
+                                       merged_sort ? order : nullptr,
+                                       merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0);
+        if (rc) return rc;
+        ScanHandoff handoff = { nullptr, 0, nullptr, 0 };   // the binning finishes (or does not need) the scan of tiles_touched
+        DirectBin db;
+        if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1);
+        rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
+                                     w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
+                                     merged_sort, direct ? &db : nullptr, (const int4 *)w.erec, dc.GX);
+        if (rc) return rc;
+        int in_tmp = 0;
+        const uint2 *bmask = nullptr;
+        // (pairs instead of values only if both tile kernels are the default 8x2 ones: no other reads them)
+        const bool pairs_ok = debug_state().fwd_variant == 3 && debug_state().bwd_variant == 3;
+        if (direct) {
+            rc = launch_bin_direct(dc, N, cap, db, handoff.counted != 0, order, w.erec, nullptr, nullptr, w.sort_scratch, w.vals,
+                                   w.ranges, &status_dev->R, &status_dev->overflow, handoff.resort_windows,
+                                   handoff.resort_edges, pairs_ok ? &bmask : nullptr, cfg->block_masks, st);
+        } else {
+            rc = launch_bin_sort(dc, N, &status_dev->R, cap, order, w.rect, w.tiles, dc.tile_cull ? w.tmask : nullptr,
+                                 (dc.GX < 65536 && dc.GY < 65536) ? w.erec : nullptr, w.depth,
+                                 w.offsets, w.tkeys, w.vals,
+                                 w.tkeys_tmp, w.vals_tmp, w.sort_scratch, w.sort_scratch_bytes, &in_tmp, w.ranges, nullptr,
+                                 &status_dev->overflow, st, &handoff, &status_dev->R,
+                                 pairs_ok ? w.sbox : nullptr, &bmask, cfg->block_masks);
+        }
+        if (rc) return rc;
+        // (with the pairs the plain value arrays are not written: the list IS the pairs, two words apart)
+        const uint32_t *sorted_vals = bmask ? (const uint32_t *)bmask : (in_tmp ? w.vals_tmp : w.vals);
+        const int vals_stride = bmask ? 2 : 1;
+        rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
+                               nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
+                               cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
+                               w.block_cost, bmask);
+        if (rc) return rc;
+        // ---- loss + dL/dallmap --------------------------------------------------------
+        // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
+        // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
+        const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
+        // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
+        // passenger workgroups of the consumer's launch): 8x2 kernels, XCD-interleaved tile mapping (T % 32 == 0)
+        const bool order_bwd = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
+                               (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
+        ConsumerArgs cargs;
+        rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
+                             cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
+                             w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr,
+                             order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order);
+        if (rc) return rc;
+        // ---- backward -----------------------------------------------------------------
+        if (det) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
+        const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
+        rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
+                               w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
+                               fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
+                               vals_stride, (int)debug_state().fwd_variant);
+        if (rc) return rc;
+        if (cfg->phase == 1 && cfg->grad_bitmap)      // the bitmap EARLY: an all-gather of it can overlap phase 2
+            return launch_touched_bitmap(N, touched, scaling_raw, cfg->scaling_max, cfg->scaling_max_penalty,
+                                         (const uint32_t *)status_dev, cfg->grad_bitmap, st);
+        return SLS_OK;
+    };
+    int rc = SLS_OK;
+    if (cfg->phase != 2) rc = front();
+    if (rc || cfg->phase == 1) return rc;
     // flat gradient bucket: [xyz 3N | opacity N | scaling 2N | rotation 4N] (optimizer group order)
     float *g_xyz = grads, *g_op = grads + (size_t)3 * N, *g_sc = grads + (size_t)4 * N, *g_rot = grads + (size_t)6 * N;
     // ---- backward of the projection + optimiser -------------------------------------------
@@ -447,7 +460,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.void_flags = cfg->void_flags_out;
     fuse.void_count = 1; fuse.void_stride = 0;
     if (det) { fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc; }
-    if (cfg->grad_bitmap) {
+    if (cfg->grad_bitmap && cfg->phase != 2) {      // (phase 2: phase 1 wrote the bitmap early — a superset, left alone)
         fuse.grad_bitmap = cfg->grad_bitmap;
         fuse.grad_bitmap_words = (N + 63) / 64;
     }

@@ -105,6 +105,26 @@ __device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32
 // gather per position anyway.  Tiles <= 512 (every size the reference's mapper meets and BASELINE config 3), D10 off;
 // anything else takes the emission + radix pass below.
 // ---------------------------------------------------------------------------
+#ifdef SLS_TRACE
+// Experiment build only (tools/build_variant.sh trace ... -DSLS_TRACE, tools/bin_trace.py): every wave of bin_direct_kernel
+// and every workgroup of the counting merge records the 100 MHz wall clock at its phases.
+__device__ uint32_t g_bin_trace[32768 * 8];      // per wave: start, loads done, counted, cursors ready, end, rounds, S, (pad)
+__device__ uint32_t g_merge_trace[1024 * 4];     // per workgroup: start, network done, counted + stored, end
+extern "C" int sls_debug_read_bin_trace(uint32_t *host_bin, uint32_t *host_merge)
+{
+    int rc = (int)hipMemcpyFromSymbol(host_bin, HIP_SYMBOL(g_bin_trace), sizeof(g_bin_trace));
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(host_merge, HIP_SYMBOL(g_merge_trace), sizeof(g_merge_trace));
+    return rc;
+}
+#define SLS_BT(k_) do { if (lane == 0) { const int wi_ = (int)blockIdx.x * WAVES + w; if (wi_ < 32768) g_bin_trace[8 * wi_ + (k_)] = (uint32_t)wall_clock64(); } } while (0)
+#define SLS_BTV(k_, v_) do { if (lane == 0) { const int wi_ = (int)blockIdx.x * WAVES + w; if (wi_ < 32768) g_bin_trace[8 * wi_ + (k_)] = (uint32_t)(v_); } } while (0)
+#define SLS_MT(k_) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_merge_trace[4 * blockIdx.x + (k_)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define SLS_BT(k_)
+#define SLS_BTV(k_, v_)
+#define SLS_MT(k_)
+#endif
+
 // The emission record of a surfel, 8 bytes: x = its tile rectangle in ONE word — txlo (9 bits) | ncols (10) | tylo (6) |
 // nrows (7), zero: nothing emitted; grids up to 512 x 64 tiles (bin_direct_possible) — y = its block box.
 __host__ __device__ inline uint32_t pack_rect32(int txlo, int ncols, int tylo, int nrows)
@@ -666,6 +686,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) s_hist[d] = 0u;   // (the network's barriers come before its use)
     }
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2, o0 = 2 * (int)threadIdx.x;
+    SLS_MT(0);
     uint64_t e[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -674,6 +695,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         e[q] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
     }
     bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
+    SLS_MT(1);
     uint32_t v = 0;
     if (DIRECT) {
         uint2 er[2];
@@ -714,8 +736,10 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         if (o0 + q == hi) edges[2 * blockIdx.x + 1] = e[q];
     }
     __syncthreads();
+    SLS_MT(2);
     if (DIRECT) {
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) db.cnt[(size_t)d * db.nchunks + blockIdx.x] = s_hist[d];
+        SLS_MT(3);
     } else if (threadIdx.x < 4) {
         const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
         if (base + (int)threadIdx.x * 256 >= 0 && blk * 256 < N)
@@ -791,6 +815,7 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     __shared__ uint32_t s_part[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk = (int)blockIdx.x / SPLIT, sub = (int)blockIdx.x % SPLIT;
+    SLS_BT(0);
     if (resort_windows > 0 && blockIdx.x == 0) {
         for (int b = tid; b + 1 < resort_windows; b += TPB)
             if (resort_edges[2 * b + 1] >= resort_edges[2 * (b + 1)]) atomicOr(fail_flag, kResortFailed);
@@ -836,10 +861,12 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     const uint32_t first = incl - t;
     s_lane[w][lane] = make_uint4(er.x, er.y, g, first);
     __syncthreads();
+    SLS_BT(1);
     // per-wave counts (the order inside a wave does not matter for counting: every lane walks its own rectangle)
     count_rect_tiles(er.x, GX, s_cur + w * BINS);
 #pragma unroll
     for (int m = 0; m < SPLIT - 1; ++m) count_rect_tiles(front[m], GX, s_pre);
+    SLS_BT(2);
     // digit bases: exclusive scan of the tile totals (PER consecutive ones per thread)
     uint32_t loc[PER], dsum = 0;
 #pragma unroll
@@ -878,6 +905,9 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
         }
     }
     __syncthreads();
+    SLS_BT(3);
+    SLS_BTV(5, (S + 63u) / 64u);
+    SLS_BTV(6, S);
     // The wave's S instances, 64 at a time in emission order (lane-major, then the rectangle row-major).  Owner of slot q:
     // the last lane whose first instance is <= q — every lane marks the slot its instances start at, a max-scan over the
     // round's 64 slots (carried on from the previous round) names the owner: one LDS round trip and six DPP steps.
@@ -924,6 +954,7 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
         }
         __builtin_amdgcn_wave_barrier();
     }
+    SLS_BT(4);
 }
 
 // A2 on the depth-ordered surfels, level 1: per-block sums of tiles[order[i]]

@@ -157,6 +157,12 @@ class MappingEngine:
         self.exchanged_bytes = 0          # bytes this rank handed to collectives in the last keyframe-parallel step
         self.exchange_at_world_1 = False  # take the keyframe-parallel path (collectives + separate Adam) in a 1-rank group too
         self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
+        # sparse scheme only: overlap the exchange with what does not need it — the bitmaps are all-gathered on a side
+        # stream while the projection's backward runs (SlsMappingConfig.phase), the union's rows are reduced while Adam
+        # updates the surfels outside the union (sls_adam_step_sparse part 1 / 2).  Same parameters to the bit.
+        self.overlap = os.environ.get("SLS_DP_OVERLAP", "0") == "1"
+        self._side = None                 # the side stream the collectives are issued from
+        self._last_call = None            # (arguments, config) of the last sls_mapping_step: phase 2 repeats them
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
     # when keep_grads is set; keyframe-parallel mode always fills and all-reduces it)
@@ -225,7 +231,13 @@ class MappingEngine:
                 raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
         return ps
 
-    def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None, allow_reuse=True):
+    def _enqueue_rest(self):
+        """Phase 2 of the iteration _enqueue(..., phase=1) started: the projection's backward, same arguments."""
+        args, cfg = self._last_call
+        cfg.phase, cfg.workspace_ready = 2, 1
+        _abi.check(_abi.lib().sls_mapping_step(*args), "sls_mapping_step (phase 2)")
+
+    def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None, allow_reuse=True, phase=0):
         lib = _abi.lib()
         H, W = int(camera.image_height), int(camera.image_width)
         settings = GaussianRasterizationSettings(H, W, 1.0, camera.world_view_transform, camera.projection_matrix)
@@ -260,14 +272,15 @@ class MappingEngine:
         cfg.status_mirror = mirror
         # keyframe-parallel mode: the void bits leave the step as two floats behind the gradient bucket
         cfg.void_flags_out = None if (apply_adam or self._dp is not None) else self.grads.data_ptr() + 4 * 10 * self.N
-        _abi.check(lib.sls_mapping_step(
-            C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
-            self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
-            aux.gt.data_ptr(), aux.valid.data_ptr(), aux.n_valid, ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
-            aux.col_h.data_ptr(), aux.row_h.data_ptr(), C.byref(cfg), self.capacity, ws_ptr, ws_bytes,
-            (self.status if status is None else status).data_ptr(), C.byref(self.allmap_ptr),
-            torch.cuda.current_stream(self.dev).cuda_stream),
-            "sls_mapping_step")
+        cfg.phase = int(phase)
+        args = (C.byref(ce.cam), self.N, xyz.data_ptr(), scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
+                self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.t + 1,
+                aux.gt.data_ptr(), aux.valid.data_ptr(), aux.n_valid, ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
+                aux.col_h.data_ptr(), aux.row_h.data_ptr(), C.byref(cfg), self.capacity, ws_ptr, ws_bytes,
+                (self.status if status is None else status).data_ptr(), C.byref(self.allmap_ptr),
+                torch.cuda.current_stream(self.dev).cuda_stream)
+        self._last_call = (args, cfg) if phase == 1 else None      # (cfg and the camera entry stay alive with it)
+        _abi.check(lib.sls_mapping_step(*args), "sls_mapping_step")
 
     @staticmethod
     def _void_reason(st):
@@ -345,7 +358,8 @@ class MappingEngine:
             else:
                 rank = dist.get_rank(group)
                 self._ensure_dp(group)
-                self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0), allow_reuse=reuse_ok)
+                self._enqueue(camera, apply_adam=False, with_regulariser=(rank == 0), allow_reuse=reuse_ok,
+                              phase=self._phase_for_exchange())
                 # the step left its void flags behind the gradients: no torch glue kernels; any rank's flag voids
                 # the iteration everywhere: Adam reads the reduced flags and stores the group's verdict into the
                 # local status word, so the one status read below is the only sync
@@ -381,7 +395,7 @@ class MappingEngine:
             # gradient all-reduce and guard Adam), so the host can lag here exactly as on one GPU
             self._ensure_dp(group)
             self._enqueue(camera, apply_adam=False, with_regulariser=(dist.get_rank(group) == 0),
-                          status=self._lag_dev[slot])
+                          status=self._lag_dev[slot], phase=self._phase_for_exchange())
             self._exchange_and_adam(group, self._lag_dev[slot],
                                     self._lag_host[slot].data_ptr() if self.status_mirror else None)
             if not self.status_mirror:
@@ -536,7 +550,55 @@ class MappingEngine:
         self._dp = {"G": G, "rank": rank, "C": C, "flat": flat, "lo": lo, "hi": hi,
                     "gshard": torch.zeros((C + 4,), dtype=torch.float32, device=self.dev)}
 
+    def _phase_for_exchange(self):
+        """1 = the native step stops after the tile backward (the overlapped sparse exchange runs the rest itself)"""
+        return 1 if (self.overlap and self._sx is not None) else 0
+
+    def _exchange_overlapped(self, group, status, mirror):
+        """dp_mode "sparse" with the collectives off the critical path (self.overlap).  Stream picture:
+            main:  ... tile backward | early bitmap |  projection's backward   | compact |  Adam outside the union  | Adam on the union
+            side:                                   |  all-gather of bitmaps   |         |  all-reduce of the rows  |
+        The early bitmap is a superset of the non-zero gradients (touched by the tile backward, or within a margin of
+        the regulariser's threshold): the union carries some all-zero rows, no sum changes, the parameters are those of
+        the serial exchange to the bit."""
+        lib, sx, N = _abi.lib(), self._sx, self.N
+        main = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        side = self._side
+        side.wait_stream(main)                          # the early bitmap is written
+        with torch.cuda.stream(side):
+            w1 = dist.all_gather_into_tensor(sx["all"], sx["mine"], group=group, async_op=True)
+        self._enqueue_rest()                            # main: the projection's backward fills the gradient bucket
+        w1.wait()                                       # (main waits for the gathered bitmaps)
+        main.wait_stream(side)
+        st = main.cuda_stream
+        G = int(sx["all"].numel() // sx["mine"].numel())
+        send = int(sx["send"])
+        _abi.check(lib.sls_grad_compact(N, sx["all"].data_ptr(), G, sx["bitmap"].data_ptr(), self.grads.data_ptr(),
+                                        sx["compact"].data_ptr(), send, sx["prefix"].data_ptr(), status.data_ptr(), st),
+                   "sls_grad_compact")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            w2 = dist.all_reduce(sx["compact"][:10 * send], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        xyz, scaling, rotation, opacity = self._params()
+
+        def adam(part, mir):
+            _abi.check(lib.sls_adam_step_sparse(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
+                                                rotation.data_ptr(), sx["bitmap"].data_ptr(), sx["prefix"].data_ptr(),
+                                                sx["compact"].data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2],
+                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1, part,
+                                                status.data_ptr(), mir, st), "sls_adam_step_sparse")
+        adam(1, None)                                   # main: the surfels no rank touched — while the rows travel
+        w2.wait()
+        main.wait_stream(side)
+        adam(2, mirror)                                 # the union's surfels; mirrors the status
+        self.exchanged_bytes = 8 * int(sx["mine"].numel()) + 40 * send
+
     def _exchange_and_adam(self, group, status, mirror):
+        if self._phase_for_exchange() == 1:
+            return self._exchange_overlapped(group, status, mirror)
         ev = None
         if self.comm_events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -560,7 +622,7 @@ class MappingEngine:
                                                 rotation.data_ptr(), sx["bitmap"].data_ptr(), sx["prefix"].data_ptr(),
                                                 sx["compact"].data_ptr(), self.exp_avg.data_ptr(),
                                                 self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2],
-                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1,
+                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1, 0,
                                                 status.data_ptr(), mirror, st), "sls_adam_step_sparse")
             if ev:
                 ev[2].record(); ev[3].record()
