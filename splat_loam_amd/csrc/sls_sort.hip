@@ -1474,9 +1474,11 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     }
     {
         ScopedTimer tm(T_SORT_SCATTER, st);
-        // (SLS_BIN_SPLIT=1|2|4: workgroups per chunk, for A/B runs; default 4)
-        static const int split_env = getenv("SLS_BIN_SPLIT") ? atoi(getenv("SLS_BIN_SPLIT")) : 4;
-        const int split = (split_env == 1 || split_env == 2) ? split_env : 4;
+        // (SLS_BIN_SPLIT=2|4: that many workgroups per chunk, for A/B runs.  Measured, tools/bin_trace.py: a wave never has
+        //  more than 8 rounds at BASELINE config 3 — the launch is its chain of phases, not its heaviest chunk — and
+        //  the sub-chunks' extra loads and counts cost more than the split gives: 24.8 / 24.0 / 26.6 us with 1 / 2 / 4)
+        static const int split_env = getenv("SLS_BIN_SPLIT") ? atoi(getenv("SLS_BIN_SPLIT")) : 1;
+        const int split = (split_env == 2 || split_env == 4) ? split_env : 1;
 #define SLS_DIRECT3(B_, P_, S_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_, S_>), dim3(db.nchunks * S_), dim3(kDirectChunk / S_), 0, st, N, cam.GX, db, \
                                order, (const uint2 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
                                total_out, overflow, resort_windows, resort_edges, overflow)
