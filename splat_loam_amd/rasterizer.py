@@ -149,11 +149,54 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_DT = {"f32": (torch.float32, 4), "i32": (torch.int32, 4), "i64": (torch.int64, 8), "u8": (torch.uint8, 1)}
+
+
+class _Arena:
+    """ONE device allocation carved into the named buffers of a forward stage: a forward needs some twenty-five
+    buffers, and twenty-five torch.empty calls were half of the drop-in path's host time at the mapper's real sizes.
+    Views are made on demand (the tests look at everything, the mapper at two of them)."""
+    __slots__ = ("base", "spec")
+
+    def __init__(self, dev, spec):
+        off, table = 0, {}
+        for name, kind, shape in spec:
+            dt, size = _DT[kind]
+            n = 1
+            for d in shape:
+                n *= int(d)
+            table[name] = (off, n * size, dt, tuple(int(d) for d in shape))
+            off += (n * size + 255) & ~255
+        self.spec = table
+        self.base = torch.empty((max(off, 256),), dtype=torch.uint8, device=dev)
+
+    def ptr(self, name) -> int:
+        return self.base.data_ptr() + self.spec[name][0]
+
+    def view(self, name) -> torch.Tensor:
+        off, nbytes, dt, shape = self.spec[name]
+        return self.base[off:off + nbytes].view(dt).view(shape)
+
+
 class ForwardState:
-    """Everything the backward (and the tests) need from one forward."""
-    __slots__ = ("cam", "N", "R", "rec", "radii", "rect", "tiles", "tmask", "sbox", "depth", "order", "offsets", "keys",
-                 "vals", "vals_ptr", "vals_stride", "sort_scratch", "ranges", "pix_state", "pix_contrib", "tile_consumed",
-                 "block_masks", "block_masks_shape", "allmap")
+    """Everything the backward (and the tests) need from one forward: two arenas (stage 1, stage 2) and the scalars.
+    Buffers are reached as attributes (`st.radii`, `st.allmap`, ...), views created when asked for."""
+    __slots__ = ("cam", "N", "R", "a1", "a2", "keys", "_vals", "vals_ptr", "vals_stride", "block_masks_shape", "_views")
+
+    def __getattr__(self, name):
+        # (only reached for names that are not slots: the arenas' buffers)
+        views = object.__getattribute__(self, "_views")
+        if name in views:
+            return views[name]
+        for arena in (object.__getattribute__(self, "a1"), object.__getattribute__(self, "a2")):
+            if arena is not None and name in arena.spec:
+                views[name] = arena.view(name)
+                return views[name]
+        if name == "vals":           # the sorted list of surfel indices
+            return sorted_list(self)
+        if name == "block_masks":
+            return None
+        raise AttributeError(name)
 
 
 def list_pairs_mode() -> int:
@@ -190,80 +233,76 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
             torch.cuda.synchronize(dev)
 
     s = ForwardState()
-    s.cam, s.N = ce, N
-    i32, u32, f32 = torch.int32, torch.int32, torch.float32   # uint32 buffers are carried as int32 tensors
-    s.rec = torch.empty((N, lib.sls_rec_stride()), dtype=f32, device=dev)
-    s.radii = torch.empty((N,), dtype=i32, device=dev)
-    s.rect = torch.empty((N, 4), dtype=i32, device=dev)
-    s.tiles = torch.empty((N,), dtype=u32, device=dev)
-    s.tmask = torch.empty((N,), dtype=torch.int64, device=dev)     # D10: which tiles of the rectangle are emitted
-    s.sbox = torch.empty((N,), dtype=u32, device=dev)              # the surfels' block boxes (for the list's block masks)
-    s.depth = torch.empty((N,), dtype=f32, device=dev)
-    s.order = torch.empty((N,), dtype=u32, device=dev)
-    s.offsets = torch.empty((N,), dtype=u32, device=dev)
-    total = torch.zeros((1,), dtype=u32, device=dev)
+    s.cam, s.N, s.a2, s.keys, s._views = ce, N, None, None, {}
+    # (uint32 buffers are carried as int32 tensors)
     sb = int(lib.sls_stage1_scratch_bytes(N))
-    scratch1 = torch.empty((max(sb, 4),), dtype=torch.uint8, device=dev)
+    a1 = s.a1 = _Arena(dev, (("rec", "f32", (N, lib.sls_rec_stride())), ("radii", "i32", (N,)), ("rect", "i32", (N, 4)),
+                             ("tiles", "i32", (N,)), ("tmask", "i64", (N,)),      # D10: which tiles of the rectangle are emitted
+                             ("sbox", "i32", (N,)),                                # the surfels' block boxes (for the list's block masks)
+                             ("depth", "f32", (N,)), ("order", "i32", (N,)), ("offsets", "i32", (N,)),
+                             ("total", "i32", (4,)), ("scratch1", "u8", (max(sb, 4),))))
     _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                       opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
-                                      s.rec.data_ptr(), s.radii.data_ptr(), s.rect.data_ptr(),
-                                      s.tiles.data_ptr(), s.tmask.data_ptr(), s.sbox.data_ptr(), s.depth.data_ptr(),
-                                      s.order.data_ptr(), s.offsets.data_ptr(),
-                                      total.data_ptr(), scratch1.data_ptr(), sb, st), "sls_forward_stage1")
+                                      a1.ptr("rec"), a1.ptr("radii"), a1.ptr("rect"), a1.ptr("tiles"), a1.ptr("tmask"),
+                                      a1.ptr("sbox"), a1.ptr("depth"), a1.ptr("order"), a1.ptr("offsets"),
+                                      a1.ptr("total"), a1.ptr("scratch1"), sb, st), "sls_forward_stage1")
     dbg()
-    R = int(total.item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
+    R = int(a1.view("total")[0].item()) & 0xFFFFFFFF   # the one device->host sync of the forward (as in the lineage)
     s.R = R
     Ra = max(R, 1)
-    keys_a = torch.empty((Ra,), dtype=u32, device=dev)
-    keys_b = torch.empty((Ra,), dtype=u32, device=dev)
-    vals_a = torch.empty((Ra,), dtype=u32, device=dev)
-    vals_b = torch.empty((Ra,), dtype=u32, device=dev)
     ssb = int(lib.sls_sort_scratch_bytes(R))
-    s.sort_scratch = torch.empty((max(ssb, 4),), dtype=torch.uint8, device=dev)
-    s.ranges = torch.empty((T, 2), dtype=u32, device=dev)
-    s.allmap = torch.empty((7, H, W), dtype=f32, device=dev)
-    s.pix_state = torch.empty((H * W, 4), dtype=f32, device=dev)
-    s.pix_contrib = torch.empty((H * W, 2), dtype=u32, device=dev)
-    s.tile_consumed = torch.empty((T,), dtype=u32, device=dev)
     # forward -> backward hand-over: 128 B per instance of capacity (room for every list entry in each of a tile's 16
     # pixel blocks; only what contributes is written).  SLS_NO_HANDOVER=1 (memory-tight callers): no buffer, the
     # backward culls the tiles' lists itself (about a third slower at the mapper's sizes).
-    s.block_masks = None if os.environ.get("SLS_NO_HANDOVER", "0") == "1" else \
-        torch.empty((int(lib.sls_block_mask_bytes(R, H, W)) // 8,), dtype=torch.int64, device=dev)
+    hand_over = os.environ.get("SLS_NO_HANDOVER", "0") != "1"
+    spec2 = [("allmap", "f32", (7, H, W)), ("ranges", "i32", (T, 2)), ("pix_state", "f32", (H * W, 4)),
+             ("pix_contrib", "i32", (H * W, 2)), ("tile_consumed", "i32", (T,)),
+             ("keys_a", "i32", (Ra,)), ("keys_b", "i32", (Ra,)), ("vals_a", "i32", (Ra,)), ("vals_b", "i32", (Ra,)),
+             ("sort_scratch", "u8", (max(ssb, 4),))]
+    if hand_over:
+        spec2.append(("block_masks", "i64", (int(lib.sls_block_mask_bytes(R, H, W)) // 8,)))
+    a2 = s.a2 = _Arena(dev, spec2)
     in_tmp, stride, shape = C.c_int(0), C.c_int(1), C.c_int(0)
     lst = C.c_void_p(0)
-    _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, s.rec.data_ptr(), s.rect.data_ptr(), s.tiles.data_ptr(),
-                                      s.tmask.data_ptr(), s.sbox.data_ptr(), s.depth.data_ptr(), s.order.data_ptr(),
-                                      s.offsets.data_ptr(), total.data_ptr(),
-                                      keys_a.data_ptr(), vals_a.data_ptr(), keys_b.data_ptr(), vals_b.data_ptr(),
-                                      s.sort_scratch.data_ptr(), ssb, C.byref(in_tmp), None,
+    _abi.check(lib.sls_forward_stage2(C.byref(cam), N, R, a1.ptr("rec"), a1.ptr("rect"), a1.ptr("tiles"),
+                                      a1.ptr("tmask"), a1.ptr("sbox"), a1.ptr("depth"), a1.ptr("order"),
+                                      a1.ptr("offsets"), a1.ptr("total"),
+                                      a2.ptr("keys_a"), a2.ptr("vals_a"), a2.ptr("keys_b"), a2.ptr("vals_b"),
+                                      a2.ptr("sort_scratch"), ssb, C.byref(in_tmp), None,
                                       list_pairs_mode() if list_pairs is None else int(list_pairs),
-                                      C.byref(lst), C.byref(stride), s.ranges.data_ptr(),
-                                      ce.col_cs.data_ptr(),
-                                      ce.row_cs.data_ptr(), s.allmap.data_ptr(), s.pix_state.data_ptr(),
-                                      s.pix_contrib.data_ptr(), s.tile_consumed.data_ptr(),
-                                      s.block_masks.data_ptr() if s.block_masks is not None else None,
-                                      C.byref(shape), st),
+                                      C.byref(lst), C.byref(stride), a2.ptr("ranges"),
+                                      ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), a2.ptr("allmap"), a2.ptr("pix_state"),
+                                      a2.ptr("pix_contrib"), a2.ptr("tile_consumed"),
+                                      a2.ptr("block_masks") if hand_over else None, C.byref(shape), st),
                "sls_forward_stage2")
     dbg()
     s.vals_stride, s.block_masks_shape = int(stride.value), int(shape.value)
-    if s.vals_stride == 2:
-        # the list is the tile sort's (surfel, block mask) pairs inside the sort scratch: a strided view of it
-        off = int(lst.value) - s.sort_scratch.data_ptr()
-        s.vals = s.sort_scratch[off:off + 8 * Ra].view(torch.int32).view(Ra, 2)[:, 0]
-    else:
-        s.vals = vals_b if in_tmp.value else vals_a
-        s.sort_scratch = None
-    s.vals_ptr = int(lst.value) if R > 0 else s.vals.data_ptr()
-    if R == 0:
-        s.vals = s.vals[:0]
-    s.keys = None
-    if want_keys:   # (tile << 32 | depth bits) of every list entry, from the ranges, the list and the depths
-        cnt = (s.ranges[:, 1].long() - s.ranges[:, 0].long()) & 0xFFFFFFFF
-        tile = torch.repeat_interleave(torch.arange(T, device=dev, dtype=torch.int64), cnt)
-        bits = s.depth.view(torch.int32)[s.vals.long()].long() & 0xFFFFFFFF
-        s.keys = (tile << 32) | bits
+    s.vals_ptr = int(lst.value) if R > 0 else a2.ptr("vals_a")
+    s._vals = None
+    if want_keys:
+        _list_and_keys(s, T)
     return s
+
+
+def sorted_list(s: ForwardState) -> torch.Tensor:
+    """The sorted list of surfel indices (R entries) as a tensor: a plain array, or a strided view of the tile sort's
+    (surfel, block mask) pairs inside the sort scratch."""
+    if s._vals is None:
+        Ra = max(s.R, 1)
+        off = s.vals_ptr - s.a2.base.data_ptr()
+        v = s.a2.base[off:off + 4 * s.vals_stride * Ra].view(torch.int32).view(Ra, s.vals_stride)[:, 0]
+        s._vals = v[:0] if s.R == 0 else v
+    return s._vals
+
+
+def _list_and_keys(s: ForwardState, T: int) -> None:
+    """(tile << 32 | depth bits) of every list entry, from the ranges, the list and the depths"""
+    vals = sorted_list(s)
+    dev = vals.device
+    cnt = (s.ranges[:, 1].long() - s.ranges[:, 0].long()) & 0xFFFFFFFF
+    tile = torch.repeat_interleave(torch.arange(T, device=dev, dtype=torch.int64), cnt)
+    bits = s.depth.view(torch.int32)[vals.long()].long() & 0xFFFFFFFF
+    s.keys = (tile << 32) | bits
 
 
 def deterministic_mode() -> bool:
@@ -276,35 +315,31 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
     lib = _abi.lib()
     dev = means3D.device
     N = state.N
-    f32 = torch.float32
     dL = _f32c(dL_dallmap)
-    dmeans = torch.empty((N, 3), dtype=f32, device=dev)
-    dscales = torch.empty((N, 2), dtype=f32, device=dev)
-    drots = torch.empty((N, 4), dtype=f32, device=dev)
-    dopac = torch.empty((N, 1), dtype=f32, device=dev)
-    ce = state.cam
-    bm = state.block_masks.data_ptr() if state.block_masks is not None else None
-    if deterministic_mode() if deterministic is None else deterministic:
-        nbytes = int(lib.sls_backward_det_scratch_bytes(N))
-        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    det = deterministic_mode() if deterministic is None else deterministic
+    nbytes = int(lib.sls_backward_det_scratch_bytes(N)) if det else 0
+    out = _Arena(dev, (("dmeans", "f32", (N, 3)), ("dscales", "f32", (N, 2)), ("drots", "f32", (N, 4)), ("dopac", "f32", (N, 1)))
+                 + ((("scratch", "u8", (nbytes,)),) if det else (("grec", "f32", (N, lib.sls_grec_stride())),)))
+    ce, a1, a2 = state.cam, state.a1, state.a2
+    bm = a2.ptr("block_masks") if "block_masks" in a2.spec else None
+    if det:
         _abi.check(lib.sls_backward_det(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
-                                        rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
-                                        state.ranges.data_ptr(), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
-                                        ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
-                                        dL.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(), drots.data_ptr(),
-                                        dopac.data_ptr(), bm, state.block_masks_shape,
-                                        scratch.data_ptr(), nbytes, _stream(dev)), "sls_backward_det")
-        return dmeans, dscales, drots, dopac, None
-    grec = torch.empty((N, lib.sls_grec_stride()), dtype=f32, device=dev)
+                                        rotations.data_ptr(), a1.ptr("radii"), a1.ptr("rec"),
+                                        a2.ptr("ranges"), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
+                                        ce.row_cs.data_ptr(), a2.ptr("pix_state"), a2.ptr("pix_contrib"),
+                                        dL.data_ptr(), out.ptr("dmeans"), out.ptr("dscales"), out.ptr("drots"),
+                                        out.ptr("dopac"), bm, state.block_masks_shape,
+                                        out.ptr("scratch"), nbytes, _stream(dev)), "sls_backward_det")
+        return out.view("dmeans"), out.view("dscales"), out.view("drots"), out.view("dopac"), None
     _abi.check(lib.sls_backward(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
-                                rotations.data_ptr(), state.radii.data_ptr(), state.rec.data_ptr(),
-                                state.ranges.data_ptr(), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
-                                ce.row_cs.data_ptr(), state.pix_state.data_ptr(), state.pix_contrib.data_ptr(),
-                                dL.data_ptr(), grec.data_ptr(), dmeans.data_ptr(), dscales.data_ptr(),
-                                drots.data_ptr(), dopac.data_ptr(), bm,
+                                rotations.data_ptr(), a1.ptr("radii"), a1.ptr("rec"),
+                                a2.ptr("ranges"), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
+                                ce.row_cs.data_ptr(), a2.ptr("pix_state"), a2.ptr("pix_contrib"),
+                                dL.data_ptr(), out.ptr("grec"), out.ptr("dmeans"), out.ptr("dscales"),
+                                out.ptr("drots"), out.ptr("dopac"), bm,
                                 state.block_masks_shape, _stream(dev)),
                "sls_backward")
-    return dmeans, dscales, drots, dopac, grec
+    return out.view("dmeans"), out.view("dscales"), out.view("drots"), out.view("dopac"), out.view("grec")
 
 
 def frame_from_precomp(cov3D_precomp: torch.Tensor):

@@ -533,10 +533,12 @@ def test_mapping_engine_matches_unfused_step(device):
     assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
 
 
-def test_mapping_engine_lagged_status_read(device):
+@pytest.mark.parametrize("deterministic", [False, True], ids=["float-atomics", "deterministic"])
+def test_mapping_engine_lagged_status_read(device, deterministic):
     """sync="lagged" (status of iteration k read after iteration k+1 was enqueued)
     walks the same parameter trajectory and reports the same losses as the
-    synchronous mode, also across an overflow of the instance buffers."""
+    synchronous mode, also across an overflow of the instance buffers.  With deterministic accumulation
+    (SlsMappingConfig.deterministic) "the same" is meant to the bit."""
     from splat_loam_amd import synth
     from splat_loam_amd.engine import MappingEngine
     from splat_loam_amd.mapping import MappingConfig
@@ -550,6 +552,7 @@ def test_mapping_engine_lagged_status_read(device):
               for _ in range(2)]
     init = {k: getattr(models[0], k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
     ref, lag = MappingEngine(models[0], cfg), MappingEngine(models[1], cfg)
+    ref.deterministic = lag.deterministic = deterministic
     lag.capacity = 2048            # overflows on the first two (pipelined) iterations
     n_it = 6
     ref_losses = [ref.step(cam)["loss"] for _ in range(n_it)]
@@ -569,10 +572,13 @@ def test_mapping_engine_lagged_status_read(device):
         pa, pb = getattr(models[0], k).detach(), getattr(models[1], k).detach()
         moved = float((pa - init[k]).abs().max())
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.02 * moved, k
+        if deterministic:
+            assert torch.equal(pa, pb), f"deterministic accumulation: lagged and synchronous trajectories differ in {k}"
 
 
+@pytest.mark.parametrize("deterministic", [False, True], ids=["float-atomics", "deterministic"])
 @pytest.mark.parametrize("N", [30000, 4999], ids=["even-n", "odd-n"])   # odd N: separate optimiser kernel, unaligned scratch views
-def test_mapping_engine_depth_order_repair(device, N):
+def test_mapping_engine_depth_order_repair(device, N, deterministic):
     """reuse_depth_order: repairing the previous iteration's depth order (windowed re-sort +
     exactness check) gives the same iterations as sorting from scratch; when the surfels are
     moved so far that the repair cannot reach the exact order, the iteration is flagged,
@@ -590,6 +596,7 @@ def test_mapping_engine_depth_order_repair(device, N):
               for _ in range(2)]
     init = {k: getattr(models[0], k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
     full, rep = MappingEngine(models[0], cfg), MappingEngine(models[1], cfg)
+    full.deterministic = rep.deterministic = deterministic     # (then the two trajectories are compared to the bit)
     full.reuse_depth_order = False
     losses = [[], []]
     for phase in range(2):
@@ -627,6 +634,8 @@ def test_mapping_engine_depth_order_repair(device, N):
         pa, pb = getattr(models[0], k).detach(), getattr(models[1], k).detach()
         moved = float((pa - init[k]).abs().max())
         assert moved > 0 and float((pa - pb).abs().max()) <= 0.02 * moved, k
+        if deterministic:
+            assert torch.equal(pa, pb), f"deterministic accumulation: repaired and from-scratch trajectories differ in {k}"
 
 
 def test_mapping_engine_remap_after_prune_and_densify(device):
