@@ -39,13 +39,14 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
                       uint64_t *block_masks = nullptr, bool no_median_dist = false, uint32_t *block_cost = nullptr,
-                      const uint2 *bmask = nullptr);
+                      const uint2 *bmask = nullptr, bool order_in_handover = false);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
                       uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr,
                       uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr,
-                      const uint32_t *block_order = nullptr, int vals_stride = 1, int block_masks_shape = -1);
+                      const uint32_t *block_order = nullptr, int vals_stride = 1, int block_masks_shape = -1,
+                      bool order_in_handover = false);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -226,7 +227,8 @@ int sls_forward_stage2(const SlsCamera *cam, int N, uint64_t R, const float *rec
     *sorted_stride = bmask ? 2 : 1;
     if (block_masks_shape) *block_masks_shape = block_masks ? (int)debug_state().fwd_variant : 0;
     return launch_render_fwd(dc, ranges, sorted_vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
-                             tile_consumed, st, false, block_masks, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, bmask);
+                             tile_consumed, st, false, block_masks, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, bmask,
+                             true);       // (+ the backward's launch order into the hand-over buffer)
 }
 
 int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, const float *scales,
@@ -255,7 +257,7 @@ int sls_backward(const SlsCamera *cam, int N, uint64_t R, const float *means3D, 
                     "null pointer");
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
                                    grec, st, block_masks_shape ? block_masks : nullptr, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0,
-                                   nullptr, nullptr, nullptr, nullptr, nullptr, vals_stride, block_masks_shape);
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, vals_stride, block_masks_shape, true);
         if (rc) return rc;
     }
     return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, grec, dL_dmeans3D,
@@ -294,7 +296,7 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
         int rc = launch_render_bwd(dc, ranges, vals_sorted, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
                                    nullptr, st, block_masks_shape ? block_masks : nullptr,
                                    (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, nullptr, mx, acc,
-                                   nullptr, vals_stride, block_masks_shape);
+                                   nullptr, vals_stride, block_masks_shape, true);
         if (rc) return rc;
     }
     AdamFuse fuse;

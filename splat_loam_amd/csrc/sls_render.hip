@@ -12,7 +12,9 @@ namespace sls {
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask);
+                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover);
+bool handover_has_order(int T);
+const uint32_t *handover_block_order(const uint64_t *block_masks, int T);
 size_t block_mask_bytes(uint64_t cap, int T);
 int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, const float *pix_state,
@@ -34,7 +36,8 @@ DebugState &debug_state()
 int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                       const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                       uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed,
-                      uint64_t *block_masks, bool no_median_dist, uint32_t *block_cost, const uint2 *bmask)
+                      uint64_t *block_masks, bool no_median_dist, uint32_t *block_cost, const uint2 *bmask,
+                      bool order_in_handover)
 {
     const int T = cam.GX * cam.GY;
     // the block kernels combine their blocks' counters with atomicMax: start from zero
@@ -42,7 +45,7 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
         SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
                                    tile_consumed, block_masks, debug_state().fwd_variant - 2, st, no_median_dist,
-                                   debug_state().fwd_variant == 3 ? block_cost : nullptr, bmask);
+                                   debug_state().fwd_variant == 3 ? block_cost : nullptr, bmask, order_in_handover);
 }
 
 int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
@@ -50,7 +53,7 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st,
                       const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched,
                       const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
-                      const uint32_t *block_order, int vals_stride, int block_masks_shape)
+                      const uint32_t *block_order, int vals_stride, int block_masks_shape, bool order_in_handover)
 {
     // vals_stride: 1 = plain list of surfel indices, 2 = the tile sort's (surfel, block mask) pairs.
     // block_masks_shape: the pixel-block shape (sls_debug_variant numbering: 2 = 4x4, 3 = 8x2) of the forward that
@@ -58,6 +61,9 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
     // combination culls the tile's list itself (the buffer's tag word is the kernel's last guard).
     const int variant = det_max ? 3 : (int)debug_state().bwd_variant;
     const bool dense = block_masks != nullptr && block_masks_shape == variant;
+    // no order from the caller: the staged forward left one in the hand-over buffer (block_order_kernel)
+    if (!block_order && order_in_handover && dense && variant == 3 && handover_has_order(cam.GX * cam.GY))
+        block_order = handover_block_order(block_masks, cam.GX * cam.GY);
     return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
                                    grec, block_masks, variant - 2, st, no_median_dist_grad,
                                    touched, fused_consumer, det_max, det_acc,

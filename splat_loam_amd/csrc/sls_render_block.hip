@@ -111,11 +111,57 @@ __device__ __forceinline__ void quad_excl_total(float x, float k1, float k2, flo
 // mask + list 1000-1200, against 1600 per step — were 28 % of a wave's life at C3 and 40 % at the mapper's real
 // sizes, tools/wave_trace.py).
 // Layout in 8-byte words: [0] tag naming the producer's block shape; [1, 1 + T*8) the blocks' entry counts (u32,
-// T*16 of them); then the entries: block `sub` of a tile whose list is [first, first + n) owns
+// T*16 of them); [1 + T*8, 1 + T*16) the launch order of the backward's blocks, most expensive first (u32, written by
+// block_order_kernel behind the staged forward; sls_mapping_step keeps its own, made by the consumer's launch); then
+// the entries: block `sub` of a tile whose list is [first, first + n) owns
 // [first*16 + sub*n, first*16 + (sub+1)*n) — room for every entry of the tile, so 16 words per instance of capacity
 // (only what contributes is ever written or read).
 __host__ __device__ inline uint64_t block_mask_tag(int bw) { return 0x534C4C4953540000ull | (uint64_t)bw; }
-__host__ __device__ inline size_t block_list_entries_word(int T, int per_tile) { return 1 + ((size_t)T * per_tile + 1) / 2; }
+__host__ __device__ inline size_t block_list_order_word(int T, int per_tile) { return 1 + ((size_t)T * per_tile + 1) / 2; }
+__host__ __device__ inline size_t block_list_entries_word(int T, int per_tile) { return 1 + 2 * (((size_t)T * per_tile + 1) / 2); }
+__host__ __device__ inline uint32_t block_backward_cost(uint32_t entries)
+{
+    // steps, a round of 64 entries ~1.3 steps' worth + its latency (one byte: the order is a counting sort)
+    return min(255u, 2u * ((entries + 63u) / 64u) + (entries + 3u) / 4u);
+}
+
+// The backward's blocks of one XCD (index i = tile slot * 16 + block; tile = ((slot >> 2) * 8 + xcd) * 4 + (slot & 3),
+// the mapping of tile_of_block) ordered by their cost, most expensive first, from the forward's entry counts: a counting
+// sort per XCD, eight workgroups.  A permutation whatever the counts are: only speed depends on it.
+__global__ __launch_bounds__(256) void block_order_kernel(uint64_t *__restrict__ blk_mask, int T)
+{
+    constexpr int kPerTile = kTilePix / 16;
+    __shared__ uint32_t s_hist[256];
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(blk_mask + 1);
+    uint32_t *order = reinterpret_cast<uint32_t *>(blk_mask + block_list_order_word(T, kPerTile));
+    const int xcd = blockIdx.x, n_x = T * kPerTile / 8, tid = threadIdx.x;
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n_x; i += 256) {
+        const int ts = i / kPerTile;
+        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        atomicAdd(&s_hist[255u - block_backward_cost(counts[tile * kPerTile + (i % kPerTile)])], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {      // exclusive scan of the 256 bins
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = s_hist[tid * 4 + k]; sum += v[k]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (tid >= off) inc += t; }
+        uint32_t base = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_hist[tid * 4 + k] = base; base += v[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_x; i += 256) {
+        const int ts = i / kPerTile;
+        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
+        const uint32_t bin = 255u - block_backward_cost(counts[tile * kPerTile + (i % kPerTile)]);
+        order[(size_t)xcd * n_x + atomicAdd(&s_hist[bin], 1u)] = (uint32_t)i;
+    }
+}
 size_t block_mask_bytes(uint64_t cap, int T)
 {
     return sizeof(uint64_t) * (block_list_entries_word(T, kTilePix / 16) + (size_t)cap * (size_t)(kTilePix / 16));
@@ -372,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     }
     if (blk_mask && lane == 0) reinterpret_cast<uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] = ccnt;
     // cost of this block in the backward, for its longest-first launch order: steps, a round of 64 entries ~1.3 steps' worth + its latency
-    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, 2u * ((ccnt + 63u) / 64u) + (ccnt + 3u) / 4u);
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = block_backward_cost(ccnt);
     if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
         uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
 #pragma unroll
@@ -668,7 +714,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     }
     if (blk_mask && lane == 0) reinterpret_cast<uint32_t *>(blk_mask + 1)[tile * kPerTile + sub] = ccnt;
     // cost of this block in the backward, for its longest-first launch order: steps, a round of 64 entries ~1.3 steps' worth + its latency
-    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = min(255u, 2u * ((ccnt + 63u) / 64u) + (ccnt + 3u) / 4u);
+    if (block_cost && lane == 0) block_cost[tile * kPerTile + sub] = block_backward_cost(ccnt);
     if (tile_consumed) {   // tile value = max over its pixels (buffer zeroed by the launcher)
         uint32_t c = inside ? (done ? cons : (uint32_t)n) : 0u;
 #pragma unroll
@@ -972,6 +1018,13 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// the hand-over buffer carries a launch order for the backward (8x2 blocks, XCD-interleaved tile mapping)
+bool handover_has_order(int T) { return T % 32 == 0 && kTileW == 16 && kTileH == 16; }
+const uint32_t *handover_block_order(const uint64_t *block_masks, int T)
+{
+    return reinterpret_cast<const uint32_t *>(block_masks + block_list_order_word(T, kTilePix / 16));
+}
+
 #ifdef SLS_TRACE
 extern "C" int sls_debug_read_trace(uint32_t *host)
 {
@@ -994,7 +1047,7 @@ extern "C" int sls_debug_read_trace_marks(uint32_t *host)
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask)
+                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_FWD, st);
@@ -1017,6 +1070,11 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
 #undef SLS_FWD_DENSE
 #undef SLS_FWD_ARGS
     SLS_LAUNCH_CHECK("render_fwd_block_kernel");
+    if (order_in_handover && block_masks && shape == 1 && handover_has_order(T)) {
+        // the staged API: the order the backward launches its blocks in, from the counts the forward just wrote
+        hipLaunchKernelGGL(block_order_kernel, dim3(8), dim3(256), 0, st, block_masks, T);
+        SLS_LAUNCH_CHECK("block_order_kernel");
+    }
     return SLS_OK;
 }
 

@@ -553,6 +553,9 @@ def test_mapping_engine_lagged_status_read(device, deterministic):
     init = {k: getattr(models[0], k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
     ref, lag = MappingEngine(models[0], cfg), MappingEngine(models[1], cfg)
     ref.deterministic = lag.deterministic = deterministic
+    # (which forward kernel runs follows the instance capacity — dense rounds from 1500 instances per tile on — and the
+    #  two engines end with different capacities; the two forwards agree to ~1e-7, not to the bit: pin the choice)
+    ref.block_masks = lag.block_masks = 1
     lag.capacity = 2048            # overflows on the first two (pipelined) iterations
     n_it = 6
     ref_losses = [ref.step(cam)["loss"] for _ in range(n_it)]
@@ -597,6 +600,7 @@ def test_mapping_engine_depth_order_repair(device, N, deterministic):
     init = {k: getattr(models[0], k).detach().clone() for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
     full, rep = MappingEngine(models[0], cfg), MappingEngine(models[1], cfg)
     full.deterministic = rep.deterministic = deterministic     # (then the two trajectories are compared to the bit)
+    full.block_masks = rep.block_masks = 1
     full.reuse_depth_order = False
     losses = [[], []]
     for phase in range(2):
