@@ -25,7 +25,7 @@ void set_error(const char *fmt, ...)
 // ---------------------------------------------------------------------------
 static const char *kTimerNames[T_COUNT] = {
     "preprocess_fwd", "scan", "emit_keys", "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges",
-    "render_fwd", "grec_memset", "render_bwd", "preprocess_bwd", "adam", "knn", "consumer", "resort"
+    "render_fwd", "grec_memset", "render_bwd", "preprocess_bwd", "adam", "knn", "consumer", "resort", "bin_count", "bin_direct"
 };
 constexpr int kTimerPool = 8192;
 struct TimerState {

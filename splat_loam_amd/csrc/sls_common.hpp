@@ -38,7 +38,8 @@ void set_error(const char *fmt, ...);
 // figures).  Disabled: zero cost beyond one branch per launch.
 enum TimerSlot {
     T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT_KEYS, T_SORT_HIST, T_SORT_ROWSCAN, T_SORT_SCATTER, T_TILE_RANGES,
-    T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_RESORT, T_COUNT
+    T_RENDER_FWD, T_GREC_MEMSET, T_RENDER_BWD, T_PREPROCESS_BWD, T_ADAM, T_KNN, T_CONSUMER, T_RESORT, T_BIN_COUNT, T_BIN_DIRECT,
+    T_COUNT
 };
 // Debug / tuning switches (sls_debug_variant, sls_debug_wave_cycles, sls_timing_*): ONE set per process, relaxed
 // atomics — a backward reached through torch autograd runs on the autograd engine's device thread and must see

@@ -1453,7 +1453,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     const int T = cam.GX * cam.GY;
     if (bmask_out) *bmask_out = nullptr;
     if (!counted) {
-        ScopedTimer tm(T_EMIT_KEYS, st);
+        ScopedTimer tm(T_BIN_COUNT, st);
         hipLaunchKernelGGL(gather_count_kernel, dim3(db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, order,
                            (const uint2 *)erec_box, (const int4 *)rect, sbox, db);
         SLS_LAUNCH_CHECK("gather_count_kernel");
@@ -1473,7 +1473,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
         *bmask_out = bm.out;
     }
     {
-        ScopedTimer tm(T_SORT_SCATTER, st);
+        ScopedTimer tm(T_BIN_DIRECT, st);
         // (SLS_BIN_SPLIT=2|4: that many workgroups per chunk, for A/B runs.  Measured, tools/bin_trace.py: a wave never has
         //  more than 8 rounds at BASELINE config 3 — the launch is its chain of phases, not its heaviest chunk — and
         //  the sub-chunks' extra loads and counts cost more than the split gives: 24.8 / 24.0 / 26.6 us with 1 / 2 / 4)

@@ -24,20 +24,20 @@ class MappingConfig:
 
 
 def mapping_loss(render_pkg: dict, camera, model, cfg: MappingConfig) -> torch.Tensor:
-    """slam/mapper.py:158-199."""
-    est_alpha, est_depth = render_pkg["rend_alpha"], render_pkg["surf_depth"]
-    est_normal, surf_normal = render_pkg["rend_normal"], render_pkg["surf_normal"]
-    gt_alpha, gt_depth = camera.image_valid, camera.image_depth
-    valid = gt_alpha[0] == 1.0
-    geom_l1 = torch.abs(valid * (est_depth - gt_depth)).mean()
-    normal_loss = (1 - (est_normal[..., valid] * surf_normal[..., valid]).sum(dim=0)).mean()
-    normal_loss = normal_loss * cfg.opt_lambda_normal
-    alpha_loss = torch.nn.functional.binary_cross_entropy(
-        est_alpha[..., valid], gt_alpha[..., valid].float(), reduction="mean") * cfg.opt_lambda_alpha
-    scales_max = model.get_scaling.max(dim=1).values
-    over = scales_max[scales_max >= cfg.opt_scaling_max] - cfg.opt_scaling_max
-    reg_scales = (cfg.opt_scaling_max_penalty * over).sum()
-    return geom_l1 + alpha_loss + normal_loss + reg_scales
+    """The mapper's objective on render()'s maps — the four terms of slam/mapper.py:158-199, pinned by golden G2 / G5:
+    range error, agreement of the blended normals with the normals of the rendered range image, occupancy where the
+    sensor measured something, and a linear price on surfels longer than the cap."""
+    measured = camera.image_valid[0] == 1.0                    # (H, W): pixels that carry a measurement
+    alpha = render_pkg["rend_alpha"]
+    # mean over ALL pixels of the absolute range error at the measured ones
+    range_term = (measured * (render_pkg["surf_depth"] - camera.image_depth)).abs().mean()
+    cosine = (render_pkg["rend_normal"][..., measured] * render_pkg["surf_normal"][..., measured]).sum(dim=0)
+    normal_term = cfg.opt_lambda_normal * (1 - cosine).mean()
+    occupancy_term = cfg.opt_lambda_alpha * torch.nn.functional.binary_cross_entropy(
+        alpha[..., measured], camera.image_valid[..., measured].float(), reduction="mean")
+    longest = model.get_scaling.max(dim=1).values              # the larger of a surfel's two axes
+    size_term = cfg.opt_scaling_max_penalty * (longest[longest >= cfg.opt_scaling_max] - cfg.opt_scaling_max).sum()
+    return range_term + occupancy_term + normal_term + size_term
 
 
 def optimize_step(model, camera, cfg: MappingConfig, **render_kw) -> torch.Tensor:

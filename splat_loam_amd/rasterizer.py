@@ -236,14 +236,17 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     s.cam, s.N, s.a2, s.keys, s._views = ce, N, None, None, {}
     # (uint32 buffers are carried as int32 tensors)
     sb = int(lib.sls_stage1_scratch_bytes(N))
-    a1 = s.a1 = _Arena(dev, (("rec", "f32", (N, lib.sls_rec_stride())), ("radii", "i32", (N,)), ("rect", "i32", (N, 4)),
+    # (radii and allmap are what autograd hands to the caller, who may write into them in place: tensors of their own,
+    #  never views of an arena — torch forbids in-place changes of a view made inside a custom Function)
+    radii = s._views["radii"] = torch.empty((N,), dtype=torch.int32, device=dev)
+    a1 = s.a1 = _Arena(dev, (("rec", "f32", (N, lib.sls_rec_stride())), ("rect", "i32", (N, 4)),
                              ("tiles", "i32", (N,)), ("tmask", "i64", (N,)),      # D10: which tiles of the rectangle are emitted
                              ("sbox", "i32", (N,)),                                # the surfels' block boxes (for the list's block masks)
                              ("depth", "f32", (N,)), ("order", "i32", (N,)), ("offsets", "i32", (N,)),
                              ("total", "i32", (4,)), ("scratch1", "u8", (max(sb, 4),))))
     _abi.check(lib.sls_forward_stage1(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                       opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(),
-                                      a1.ptr("rec"), a1.ptr("radii"), a1.ptr("rect"), a1.ptr("tiles"), a1.ptr("tmask"),
+                                      a1.ptr("rec"), radii.data_ptr(), a1.ptr("rect"), a1.ptr("tiles"), a1.ptr("tmask"),
                                       a1.ptr("sbox"), a1.ptr("depth"), a1.ptr("order"), a1.ptr("offsets"),
                                       a1.ptr("total"), a1.ptr("scratch1"), sb, st), "sls_forward_stage1")
     dbg()
@@ -255,7 +258,8 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     # pixel blocks; only what contributes is written).  SLS_NO_HANDOVER=1 (memory-tight callers): no buffer, the
     # backward culls the tiles' lists itself (about a third slower at the mapper's sizes).
     hand_over = os.environ.get("SLS_NO_HANDOVER", "0") != "1"
-    spec2 = [("allmap", "f32", (7, H, W)), ("ranges", "i32", (T, 2)), ("pix_state", "f32", (H * W, 4)),
+    allmap = s._views["allmap"] = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+    spec2 = [("ranges", "i32", (T, 2)), ("pix_state", "f32", (H * W, 4)),
              ("pix_contrib", "i32", (H * W, 2)), ("tile_consumed", "i32", (T,)),
              ("keys_a", "i32", (Ra,)), ("keys_b", "i32", (Ra,)), ("vals_a", "i32", (Ra,)), ("vals_b", "i32", (Ra,)),
              ("sort_scratch", "u8", (max(ssb, 4),))]
@@ -271,7 +275,7 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
                                       a2.ptr("sort_scratch"), ssb, C.byref(in_tmp), None,
                                       list_pairs_mode() if list_pairs is None else int(list_pairs),
                                       C.byref(lst), C.byref(stride), a2.ptr("ranges"),
-                                      ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), a2.ptr("allmap"), a2.ptr("pix_state"),
+                                      ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), allmap.data_ptr(), a2.ptr("pix_state"),
                                       a2.ptr("pix_contrib"), a2.ptr("tile_consumed"),
                                       a2.ptr("block_masks") if hand_over else None, C.byref(shape), st),
                "sls_forward_stage2")
@@ -324,7 +328,7 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
     bm = a2.ptr("block_masks") if "block_masks" in a2.spec else None
     if det:
         _abi.check(lib.sls_backward_det(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
-                                        rotations.data_ptr(), a1.ptr("radii"), a1.ptr("rec"),
+                                        rotations.data_ptr(), state.radii.data_ptr(), a1.ptr("rec"),
                                         a2.ptr("ranges"), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
                                         ce.row_cs.data_ptr(), a2.ptr("pix_state"), a2.ptr("pix_contrib"),
                                         dL.data_ptr(), out.ptr("dmeans"), out.ptr("dscales"), out.ptr("drots"),
@@ -332,7 +336,7 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
                                         out.ptr("scratch"), nbytes, _stream(dev)), "sls_backward_det")
         return out.view("dmeans"), out.view("dscales"), out.view("drots"), out.view("dopac"), None
     _abi.check(lib.sls_backward(C.byref(ce.cam), N, state.R, means3D.data_ptr(), scales.data_ptr(),
-                                rotations.data_ptr(), a1.ptr("radii"), a1.ptr("rec"),
+                                rotations.data_ptr(), state.radii.data_ptr(), a1.ptr("rec"),
                                 a2.ptr("ranges"), state.vals_ptr, state.vals_stride, ce.col_cs.data_ptr(),
                                 ce.row_cs.data_ptr(), a2.ptr("pix_state"), a2.ptr("pix_contrib"),
                                 dL.data_ptr(), out.ptr("grec"), out.ptr("dmeans"), out.ptr("dscales"),

@@ -6,13 +6,14 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log
 tail -3 gpurun_out/${TAG}_pytest.log
-cp splat_loam_amd/libsls_hip.so /tmp/keep.so
-cp gpurun_tmp_trace.so splat_loam_amd/libsls_hip.so
-for split in 1 4; do
-  for shape in "500000 64 2048" "50000 64 1024"; do
-    echo "#### SLS_BIN_SPLIT=$split $shape"
-    SLS_BIN_SPLIT=$split timeout 120 python tools/bin_trace.py $shape 2>&1 | grep -v "amdgpu.ids\|Warning"
-  done
-done > gpurun_out/${TAG}_bin_trace.txt 2>&1
-cp /tmp/keep.so splat_loam_amd/libsls_hip.so
-cat gpurun_out/${TAG}_bin_trace.txt
+timeout 300 bash tools/mem_calib.sh > gpurun_out/${TAG}_mem_calib.txt 2>&1; cat gpurun_out/${TAG}_mem_calib.txt
+timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_bench.json"))
+print(d["value"], d["config"]["ms_per_iteration"])
+for k, v in d["extras"]["dropin"].items():
+    if isinstance(v, dict):
+        for kk, vv in v.items():
+            print(k, kk, {a: b for a, b in vv.items() if a != "kernels_us"}, vv["kernels_us"].get("render_bwd"))
+PY

@@ -25,7 +25,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != c:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        k = (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("HIP_vector_type<unsigned int, 4u> ", "uint4")
+             .replace("HIP_vector_type<unsigned int, 2u> ", "uint2").replace("HIP_vector_type<unsigned int, 4u>", "uint4")
+             .replace("HIP_vector_type<unsigned int, 2u>", "uint2").replace("unsigned int", "uint32_t").strip())
         vals.setdefault(k, {}).setdefault(c, 0.0)
         vals[k][c] += float(r["Counter_Value"]) * 1024
 for k, c in cases.items():
