@@ -57,9 +57,6 @@ __device__ void order_blocks_by_cost(const ConsumerArgs &a, int xcd)
         const uint32_t bin = 255u - min(a.block_cost[tile * 16 + (i & 15)], 255u);
         a.block_order[(size_t)xcd * n_x + atomicAdd(&s_hist[bin], 1u)] = (uint32_t)i;
     }
-    // the word behind the order says "a complete order for this many tiles": the next forward on this workspace may
-    // launch its blocks in it (stale memory never passes for one)
-    if (xcd == 0 && tid == 0) a.block_order[8 * (size_t)n_x] = 0x4F524452u ^ (uint32_t)a.order_tiles;
 }
 
 __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a, int consumer_blocks_x, int consumer_blocks)

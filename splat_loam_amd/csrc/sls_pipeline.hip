@@ -39,7 +39,7 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
 int launch_render_fwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, float *, float *, uint32_t *, uint32_t *, hipStream_t, bool consumed_zeroed = false,
                       uint64_t *block_masks = nullptr, bool no_median_dist = false, uint32_t *block_cost = nullptr,
-                      const uint2 *bmask = nullptr, bool order_in_handover = false, const uint32_t *fwd_order = nullptr);
+                      const uint2 *bmask = nullptr, bool order_in_handover = false);
 int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const float *, const float *,
                       const float *, const float *, const uint32_t *, const float *, float *, hipStream_t,
                       const uint64_t *block_masks = nullptr, bool no_median_dist_grad = false,
@@ -118,7 +118,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
     w.zero_bytes = (size_t)((char *)w.grec - (char *)w.reg_accum) + n * SLS_GREC_STRIDE * 4;
     w.block_cost = (uint32_t *)take(T * (kTilePix / 16) * 4);
-    w.block_order = (uint32_t *)take(T * (kTilePix / 16) * 4 + 16);     // (+ the word that says the order is complete)
+    w.block_order = (uint32_t *)take(T * (kTilePix / 16) * 4);
     // deterministic accumulation only (192 B per surfel: as much again as everything per-surfel above)
     w.det_max = nullptr; w.det_acc = nullptr; w.det_bytes = 0;
     if (deterministic) {
@@ -356,9 +356,6 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
     const bool det = cfg->deterministic != 0;
     // cfg->phase: 0 = the whole iteration; 1 = up to the tile backward (+ the early gradient bitmap); 2 = the rest
-    static const bool fwd_order_on = !(getenv("SLS_FWD_ORDER") && getenv("SLS_FWD_ORDER")[0] == '0');
-    const bool order_bwd_possible = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
-                                    (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
     auto front = [&]() -> int {
         // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
         if (!cfg->workspace_ready) {
@@ -417,10 +414,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         rc = launch_render_fwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.allmap, w.pix_state, w.pix_contrib,
                                nullptr, st, true, w.block_masks,    // (nobody reads the consumed counters here)
                                cfg->depth_ratio == 0.0f,            // (nor, then, the median / distortion planes: not tracked)
-                               w.block_cost, bmask, false,
-                               // the forward's blocks in the order the last backward on this workspace was sorted into
-                               // (SLS_FWD_ORDER=0: block order, for A/B runs); valid from the second iteration on
-                               (fwd_order_on && cfg->workspace_ready && order_bwd_possible) ? w.block_order : nullptr);
+                               w.block_cost, bmask);
         if (rc) return rc;
         // ---- loss + dL/dallmap --------------------------------------------------------
         // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the

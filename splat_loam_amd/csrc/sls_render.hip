@@ -12,8 +12,7 @@ namespace sls {
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover,
-                            const uint32_t *fwd_order);
+                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover);
 bool handover_has_order(int T);
 const uint32_t *handover_block_order(const uint64_t *block_masks, int T);
 size_t block_mask_bytes(uint64_t cap, int T);
@@ -38,7 +37,7 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                       uint32_t *pix_contrib, uint32_t *tile_consumed, hipStream_t st, bool consumed_zeroed,
                       uint64_t *block_masks, bool no_median_dist, uint32_t *block_cost, const uint2 *bmask,
-                      bool order_in_handover, const uint32_t *fwd_order)
+                      bool order_in_handover)
 {
     const int T = cam.GX * cam.GY;
     // the block kernels combine their blocks' counters with atomicMax: start from zero
@@ -46,8 +45,7 @@ int launch_render_fwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
         SLS_HIP_CHECK(hipMemsetAsync(tile_consumed, 0, sizeof(uint32_t) * (size_t)T, st));
     return launch_render_fwd_block(cam, ranges, vals, rec, col_cs, row_cs, allmap, pix_state, pix_contrib,
                                    tile_consumed, block_masks, debug_state().fwd_variant - 2, st, no_median_dist,
-                                   debug_state().fwd_variant == 3 ? block_cost : nullptr, bmask, order_in_handover,
-                                   debug_state().fwd_variant == 3 ? fwd_order : nullptr);
+                                   debug_state().fwd_variant == 3 ? block_cost : nullptr, bmask, order_in_handover);
 }
 
 int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,

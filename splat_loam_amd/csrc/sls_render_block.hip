@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     float *__restrict__ allmap, float4 *__restrict__ pix_state, uint2 *__restrict__ pix_contrib,
     uint32_t *__restrict__ tile_consumed, uint32_t *__restrict__ dbg_cycles, uint32_t *__restrict__ block_cost,
-    const uint2 *__restrict__ bmask, const uint32_t *__restrict__ fwd_order)
+    const uint2 *__restrict__ bmask)
 {
     static_assert(BW == 8 && BH == 2 && kTileW == 16 && kTileH == 16, "the block masks name the 8x2 blocks of a 16x16 tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
@@ -472,18 +472,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
     int tile, sub;
-    if (fwd_order && fwd_order[T * kPerTile] == (0x4F524452u ^ (uint32_t)T)) {
-        // the blocks of this XCD in the order the keyframe window's last backward was sorted into (most entries first:
-        // a block's cost barely changes between neighbouring keyframes and iterations) — the launch drains behind
-        // its last-started waves, which should be the cheap ones.  A permutation whatever it holds: only speed.
-        const int xcd = blockIdx.x % 8;
-        const int i = (int)fwd_order[xcd * (T * kPerTile / 8) + blockIdx.x / 8];
-        const int ts = i / kPerTile;
-        tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
-        sub = i % kPerTile;
-    } else {
-        tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
-    }
+    tile_of_block<kPerTile>(blockIdx.x, T, tile, sub);
     const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -1058,11 +1047,9 @@ extern "C" int sls_debug_read_trace_marks(uint32_t *host)
 int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uint32_t *vals, const float *rec,
                             const float *col_cs, const float *row_cs, float *allmap, float *pix_state,
                             uint32_t *pix_contrib, uint32_t *tile_consumed, uint64_t *block_masks, int shape,
-                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover,
-                            const uint32_t *fwd_order)
+                            hipStream_t st, bool lean, uint32_t *block_cost, const uint2 *bmask, bool order_in_handover)
 {
     const int T = cam.GX * cam.GY;
-    if (!handover_has_order(T)) fwd_order = nullptr;      // (the order's encoding is the XCD-interleaved tile mapping's)
     ScopedTimer tm(T_RENDER_FWD, st);
     const dim3 grid(T * (kTilePix / 16)), block(64);
     uint32_t *const g_dbg_fwd_cycles = debug_state().dbg_fwd_cycles;
@@ -1071,7 +1058,7 @@ int launch_render_fwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                      (const float2 *)col_cs, (const float2 *)row_cs, allmap, (float4 *)pix_state,                \
                      (uint2 *)pix_contrib, tile_consumed, g_dbg_fwd_cycles, block_cost
 #define SLS_FWD_BLOCK(BW_, BH_, DBG_, LEAN_) hipLaunchKernelGGL((render_fwd_block_kernel<BW_, BH_, DBG_, LEAN_>), SLS_FWD_ARGS)
-#define SLS_FWD_DENSE(DBG_, LEAN_) hipLaunchKernelGGL((render_fwd_dense_kernel<8, 2, DBG_, LEAN_>), SLS_FWD_ARGS, bmask, fwd_order)
+#define SLS_FWD_DENSE(DBG_, LEAN_) hipLaunchKernelGGL((render_fwd_dense_kernel<8, 2, DBG_, LEAN_>), SLS_FWD_ARGS, bmask)
     // the instances' block masks in list order (a passenger of the tile sort): dense rounds, 8x2 blocks only
     if (bmask && shape == 1) {
         if (g_dbg_fwd_cycles) SLS_FWD_DENSE(true, false); else if (lean) SLS_FWD_DENSE(false, true); else SLS_FWD_DENSE(false, false);

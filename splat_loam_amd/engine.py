@@ -142,8 +142,7 @@ class MappingEngine:
         # iterations gets an extra repair round, one older than max_order_age_extra is rebuilt from scratch
         self._orders = {}
         self.max_order_age = 4
-        # up to this age an order is still repaired, with one more round (two more beyond 12 iterations)
-        self.max_order_age_extra = int(os.environ.get("SLS_ORDER_AGE_EXTRA", "12"))
+        self.max_order_age_extra = 12     # up to this age an order is still repaired, with one more round
         self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
@@ -265,8 +264,7 @@ class MappingEngine:
             self._repair_rounds -= 1
             self._repair_until = self._enq + self.repair_span
         # an order older than max_order_age iterations gets one more round (the surfels have drifted further)
-        reuse = min(self._repair_rounds + (1 if age is not None and age > self.max_order_age else 0)
-                    + (1 if age is not None and age > 12 else 0), 4) if reuse else 0
+        reuse = min(self._repair_rounds + (1 if age is not None and age > self.max_order_age else 0), 3) if reuse else 0
         self._enq += 1
         ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
