@@ -676,7 +676,7 @@ def main():
                    "parallelism": f"keyframe-dp{world}",
                    "status_read": {True: "sync", False: "async", "lagged": "lagged-1"}[status_read]
                    if engine is not None else "torch",
-                   "depth_order": ("per keyframe: repaired from the keyframe's last order while it is at most 12 "
+                   "depth_order": (f"per keyframe: repaired from the keyframe's last order while it is at most {engine.max_order_age_extra} "
                                    "iterations old (verified exact), else sorted from scratch"
                                    if (engine is not None and engine.reuse_depth_order and status_read is not False)
                                    else "sorted from scratch"),

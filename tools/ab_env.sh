@@ -12,7 +12,7 @@ for shape in ${SHAPES:-"500000,64,2048" "170000,64,1024" "50000,64,1024"}; do
       env $envs timeout 90 python bench.py --no-cpu-baseline --no-extras --n $n --height $h --width $w 2>/dev/null | python -c "
 import json, os, sys
 d = json.loads(sys.stdin.read()); sel = os.environ.get('KERNELS', '')
-print('$n ${h}x$w [$v]', d['value'], d['config']['ms_per_iteration'], {k: v['avg_us'] for k, v in d['kernels'].items() if sel in k})" || echo "$n ${h}x$w [$v] FAILED"
+print('$n ${h}x$w [$v]', d['value'], d['config']['ms_per_iteration'], {k: v['avg_us'] for k, v in d['kernels'].items() if sel in k}, d['config']['repeated_iterations'])" || echo "$n ${h}x$w [$v] FAILED"
     done
   done
 done
