@@ -502,6 +502,17 @@ def main():
         extras["ms_per_iteration_400_800"] = round(d3 / 400 * 1e3, 4)
         extras["repeated_iterations_0_800"] = dict(e3.stats)
         del m3, e3
+        # deterministic accumulation of the gradient records (integer atomics): what bit-reproducible gradients cost
+        det = {}
+        for name, mode in (("two_launches", True), ("one_launch_predicted_scales", 2)):
+            md, ed = fresh()
+            ed.deterministic = mode
+            dd, _ = run(md, ed, cams if n_kf > 1 else [cam], args.warmup * ips, n_iters, pick=pick_rank)
+            det[name + "_ms_per_iteration"] = round(dd / n_iters * 1e3, 4)
+            det[name + "_repeated"] = dict(ed.stats)
+            del md, ed
+        det["float_atomics_ms_per_iteration"] = round(ms_per_iter, 4)
+        extras["deterministic"] = det
         # the sizes the reference's mapper really meets (BASELINE config 2 and a grown map at its geometry): there an
         # iteration is a chain of launches, not of bandwidth — tracked since VERDICT r02 (targets 0.100 / 0.18 ms)
         def real_size(n2, h2, w2):

@@ -271,7 +271,13 @@ typedef struct SlsMappingConfig {
     int32_t deterministic;   /* 1: the backward tile kernel accumulates the gradient records with integer atomics
                               * (two launches: per-field maximum, then fixed-point sum scaled by it): bit-identical
                               * gradients from run to run, about one extra tile-backward per iteration.  0: float
-                              * atomics, whose order — and so the last bits of the sums — changes between runs */
+                              * atomics, whose order — and so the last bits of the sums — changes between runs.
+                              * 2: the same in ONE launch — every (surfel, field)'s scale is predicted from its sum in
+                              * the keyframe's previous iteration (`det_prev`, needed), or from the field's default where
+                              * there is no history (defaults are set by iterations run with 1 on the same workspace:
+                              * run the first one with 1).  A prediction off by more than 2^22 sets bit 3 of
+                              * status.overflow: the iteration is void, repeat it with 1.  Needs the default 8x2 tile
+                              * kernels.  Deterministic: the scales depend on earlier (deterministic) results only. */
     int32_t block_masks;     /* the forward tile kernel's dense rounds (tile sort delivers (surfel, block mask) pairs,
                               * DESIGN.md section 4): 0 = where the lists are long enough to pay (capacity >= 1500
                               * instances per tile), 1 = always, 2 = never.  Same results either way. */
@@ -281,6 +287,9 @@ typedef struct SlsMappingConfig {
                               * the bitmap receive the void flags (non-zero: bit 0 resp. any other bit of
                               * status.overflow) — OR-reduced over the ranks they are the group's verdict
                               * (sls_grad_compact / sls_adam_step_sparse) */
+    uint8_t *det_prev;       /* optional DEVICE buffer of 16 N bytes, zero-initialised by the caller, one per keyframe
+                              * (deterministic = 1 or 2): the predicted scale of every (surfel, field), rewritten by each
+                              * iteration that is not void */
     int32_t phase;           /* 0: the whole iteration.  1: up to and including the tile backward; 2: the rest (backward
                               * of the projection [+ Adam]) of the iteration phase 1 started — same arguments, same
                               * workspace.  Between the two the caller can start a collective that needs nothing of
@@ -293,7 +302,8 @@ typedef struct SlsMappingConfig {
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
     uint32_t overflow;    /* bit 0: R > R_capacity; bit 1: depth-order repair failed (reuse_depth_order); bit 2: the
-                           * sparse exchange's compact buffer was too small (sls_grad_compact).
+                           * sparse exchange's compact buffer was too small (sls_grad_compact); bit 3: a predicted scale
+                           * of the one-pass deterministic accumulation was off (deterministic = 2: repeat with 1).
                            * Non-zero: results of this iteration are void, Adam was skipped */
     float loss_sums[4];   /* sums of the three pixel terms, pixel-loss total */
     float loss_reg;       /* scale regulariser */

@@ -39,6 +39,7 @@ class SlsMappingConfig(C.Structure):
         ("grad_chunk", C.c_uint32), ("grad_ranks", C.c_uint32),
         ("deterministic", C.c_int32), ("block_masks", C.c_int32),
         ("grad_bitmap", C.c_void_p),
+        ("det_prev", C.c_void_p),
         ("phase", C.c_int32), ("reserved", C.c_int32),
     ]
 

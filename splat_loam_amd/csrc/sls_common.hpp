@@ -281,6 +281,16 @@ __host__ __device__ inline uint32_t depth_order_key(float range)
     return k < kMax ? k : kMax;
 }
 
+// Predicted scale of the one-pass deterministic accumulation: biased exponent of |sum| + 12, one byte (0: none).
+// With it the fixed point keeps 27 bits below the previous sum's magnitude and has room for terms 2^22 times larger
+// (|q| < 2^50 is checked per contribution; beyond it the iteration is void and repeated with the two-pass scheme).
+__device__ __forceinline__ uint32_t det_predict(float sum)
+{
+    const uint32_t e = (__float_as_uint(sum) >> 23) & 0xFFu;
+    return sum == 0.0f ? 0u : min(max(e + 12u, 1u), 254u);
+}
+constexpr uint32_t kDetMispredicted = 8u;        // bit 3 of SlsMappingStatus.overflow
+
 // torch.optim.Adam update of one element (no weight decay, no amsgrad); shared by adam_kernel and
 // by the update fused into preprocess_bwd so that both produce the same bits.
 struct AdamCoef {
@@ -326,6 +336,13 @@ struct AdamFuse {
     // deterministic accumulation (render_bwd DET): the gradient record is det_acc * 2^(exponent(det_max) - 166)
     const uint32_t *det_max;
     const long long *det_acc;
+    // one-pass variant (DET = 3): the scale of every (surfel, field) is PREDICTED — det_prev[surfel][field], one byte, is
+    // the biased exponent of the field's sum in the keyframe's previous iteration + 12 (0: no history: the field's
+    // default det_gex[field], set by two-pass iterations only).  det_onepass = 1: det_acc is scaled back with the
+    // prediction and cleared where read; in every deterministic mode the new prediction is written (iteration not void).
+    uint8_t *det_prev;
+    uint32_t *det_gex;
+    int det_onepass;
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
     uint64_t *grad_bitmap;                // optional (sparse exchange): bit per surfel with a non-zero gradient + 2 verdict words
     int grad_bitmap_words;                // (N + 63) / 64

@@ -46,7 +46,8 @@ int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       uint8_t *touched = nullptr, const struct ConsumerArgs *fused_consumer = nullptr,
                       uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr,
                       const uint32_t *block_order = nullptr, int vals_stride = 1, int block_masks_shape = -1,
-                      bool order_in_handover = false);
+                      bool order_in_handover = false, const uint8_t *det_prev = nullptr, const uint32_t *det_gex = nullptr,
+                      uint32_t *det_flag = nullptr);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
@@ -70,6 +71,7 @@ struct MapWs {
     uint32_t *ranges; float *allmap; float *pix_state; uint32_t *pix_contrib; uint32_t *tile_consumed;
     float *dL_dallmap; void *consumer_scratch; size_t consumer_scratch_bytes; float *grec; size_t zero_bytes; uint64_t *block_masks; float *reg_accum; uint8_t *touched;
     uint32_t *det_max; unsigned long long *det_acc; size_t det_bytes;    // deterministic accumulation (zeroed per iteration when used)
+    uint32_t *det_gex;                                                   // one-pass variant: the fields' default scales (16 words)
     uint32_t *block_cost, *block_order;                                  // backward blocks: cost from the forward, order (most expensive first)
     size_t total;
 };
@@ -113,6 +115,7 @@ static MapWs carve(int N, int H, int W, uint64_t cap, void *base, bool determini
     w.block_masks = (uint64_t *)take(block_mask_bytes(cap, (int)T));
     // zeroed together on the first use of a workspace: [reg_accum | tile_consumed | touched | grec]
     w.reg_accum = (float *)take(4);
+    w.det_gex = (uint32_t *)take(16 * 4);
     w.tile_consumed = (uint32_t *)take(T * 4);
     w.touched = (uint8_t *)take(n);
     w.grec = (float *)take(n * SLS_GREC_STRIDE * 4);
@@ -355,6 +358,11 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (allmap_out) *allmap_out = w.allmap;
     uint8_t *touched = w.touched;   // (the backward tile kernel marks the surfels it reaches)
     const bool det = cfg->deterministic != 0;
+    // one launch with predicted scales (cfg->deterministic = 2) where the default tile kernels hand compact lists over
+    const bool det_one = cfg->deterministic == 2 && cfg->det_prev != nullptr && debug_state().bwd_variant == 3 &&
+                         debug_state().fwd_variant == 3;
+    SLS_REQUIRE(cfg->deterministic >= 0 && cfg->deterministic <= 2, "deterministic: 0 off, 1 two launches, 2 one launch with predicted scales");
+    SLS_REQUIRE(cfg->deterministic != 2 || cfg->det_prev, "deterministic = 2 needs the keyframe's det_prev buffer");
     // cfg->phase: 0 = the whole iteration; 1 = up to the tile backward (+ the early gradient bitmap); 2 = the rest
     auto front = [&]() -> int {
         // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
@@ -431,12 +439,16 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                              order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order);
         if (rc) return rc;
         // ---- backward -----------------------------------------------------------------
-        if (det) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
+        // (two launches: both accumulators start from zero; one launch: det_acc is left zeroed by every deterministic
+        //  iteration's preprocess_bwd where it was written — and the first deterministic iteration on a workspace is a
+        //  two-launch one, which also sets the fields' default scales)
+        if (det && !det_one) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
         const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
         rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                                w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
-                               fuse_c ? &cargs : nullptr, det ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
-                               vals_stride, (int)debug_state().fwd_variant);
+                               fuse_c ? &cargs : nullptr, (det && !det_one) ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
+                               vals_stride, (int)debug_state().fwd_variant, false,
+                               det_one ? cfg->det_prev : nullptr, w.det_gex, &status_dev->overflow);
         if (rc) return rc;
         if (cfg->phase == 1 && cfg->grad_bitmap)      // the bitmap EARLY: an all-gather of it can overlap phase 2
             return launch_touched_bitmap(N, touched, scaling_raw, cfg->scaling_max, cfg->scaling_max_penalty,
@@ -461,7 +473,10 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     fuse.status_mirror = (uint32_t *)cfg->status_mirror;
     fuse.void_flags = cfg->void_flags_out;
     fuse.void_count = 1; fuse.void_stride = 0;
-    if (det) { fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc; }
+    if (det) {
+        fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc;
+        fuse.det_prev = cfg->det_prev; fuse.det_gex = w.det_gex; fuse.det_onepass = det_one ? 1 : 0;
+    }
     if (cfg->grad_bitmap && cfg->phase != 2) {      // (phase 2: phase 1 wrote the bitmap early — a superset, left alone)
         fuse.grad_bitmap = cfg->grad_bitmap;
         fuse.grad_bitmap_words = (N + 63) / 64;

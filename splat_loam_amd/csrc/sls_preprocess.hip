@@ -520,12 +520,47 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         SurfelGeom g;
         surfel_geom<false>(cam, m, s, q, g);
         float4 g0, g1, g2, g3;
-        if (af.det_max) {
+        if (af.det_acc) {
+            // deterministic accumulation: the record is the fixed-point sum scaled back — by the exact maximum of the
+            // two-pass scheme, or by the predicted scale of the one-pass scheme
             float gv[16];
+            uint32_t prev[4] = { 0u, 0u, 0u, 0u };
+            if (af.det_onepass) {
+                const uint4 pv = reinterpret_cast<const uint4 *>(af.det_prev)[i];
+                prev[0] = pv.x; prev[1] = pv.y; prev[2] = pv.z; prev[3] = pv.w;
+            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int ex = (int)((af.det_max[(size_t)i * 16 + k] >> 23) & 0xFFu);
-                gv[k] = (float)ldexp((double)af.det_acc[(size_t)i * 16 + k], ex - 166);
+                int ex;
+                if (af.det_onepass) {
+                    const uint32_t pb = (prev[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    ex = (int)(pb ? pb : af.det_gex[k]);
+                } else {
+                    ex = (int)((af.det_max[(size_t)i * 16 + k] >> 23) & 0xFFu);
+                }
+                const long long acc = af.det_acc[(size_t)i * 16 + k];
+                gv[k] = (float)ldexp((double)acc, ex - 166);
+                // (cleared where read: a one-launch iteration that follows finds the accumulators at zero)
+                if (af.det_onepass || af.clear_grec) const_cast<long long *>(af.det_acc)[(size_t)i * 16 + k] = 0;
+            }
+            if (af.det_prev && (!af.status_src || af.status_src[1] == 0u)) {
+                // the scale the keyframe's NEXT iteration will use (never from a void iteration's sums)
+                uint32_t pw[4];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    pw[w4] = 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) pw[w4] |= det_predict(gv[4 * w4 + b]) << (8 * b);
+                }
+                reinterpret_cast<uint4 *>(af.det_prev)[i] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+                if (!af.det_onepass && af.det_gex) {
+                    // the fields' defaults: raised by two-pass iterations only (a one-pass iteration reads them)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t pe = (pw[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                        if (pe > af.det_gex[k]) atomicMax(&af.det_gex[k], pe);
+                    }
+                }
             }
             g0 = make_float4(gv[0], gv[1], gv[2], gv[3]); g1 = make_float4(gv[4], gv[5], gv[6], gv[7]);
             g2 = make_float4(gv[8], gv[9], gv[10], gv[11]); g3 = make_float4(gv[12], gv[13], gv[14], gv[15]);
@@ -533,7 +568,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
             g0 = grec[(size_t)i * 4 + 0]; g1 = grec[(size_t)i * 4 + 1];
             g2 = grec[(size_t)i * 4 + 2]; g3 = grec[(size_t)i * 4 + 3];
         }
-        if (af.clear_grec && !af.det_max) {   // only records of visible surfels are ever touched by the tile kernel
+        if (af.clear_grec && !af.det_acc) {   // only records of visible surfels are ever touched by the tile kernel
             const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             grec[(size_t)i * 4 + 0] = z; grec[(size_t)i * 4 + 1] = z; grec[(size_t)i * 4 + 2] = z; grec[(size_t)i * 4 + 3] = z;
         }

@@ -21,7 +21,8 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
-                            const uint32_t *block_order, int vals_stride, bool dense);
+                            const uint32_t *block_order, int vals_stride, bool dense, const uint8_t *det_prev,
+                            const uint32_t *det_gex, uint32_t *det_flag);
 // Diagnostic switches are per PROCESS (sls_common.hpp: DebugState): torch runs a backward node on its autograd
 // device thread, not on the thread that called sls_debug_variant / sls_debug_wave_cycles, so per-thread state
 // would silently not reach sls_backward under loss.backward().  They are tuning / test aids only: the data path
@@ -53,13 +54,14 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       const uint32_t *pix_contrib, const float *dL_dallmap, float *grec, hipStream_t st,
                       const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched,
                       const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
-                      const uint32_t *block_order, int vals_stride, int block_masks_shape, bool order_in_handover)
+                      const uint32_t *block_order, int vals_stride, int block_masks_shape, bool order_in_handover,
+                      const uint8_t *det_prev, const uint32_t *det_gex, uint32_t *det_flag)
 {
     // vals_stride: 1 = plain list of surfel indices, 2 = the tile sort's (surfel, block mask) pairs.
     // block_masks_shape: the pixel-block shape (sls_debug_variant numbering: 2 = 4x4, 3 = 8x2) of the forward that
     // wrote the compact lists in `block_masks`; they are walked only by a backward of the same shape — any other
     // combination culls the tile's list itself (the buffer's tag word is the kernel's last guard).
-    const int variant = det_max ? 3 : (int)debug_state().bwd_variant;
+    const int variant = (det_max || det_prev) ? 3 : (int)debug_state().bwd_variant;
     const bool dense = block_masks != nullptr && block_masks_shape == variant;
     // no order from the caller: the staged forward left one in the hand-over buffer (block_order_kernel)
     if (!block_order && order_in_handover && dense && variant == 3 && handover_has_order(cam.GX * cam.GY))
@@ -67,7 +69,8 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
     return launch_render_bwd_block(cam, ranges, vals, rec, col_cs, row_cs, pix_state, pix_contrib, dL_dallmap,
                                    grec, block_masks, variant - 2, st, no_median_dist_grad,
                                    touched, fused_consumer, det_max, det_acc,
-                                   (debug_state().bwd_variant == 3 || det_max) ? block_order : nullptr, vals_stride, dense);
+                                   (debug_state().bwd_variant == 3 || det_max || det_prev) ? block_order : nullptr, vals_stride, dense,
+                                   det_prev, det_gex, det_flag);
 }
 
 }  // namespace sls

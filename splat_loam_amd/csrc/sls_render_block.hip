@@ -751,6 +751,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 //            2^(166 - biased exponent)), rounded to an integer (a pure function of the contribution) and added
 //            with a 64-bit integer atomic into det_acc: 39 fractional bits below the largest term, |q| < 2^40,
 //            23 bits of headroom for the sum.  preprocess_bwd scales back by 2^(biased exponent - 166).
+//   DET = 3: ONE launch (DENSE only) — the scale of a (surfel, field) is predicted instead of measured: the byte
+//            det_prev[surfel][field] (biased exponent of the field's sum in the keyframe's previous iteration + 12,
+//            written by preprocess_bwd) or, without history, the field's default det_gex[field].  The exponent bytes of
+//            a round's 64 surfels are fetched a round ahead (16 bytes per entry) into LDS.  A contribution whose
+//            fixed-point value reaches 2^50 — the prediction was off by more than 2^22 — sets bit 3 of the iteration's
+//            overflow word: the iteration is void and the caller repeats it with the two launches above.
 // Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
 template <int BW, int BH, bool LEAN, bool FUSED, int DET, bool DENSE>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
@@ -760,8 +766,9 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
     uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
     uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order,
-    int vstride)
+    int vstride, const uint8_t *__restrict__ det_prev, const uint32_t *__restrict__ det_gex, uint32_t *__restrict__ det_flag)
 {
+    static_assert(DET != 3 || DENSE, "the one-pass deterministic accumulation walks the forward's compact lists");
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
     SLS_TRACE_BEGIN();
     if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
@@ -771,6 +778,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     __shared__ float4 s_rec[65 * kRec4];
     __shared__ uint32_t s_list[64 + 4];          // culling path: the round's survivors; DENSE: its entries' list positions
     __shared__ uint32_t s_gidx[65];
+    __shared__ uint4 s_ex[DET == 3 ? 65 : 1];    // DET = 3: the predicted-scale bytes (16 fields) of the round's entries
     // DENSE: blk_mask is the compact-list hand-over of a forward with the same block shape (the launcher checks what
     // it can, the tag settles it: another producer's buffer is not walked)
     if (DENSE && blk_mask[0] != block_mask_tag(BW)) return;
@@ -807,6 +815,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     // the 16 gradient fields are reduced in an order that keeps pairs adjacent (below): position p of the
     // reduction -> field of the gradient record
     const int field = p < 8 ? (int)((0x73625410u >> (4 * p)) & 15u) : p;
+    const uint32_t gex_field = DET == 3 ? det_gex[field] : 0u;          // the field's default scale (no history)
     if (inside) {
         const float2 c = col_cs[px], r = row_cs[py];
         d01 = mk2(c.x * r.x, c.y * r.x); d2 = r.y;
@@ -910,10 +919,19 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
         } else if (DET == 1) {
             if (tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
+        } else if (DET == 2) {
+            if (tot != 0.0f) {
+                const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
+                const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
+                atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
+            }
         } else if (tot != 0.0f) {
-            const int ex = (int)((det_max[(size_t)gidx * kGrec + field] >> 23) & 0xFFu);   // |tot| < 2^(ex - 126)
-            const long long q = __float2ll_rn(ldexpf(tot, 166 - ex));                   // |q| < 2^40
-            atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)q);
+            const uint32_t pb = reinterpret_cast<const uint8_t *>(s_ex)[16 * j + field];
+            const int ex = (int)(pb ? pb : gex_field);
+            const float scaled = ldexpf(tot, 166 - ex);
+            // (|q| < 2^50: 13 bits of headroom for the sum; beyond — or without any scale — the iteration is void)
+            if (!(fabsf(scaled) < 1125899906842624.0f)) atomicOr(det_flag, kDetMispredicted);
+            else atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)__float2ll_rn(scaled));
         }
     };
     if (DENSE) {
@@ -936,6 +954,15 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             uint2 mine_next = clist[SLS_CENTRY(nr - 1, lane)];      // (list position, surfel) of the entry in slot `lane`
             SLS_WSTAGE_LOAD_REC()
             if (nr > 1) { SLS_CSTAGE_LOAD_IDX(nr - 2) }
+            // DET = 3: the entries' predicted-scale bytes travel one round ahead of their use, like the records: the entry
+            // of slot `lane` two rounds ahead (mine_next2) names the surfel whose 16 bytes are requested a round ahead
+            uint2 mine_next2 = make_uint2(0u, 0u);
+            uint4 ex_next = make_uint4(0u, 0u, 0u, 0u);
+            if (DET == 3) {
+                ex_next = reinterpret_cast<const uint4 *>(det_prev)[mine_next.y];
+                if (nr > 1) mine_next2 = clist[SLS_CENTRY(nr - 2, lane)];
+                if (lane == 0) s_ex[64] = make_uint4(0u, 0u, 0u, 0u);
+            }
             SLS_PHASE_DECL();
             for (int r = nr - 1; r >= 0; --r) {
                 SLS_PHASE_RESET();
@@ -945,9 +972,16 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
                 const uint2 mine = mine_next;
                 s_gidx[lane] = mine.y;
                 s_list[lane] = mine.x + 1u;              // (the contributor numbers of the round's entries)
+                if (DET == 3) s_ex[lane] = ex_next;
                 if (r > 0) {
                     SLS_WSTAGE_LOAD_REC()
-                    mine_next = clist[SLS_CENTRY(r - 1, lane)];
+                    if (DET == 3) {
+                        mine_next = mine_next2;
+                        ex_next = reinterpret_cast<const uint4 *>(det_prev)[mine_next.y];
+                        if (r > 1) mine_next2 = clist[SLS_CENTRY(r - 2, lane)];
+                    } else {
+                        mine_next = clist[SLS_CENTRY(r - 1, lane)];
+                    }
                     if (r > 1) { SLS_CSTAGE_LOAD_IDX(r - 2) }
                 }
                 const int cnt = (int)min(64u, cc - (uint32_t)(r * 64));
@@ -1083,7 +1117,8 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint32_t *pix_contrib, const float *dL_dallmap, float *grec,
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
-                            const uint32_t *block_order, int vals_stride, bool dense)
+                            const uint32_t *block_order, int vals_stride, bool dense, const uint8_t *det_prev,
+                            const uint32_t *det_gex, uint32_t *det_flag)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -1103,10 +1138,17 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_, DENSE_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride)
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag)
 #define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
     do { if (dense) SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, true); else SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, false); } while (0)
-    if (det_max) {
+    if (det_prev) {
+        // deterministic accumulation in ONE launch: predicted scales (8x2 kernel on the forward's compact lists only)
+        SLS_REQUIRE(det_acc && det_gex && det_flag && shape == 1 && dense, "the one-pass deterministic accumulation needs the 8x2 kernel on the forward's compact lists");
+        if (fused_consumer) { SLS_REQUIRE(lean, "the fused consumer gradient exists for the lean kernel only");
+                              SLS_BWD_LAUNCH(8, 2, true, true, 3, true); }
+        else if (lean) SLS_BWD_LAUNCH(8, 2, true, false, 3, true);
+        else SLS_BWD_LAUNCH(8, 2, false, false, 3, true);
+    } else if (det_max) {
         // deterministic accumulation: two launches of the 8x2 kernel (maximum, then fixed-point sum)
         SLS_REQUIRE(det_acc && shape == 1, "deterministic accumulation exists for the 8x2 kernel");
         if (fused_consumer) { SLS_REQUIRE(lean, "the fused consumer gradient exists for the lean kernel only");

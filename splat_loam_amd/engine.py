@@ -148,14 +148,19 @@ class MappingEngine:
         # mapper's keyframe sampling)
         self.max_order_age_extra = int(os.environ.get("SLS_ORDER_AGE_EXTRA", "24"))
         self.max_cached_orders = 64
-        self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0}
+        self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0, "repeated_det": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
         # keyframe-parallel exchange (set up at the first sharded step)
         self.dp_mode = os.environ.get("SLS_DP_MODE", "rs_ag")
         self._dp = None                   # dict(G, rank, C, flat, gshard) once the reduce-scatter layout is in place
         self._dp_agreed, self._dp_use_rs, self._dp_scheme = None, False, 0    # (G, rank) the scheme was agreed for; the agreed verdict
         from .rasterizer import deterministic_mode
-        self.deterministic = deterministic_mode()     # SLS_DETERMINISTIC=1: integer-atomic gradient accumulation
+        # integer-atomic gradient accumulation: False / True (SLS_DETERMINISTIC=1: two tile-backward launches) / 2
+        # (SLS_DETERMINISTIC=2: one launch with scales predicted from the keyframe's previous iteration; the first
+        # iteration on a workspace, and any iteration after a misprediction, run the two-launch scheme)
+        self.deterministic = 2 if os.environ.get("SLS_DETERMINISTIC", "0") == "2" else deterministic_mode()
+        self._det_prev = {}               # id(camera) -> [uint8 (N, 16) predicted scales, weak reference to the camera]
+        self._det_two_pass_next = True    # the next deterministic iteration runs the two-launch scheme
         self.block_masks = int(os.environ.get("SLS_BLOCK_MASKS", "0"))   # 0: auto (long lists), 1: always, 2: never (SlsMappingConfig.block_masks)
         self._sx = None                   # sparse exchange: dict(bitmap, prefix, compact, cap, send) once set up
         self.exchanged_bytes = 0          # bytes this rank handed to collectives in the last keyframe-parallel step
@@ -209,7 +214,7 @@ class MappingEngine:
         c.beta1, c.beta2, c.eps = self.betas[0], self.betas[1], self.eps
         if self._dp is not None and not apply_adam:
             c.grad_chunk, c.grad_ranks = self._dp["C"], self._dp["G"]
-        c.deterministic = 1 if self.deterministic else 0
+        c.deterministic = 1 if self.deterministic else 0      # (_enqueue raises it to 2 where the one-launch scheme applies)
         c.block_masks = int(self.block_masks)
         if self._sx is not None and not apply_adam:
             c.grad_bitmap = self._sx["mine"].data_ptr()
@@ -273,6 +278,17 @@ class MappingEngine:
         self._enq += 1
         ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
+        if self.deterministic == 2:
+            dent = self._det_prev.get(id(camera))
+            if dent is None or dent[1]() is not camera:
+                for k in [k for k, e in self._det_prev.items() if e[1]() is None]:
+                    del self._det_prev[k]
+                dent = [torch.zeros((self.N, 16), dtype=torch.uint8, device=self.dev), weakref.ref(camera)]
+                self._det_prev[id(camera)] = dent
+            cfg.det_prev = dent[0].data_ptr()
+            # (a workspace's first deterministic iteration sets the fields' default scales: two launches)
+            cfg.deterministic = 1 if (self._det_two_pass_next or not cfg.workspace_ready) else 2
+            self._det_two_pass_next = False
         cfg.depth_order = ent[0].data_ptr()
         cfg.status_mirror = mirror
         # keyframe-parallel mode: the void bits leave the step as two floats behind the gradient bucket
@@ -289,7 +305,11 @@ class MappingEngine:
 
     @staticmethod
     def _void_reason(st):
-        return "repeated_too_small" if st["too_small"] else ("repeated_resort" if st["resort_failed"] else "repeated_exchange")
+        if st["too_small"]:
+            return "repeated_too_small"
+        if st["resort_failed"]:
+            return "repeated_resort"
+        return "repeated_det" if st.get("det_mispredicted") else "repeated_exchange"
 
     def _sharded(self, group):
         """Keyframe-parallel path?  World size > 1 — or 1 with `exchange_at_world_1` (the collectives then move
@@ -306,6 +326,8 @@ class MappingEngine:
         size follows the measured size of the union of the touched sets: up at once (50 % + 4096 slots of head room
         — keyframes of a window reach sets of different size, and an iteration voided by a union that outgrew the
         collective costs more than a few hundred KB on the wire), down by 3 % per iteration."""
+        if st.get("det_mispredicted"):
+            self._det_two_pass_next = True            # the repeat (and with it the defaults' refresh) in two launches
         if self._sx is not None and (not st["overflow"] or st["exchange_too_small"]):
             want = int(st["exchange_count"] * 1.5) + 4096
             self._sx["send"] = int(min(self.N, max(want, int(self._sx["send"] * 0.97))))
@@ -318,7 +340,8 @@ class MappingEngine:
         # "overflow": the iteration is void (Adam was skipped) and must be repeated; bit 0 = the
         # instance buffers were too small, bit 1 = the repaired depth order was not exact
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
-                "exchange_too_small": bool(flags & 4), "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
+                "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
+                "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
@@ -329,7 +352,8 @@ class MappingEngine:
         f = h.view(np.float32)
         R, flags = int(h[0]) & 0xFFFFFFFF, int(h[1])
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
-                "exchange_too_small": bool(flags & 4), "exchange_count": int(h[7]) & 0xFFFFFFFF,
+                "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
+                "exchange_count": int(h[7]) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
@@ -748,6 +772,8 @@ class MappingEngine:
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)
         self.workspace = None                        # sized by N: rebuilt at the next step
         self._orders.clear()                         # surfel indices changed: every kept depth order is void
+        self._det_prev.clear()                       # ... and so is every predicted scale
+        self._det_two_pass_next = True
         self._params()
 
     def allmap(self, H, W) -> torch.Tensor:

@@ -533,7 +533,7 @@ def test_mapping_engine_matches_unfused_step(device):
     assert torch.isfinite(am).all() and float(am[1].max()) <= 1.0
 
 
-@pytest.mark.parametrize("deterministic", [False, True], ids=["float-atomics", "deterministic"])
+@pytest.mark.parametrize("deterministic", [False, True, 2], ids=["float-atomics", "deterministic", "deterministic-one-launch"])
 def test_mapping_engine_lagged_status_read(device, deterministic):
     """sync="lagged" (status of iteration k read after iteration k+1 was enqueued)
     walks the same parameter trajectory and reports the same losses as the
@@ -579,7 +579,7 @@ def test_mapping_engine_lagged_status_read(device, deterministic):
             assert torch.equal(pa, pb), f"deterministic accumulation: lagged and synchronous trajectories differ in {k}"
 
 
-@pytest.mark.parametrize("deterministic", [False, True], ids=["float-atomics", "deterministic"])
+@pytest.mark.parametrize("deterministic", [False, True, 2], ids=["float-atomics", "deterministic", "deterministic-one-launch"])
 @pytest.mark.parametrize("N", [30000, 4999], ids=["even-n", "odd-n"])   # odd N: separate optimiser kernel, unaligned scratch views
 def test_mapping_engine_depth_order_repair(device, N, deterministic):
     """reuse_depth_order: repairing the previous iteration's depth order (windowed re-sort +

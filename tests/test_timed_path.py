@@ -351,6 +351,39 @@ def test_deterministic_accumulation(device, oracle32):
         if init is not None:
             moved = np.abs(a - init).max()
             assert np.abs(a - b).max() <= 0.02 * moved      # float atomics: same trajectory up to the usual drift
+    # ONE launch with predicted scales (SlsMappingConfig.deterministic = 2): identical bits from run to run as well, no
+    # misprediction on the way, and the two-launch scheme's trajectory up to rounding (the scales differ, the sums'
+    # last bits with them); the gradients of a one-launch iteration against the two-launch scheme's: 1e-6
+    one = []
+    for _ in range(2):
+        m = SurfelModel.from_activated(scm["means"], scm["scales"], scm["rots"], scm["opac"], device=str(device))
+        e = MappingEngine(m, MappingConfig())
+        e.deterministic = 2
+        e.keep_grads = True
+        losses = [e.step(camk)["loss"] for _ in range(5)]
+        assert e.stats["repeated_det"] == 0
+        one.append(([p.detach().cpu().numpy() for p in (m._xyz, m._scaling, m._rotation, m._opacity)], losses,
+                    {k: v.detach().cpu().numpy().copy() for k, v in e.grad_views().items()}))
+    for a, b in zip(one[0][0], one[1][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "one-launch deterministic engines: identical parameters"
+    for k in one[0][2]:
+        assert np.array_equal(one[0][2][k].view(np.uint32), one[1][2][k].view(np.uint32)), f"one-launch: identical gradients ({k})"
+    for a, b, init in zip(one[0][0], finals[0][0], (scm["means"], np.log(scm["scales"]), scm["rots"], None)):
+        if init is not None:
+            assert np.abs(a - b).max() <= 0.02 * np.abs(b - init).max()
+    # same model state, one iteration each way: the fifth iteration's gradients of a two-launch engine vs a one-launch one
+    grads = {}
+    for mode in (True, 2):
+        m = SurfelModel.from_activated(scm["means"], scm["scales"], scm["rots"], scm["opac"], device=str(device))
+        e = MappingEngine(m, MappingConfig(), lrs=(0.0, 0.0, 0.0, 0.0))      # (frozen parameters: the same iteration five times)
+        e.deterministic = mode
+        e.keep_grads = True
+        for _ in range(3):
+            e.step(camk)
+        grads[mode] = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in e.grad_views().items()}
+    for k in grads[True]:
+        scale = np.abs(grads[True][k]).max()
+        assert np.abs(grads[True][k] - grads[2][k]).max() <= 1e-6 * scale, k
 
 
 def test_cov3D_precomp_renders_the_same_surfels(device):
