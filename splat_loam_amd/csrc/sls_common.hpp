@@ -290,6 +290,15 @@ __device__ __forceinline__ uint32_t det_predict(float sum)
     return sum == 0.0f ? 0u : min(max(e + 12u, 1u), 254u);
 }
 constexpr uint32_t kDetMispredicted = 8u;        // bit 3 of SlsMappingStatus.overflow
+// The scale a one-launch iteration uses for a (surfel, field): its own prediction, but never more than 24 bits below
+// the field's default (the largest prediction any surfel had in a two-launch iteration).  A sum that all but cancelled
+// last time says nothing about the size of its terms: without the floor such elements overflowed their fixed point a
+// few times per hundred iterations at 500 k surfels (8 voided iterations in 250); with it a contribution has to reach
+// half the field's largest SUM to do so.  gex = 0 (no two-launch iteration yet): no scale, every contribution flags.
+__device__ __forceinline__ int det_scale_exp(uint32_t own, uint32_t gex)
+{
+    return (int)max(own, gex > 24u ? gex - 24u : (gex ? 1u : 0u));
+}
 
 // torch.optim.Adam update of one element (no weight decay, no amsgrad); shared by adam_kernel and
 // by the update fused into preprocess_bwd so that both produce the same bits.

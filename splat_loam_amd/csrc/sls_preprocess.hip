@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
                 int ex;
                 if (af.det_onepass) {
                     const uint32_t pb = (prev[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    ex = (int)(pb ? pb : af.det_gex[k]);
+                    ex = det_scale_exp(pb, af.det_gex[k]);
                 } else {
                     ex = (int)((af.det_max[(size_t)i * 16 + k] >> 23) & 0xFFu);
                 }

@@ -927,7 +927,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             }
         } else if (tot != 0.0f) {
             const uint32_t pb = reinterpret_cast<const uint8_t *>(s_ex)[16 * j + field];
-            const int ex = (int)(pb ? pb : gex_field);
+            const int ex = det_scale_exp(pb, gex_field);
             const float scaled = ldexpf(tot, 166 - ex);
             // (|q| < 2^50: 13 bits of headroom for the sum; beyond — or without any scale — the iteration is void)
             if (!(fabsf(scaled) < 1125899906842624.0f)) atomicOr(det_flag, kDetMispredicted);

@@ -6,14 +6,16 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log
 tail -3 gpurun_out/${TAG}_pytest.log
-timeout 300 bash tools/mem_calib.sh > gpurun_out/${TAG}_mem_calib.txt 2>&1; cat gpurun_out/${TAG}_mem_calib.txt
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+tail -3 gpurun_out/${TAG}_bench.err
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${TAG}_bench.json"))
-print(d["value"], d["config"]["ms_per_iteration"])
-for k, v in d["extras"]["dropin"].items():
+print(d["value"], d["config"]["ms_per_iteration"], d["config"]["repeated_iterations"])
+e = d["extras"]
+print(e["deterministic"]); print(e["single_keyframe"], e["real_sizes"], e["repeated_iterations_0_800"], e["ms_per_iteration_400_800"])
+for k, v in e["dropin"].items():
     if isinstance(v, dict):
         for kk, vv in v.items():
-            print(k, kk, {a: b for a, b in vv.items() if a != "kernels_us"}, vv["kernels_us"].get("render_bwd"))
+            print(k, kk, {a: b for a, b in vv.items() if a != "kernels_us"})
 PY

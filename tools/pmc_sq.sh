@@ -22,7 +22,7 @@ if not f:
 agg, cnt = collections.defaultdict(float), collections.Counter()
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sls::", "")
-    if not k.startswith(("render_", "resort_", "sort_", "emit_", "preprocess_", "consumer_")):
+    if not k.startswith(("render_", "resort_", "sort_", "emit_", "preprocess_", "consumer_", "bin_", "gather_")):
         continue
     agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 for (k, c) in sorted(agg):
