@@ -11,7 +11,7 @@
 projection matrix (K = projmatrix[:3,:3]^T, scene/cameras.py:47-50).
 
 The reference's implementation is an un-vendored CUDA/Eigen submodule; the algorithm
-behind this interface is this repository's own (DESIGN.md section 9, HIP kernels in
+behind this interface is this repository's own (DESIGN.md section 8, HIP kernels in
 csrc/sls_aligner.hip): projective association on the spherical range image,
 point-to-plane + range-image residuals with Huber weights, Gauss-Newton on SE(3).
 Device only: there is no CPU path in the product.

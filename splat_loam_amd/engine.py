@@ -280,14 +280,17 @@ class MappingEngine:
         cfg = self._config(apply_adam, with_regulariser, reuse)
         if self.deterministic == 2:
             dent = self._det_prev.get(id(camera))
-            if dent is None or dent[1]() is not camera:
+            first_visit = dent is None or dent[1]() is not camera
+            if first_visit:
                 for k in [k for k, e in self._det_prev.items() if e[1]() is None]:
                     del self._det_prev[k]
                 dent = [torch.zeros((self.N, 16), dtype=torch.uint8, device=self.dev), weakref.ref(camera)]
                 self._det_prev[id(camera)] = dent
             cfg.det_prev = dent[0].data_ptr()
-            # (a workspace's first deterministic iteration sets the fields' default scales: two launches)
-            cfg.deterministic = 1 if (self._det_two_pass_next or not cfg.workspace_ready) else 2
+            # two launches where there is nothing to predict from: a workspace's first deterministic iteration (it sets
+            # the fields' default scales) and a keyframe's first visit (measured: predicting a new view from the
+            # defaults alone voids the iteration almost every time)
+            cfg.deterministic = 1 if (self._det_two_pass_next or first_visit or not cfg.workspace_ready) else 2
             self._det_two_pass_next = False
         cfg.depth_order = ent[0].data_ptr()
         cfg.status_mirror = mirror
