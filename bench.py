@@ -184,6 +184,9 @@ def main():
                          "the parameters; allreduce: one all-reduce -> Adam everywhere; sparse: only the touched set "
                          "(bitmap OR + the union's rows SUM); auto: time all three for a few un-timed iterations and "
                          "take the fastest")
+    ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("SLS_DP_OVERLAP", "0") == "1",
+                    help="N > 1, dp_mode sparse: issue the two collectives from a side stream, behind the projection's "
+                         "backward and the Adam update of the surfels outside the union (MappingEngine.overlap)")
     ap.add_argument("--iters-per-step", type=int, default=10,
                     help="mapping iterations inside ONE bench step (the driver's --steps 20 then times 200 iterations: "
                          "20 alone are 5 ms of GPU time, too few for a stable figure); ms_per_step is the time of a "
@@ -268,6 +271,7 @@ def main():
             engine.reuse_depth_order = not full_sort
             if dp_mode:
                 engine.dp_mode = dp_mode
+            engine.overlap = bool(args.dp_overlap)
         return model, engine
 
     def barrier():
@@ -693,7 +697,8 @@ def main():
                                    else "sorted from scratch"),
                    "repeated_iterations": dict(engine.stats) if engine is not None else None},
         "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,
-        "dp_mode": (comm["mode"] if comm else dp_mode), "dp_calibration_ms": dp_cal,
+        "dp_mode": (comm["mode"] if comm else dp_mode), "dp_overlap": bool(args.dp_overlap) if world > 1 else None,
+        "dp_calibration_ms": dp_cal,
         "allreduce_us": comm["exchange_us"] if comm else None, "adam_us": comm["adam_us"] if comm else None,
         "comm": comm,
         "roofline": roofline, "cpu_baseline": cpu, "extras": extras, "kernels": breakdown,

@@ -4,12 +4,12 @@ TAG=${1:-r04x}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1
-tail -25 gpurun_out/${TAG}_profile_round.log
-for m in 1 2; do
-  SLS_DETERMINISTIC=$m timeout 120 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+for extra in "--dp-mode sparse" "--dp-mode sparse --dp-overlap" "" ; do
+  echo "== bench --gpus 2 (gloo on one GPU) $extra"
+  SLS_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 5 --warmup 2 $extra 2>/tmp/err.txt | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print('SLS_DETERMINISTIC=$m', d['value'], d['config']['ms_per_iteration'], {k: v['avg_us'] for k, v in d['kernels'].items()}, d['config']['repeated_iterations'])"
+print(d['value'], d['config']['ms_per_iteration'], d['dp_mode'], d.get('dp_overlap'), d['dp_calibration_ms'], d['comm'])" || tail -5 /tmp/err.txt
 done
-timeout 300 python -m pytest tests -m gpu -q -x -k "deterministic or lagged or repair" 2>&1 | tail -2
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3
