@@ -22,10 +22,17 @@ struct DirectBin {
     uint32_t *totals;       // bins words
     uint2 *serec;           // optional: per depth position the surfel's emission record {rectangle in one word, block box}
     int bins, nchunks, pos0;    // pos0: first depth position of chunk 0 (0, or -512: the repair's shifted windows)
+    // optional (sls_mapping_step): coarse[group][tile] = the tile's instances in the chunks of group g (kDirectGroup
+    // chunks each), summed with atomics by the counting kernels and ZEROED by the iteration's first kernel.  With it
+    // bin_direct sums what lies in front of its chunk itself — the groups in front + the chunks of its own group — and
+    // the row-scan launch disappears (one dependent launch less); cnt then keeps the RAW counts.
+    uint32_t *coarse;
 };
+constexpr int kDirectGroup = 16;
 
 bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap);
-DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired);
+DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired, bool coarse = false);
+size_t direct_coarse_words(const DevCam &cam, int N);
 int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &db, bool counted, const uint32_t *order,
                       const int32_t *erec_box, const int32_t *rect, const uint32_t *sbox, void *scratch, uint32_t *vals_out,
                       uint32_t *ranges, uint32_t *total_out, uint32_t *overflow, int resort_windows,

@@ -18,7 +18,8 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear = nullptr,
                           const float *col_cs = nullptr, const float *row_cs = nullptr, uint64_t *tile_mask = nullptr,
                           int32_t *erec = nullptr, const uint32_t *resort_prev_order = nullptr,
-                          uint64_t *resort_comp = nullptr, uint32_t *sbox = nullptr, int erec_box = 0);
+                          uint64_t *resort_comp = nullptr, uint32_t *sbox = nullptr, int erec_box = 0,
+                          uint32_t *zero_words = nullptr, int n_zero_words = 0);
 uint64_t *resort_comp_buffer(int N, void *scratch);
 void depth_order_key_buffers(int N, void *scratch, uint32_t *order, uint32_t **keys, uint32_t **vals0,
                              uint32_t **n_dev);
@@ -386,15 +387,19 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         // Direct binning (sls_sort.hip) where it applies: no unsorted instance array, no scan of tiles_touched; the preprocess
         // then leaves the emission records in the form its first kernel gathers (rectangle + block box)
         const bool direct = bin_direct_possible(dc, N, cap);
+        // (SLS_NO_COARSE_BIN=1: the count table's rows are scanned by their own launch, as in the staged API; A/B)
+        static const bool no_coarse = getenv("SLS_NO_COARSE_BIN") && getenv("SLS_NO_COARSE_BIN")[0] == '1';
+        DirectBin db;
+        if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1, !no_coarse);
         int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                        scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
                                        okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
                                        merged_sort ? order : nullptr,
-                                       merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0);
+                                       merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0,
+                                       (direct && db.coarse) ? db.coarse : nullptr,
+                                       (direct && db.coarse) ? (int)direct_coarse_words(dc, N) : 0);
         if (rc) return rc;
         ScanHandoff handoff = { nullptr, 0, nullptr, 0 };   // the binning finishes (or does not need) the scan of tiles_touched
-        DirectBin db;
-        if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1);
         rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
                                      w.order_scratch_bytes, 1, st, cfg->reuse_depth_order, &status_dev->overflow, &handoff,
                                      merged_sort, direct ? &db : nullptr, (const int4 *)w.erec, dc.GX);

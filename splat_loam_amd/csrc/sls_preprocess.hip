@@ -152,6 +152,8 @@ struct RegArgs {
     float *reg_out;     // device scalar accumulating pen * sum relu(max_axis_scale - smax)
     uint32_t *status_clear;   // optional: 8 status words of the iteration, zeroed by thread 0 of the FIRST kernel
                               // (nothing else touches them before this kernel has finished)
+    uint32_t *zero_words;     // optional: a small table the iteration's first kernel zeroes (the direct binning's coarse
+    int n_zero_words;         // counts, summed with atomics two kernels later): surfel thread i clears words i, i + N, ...
 };
 
 // EXACT (forward): the scales enter the extents of the tile rectangle — library expf for those.
@@ -210,6 +212,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
     int4 my_rc = make_int4(0, 0, 0, 0);
     float my_reg = 0.0f;
     if (i == 0 && n_dev) *n_dev = (uint32_t)N;
+    if (ra.zero_words && i < N) {
+        for (int k = i; k < ra.n_zero_words; k += N) ra.zero_words[k] = 0u;
+    }
     if (i == 0 && ra.status_clear) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) ra.status_clear[k] = 0u;
@@ -711,10 +716,12 @@ int launch_preprocess_fwd(const DevCam &cam, int raw, float smax, float pen, flo
                           int32_t *radii, int32_t *rect, uint32_t *tiles, float *depth, uint32_t *order_keys,
                           uint32_t *order_vals, uint32_t *n_dev, hipStream_t st, uint32_t *status_clear,
                           const float *col_cs, const float *row_cs, uint64_t *tile_mask, int32_t *erec,
-                          const uint32_t *resort_prev_order, uint64_t *resort_comp, uint32_t *sbox, int erec_box)
+                          const uint32_t *resort_prev_order, uint64_t *resort_comp, uint32_t *sbox, int erec_box,
+                          uint32_t *zero_words, int n_zero_words)
 {
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = reg_out; ra.status_clear = status_clear;
+    ra.zero_words = zero_words; ra.n_zero_words = n_zero_words;
     PreFwdArgs pa;
     pa.means = means; pa.scales = (const float2 *)scales; pa.rots = (const float4 *)rots; pa.opac = opac;
     pa.rec = (float4 *)rec; pa.radii = radii; pa.rect = (int4 *)rect; pa.tiles = tiles; pa.depth = depth;
@@ -747,6 +754,7 @@ int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int
     const int nb = (N + 255) / 256;
     RegArgs ra;
     ra.raw = raw; ra.smax = smax; ra.pen = pen; ra.reg_out = nullptr; ra.status_clear = nullptr;
+    ra.zero_words = nullptr; ra.n_zero_words = 0;
     AdamFuse af;
     memset(&af, 0, sizeof(af));
     if (fuse) af = *fuse;

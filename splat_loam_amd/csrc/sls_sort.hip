@@ -738,7 +738,11 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     __syncthreads();
     SLS_MT(2);
     if (DIRECT) {
-        for (int d = threadIdx.x; d < db.bins; d += kResortThreads) db.cnt[(size_t)d * db.nchunks + blockIdx.x] = s_hist[d];
+        for (int d = threadIdx.x; d < db.bins; d += kResortThreads) {
+            const uint32_t c = s_hist[d];
+            db.cnt[(size_t)d * db.nchunks + blockIdx.x] = c;
+            if (db.coarse && c) atomicAdd(&db.coarse[(size_t)(blockIdx.x / kDirectGroup) * db.bins + d], c);
+        }
         SLS_MT(3);
     } else if (threadIdx.x < 4) {
         const int blk = (base + (int)threadIdx.x * 256) / 256;      // aligned 256-block of positions
@@ -763,7 +767,11 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
         count_rect_tiles(er.x, GX, s_hist);
     }
     __syncthreads();
-    if ((int)threadIdx.x < db.bins) db.cnt[(size_t)threadIdx.x * db.nchunks + blockIdx.x] = s_hist[threadIdx.x];
+    if ((int)threadIdx.x < db.bins) {
+        const uint32_t c = s_hist[threadIdx.x];
+        db.cnt[(size_t)threadIdx.x * db.nchunks + blockIdx.x] = c;
+        if (db.coarse && c) atomicAdd(&db.coarse[(size_t)(blockIdx.x / kDirectGroup) * db.bins + threadIdx.x], c);
+    }
 }
 
 // step C, run by block 0 of the scan's first kernel
@@ -844,8 +852,26 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
         const int d = tid * PER + q;
         tot[q] = 0u; ccol[q] = 0u;
         if (d < BINS) {
-            tot[q] = db.totals[d];
-            ccol[q] = db.cnt[(size_t)d * db.nchunks + chunk];
+            if (db.coarse) {
+                // no row scan ran: the tile's total = the sum of its groups, what lies in front of this chunk = the groups
+                // in front + the chunks of its own group in front (raw counts; all loads independent)
+                const int ngroups = (db.nchunks + kDirectGroup - 1) / kDirectGroup, g0 = chunk / kDirectGroup;
+                uint32_t all = 0u, front_g = 0u;
+                for (int g = 0; g < ngroups; ++g) {
+                    const uint32_t v = db.coarse[(size_t)g * BINS + d];
+                    all += v;
+                    front_g += g < g0 ? v : 0u;
+                }
+                const uint32_t *row = db.cnt + (size_t)d * db.nchunks + g0 * kDirectGroup;
+                uint32_t front_c = 0u;
+#pragma unroll
+                for (int c = 0; c < kDirectGroup - 1; ++c) front_c += (g0 * kDirectGroup + c < chunk) ? row[c] : 0u;
+                tot[q] = all;
+                ccol[q] = front_g + front_c;
+            } else {
+                tot[q] = db.totals[d];
+                ccol[q] = db.cnt[(size_t)d * db.nchunks + chunk];
+            }
         }
     }
     for (int i = tid; i < WAVES * BINS; i += TPB) s_cur[i] = 0u;
@@ -1428,10 +1454,16 @@ bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap)
     if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX > 512 || cam.GY > 64) return false;    // (pack_rect32's fields)
     if (cam.GX * cam.GY > kDirectMaxBins) return false;
     const size_t bins = (size_t)direct_bins(cam), nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
-    return (bins * nchunks + bins) * sizeof(uint32_t) <= sort_core_bytes(cap);
+    return (bins * nchunks + bins + direct_coarse_words(cam, N)) * sizeof(uint32_t) <= sort_core_bytes(cap);
+}
+// words of the coarse table (groups of kDirectGroup chunks x tiles), for either chunking
+size_t direct_coarse_words(const DevCam &cam, int N)
+{
+    const size_t nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
+    return ((nchunks + kDirectGroup - 1) / kDirectGroup) * (size_t)direct_bins(cam);
 }
 // the table's place in the sort's scratch; repaired: the chunks are the repair's shifted windows
-DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired)
+DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *serec, bool repaired, bool coarse)
 {
     DirectBin db;
     db.bins = direct_bins(cam);
@@ -1440,6 +1472,10 @@ DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *s
     db.cnt = (uint32_t *)sort_scratch;
     db.totals = db.cnt + (size_t)db.bins * db.nchunks;
     db.serec = serec;
+    // (the coarse table sits at a place that does not depend on the chunking: the iteration's first kernel zeroes it
+    //  before the depth-order stage decides between repair and radix sort)
+    const size_t max_chunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
+    db.coarse = coarse ? (uint32_t *)sort_scratch + (size_t)db.bins * max_chunks + db.bins : nullptr;
     return db;
 }
 
@@ -1458,7 +1494,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
                            (const uint2 *)erec_box, (const int4 *)rect, sbox, db);
         SLS_LAUNCH_CHECK("gather_count_kernel");
     }
-    {
+    if (!db.coarse) {       // (with the coarse table bin_direct sums what lies in front of a chunk itself)
         ScopedTimer tm(T_SORT_ROWSCAN, st);
         hipLaunchKernelGGL(sort_rowscan_kernel, dim3(db.bins), dim3(256), 0, st, db.cnt, (const uint32_t *)nullptr, cap,
                            db.nchunks, db.totals, db.nchunks);
