@@ -298,6 +298,12 @@ typedef struct SlsMappingConfig {
                               * gradients (zero rows change no sum) — so that the ranks' bitmaps can be all-gathered
                               * while phase 2 runs (MappingEngine.overlap) */
     int32_t reserved;
+    uint32_t *block_order;   /* optional DEVICE buffer of sls_block_order_bytes(H, W) bytes, zero-initialised by the caller, one
+                              * per keyframe: the launch order of the keyframe's tile backward (most expensive pixel blocks
+                              * first), written by every iteration for the keyframe's next one.  With it the loss stage
+                              * has no launch of its own: the tile backward computes the per-pixel loss terms and their
+                              * gradient itself (default 8x2 kernel, depth_ratio = 0; otherwise the buffer is ignored).
+                              * Same gradients bit for bit; loss_sums are added up in another order (last bits) */
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
@@ -310,6 +316,7 @@ typedef struct SlsMappingStatus {
     uint32_t exchange_count;  /* sparse exchange only: number of surfels in the union of the ranks' touched sets */
 } SlsMappingStatus;
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity);
+size_t sls_block_order_bytes(int H, int W);   /* SlsMappingConfig.block_order */
 /* The same for ONE configuration: without cfg->deterministic the two fixed-point accumulators (192 B per
  * surfel, about as much as the rest of the per-surfel workspace) are not reserved.  A workspace sized by
  * sls_mapping_workspace_bytes fits every configuration. */
@@ -327,7 +334,7 @@ int sls_mapping_step(const SlsCamera *cam, int N,
 /* ---- frame-to-keyframe registration on spherical range images -------
  * The job of the reference's `gsaligner` extension (slam/tracker.py:141-197: set_query /
  * set_reference / align(iguess) -> (T, fitness, _)).  That submodule is not vendored, so the
- * algorithm is this repository's own (DESIGN.md §9): projective nearest-pixel association
+ * algorithm is this repository's own (DESIGN.md §8): projective nearest-pixel association
  * under the spherical model of `projmatrix`, point-to-plane + range-image residuals with Huber
  * weights, Gauss-Newton on SE(3) (left perturbation), the 6x6 system solved on the device.
  *   depth: H*W floats (0 / <= depth_min = invalid), points: H*W*3 floats in the frame's own

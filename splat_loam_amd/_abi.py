@@ -41,6 +41,7 @@ class SlsMappingConfig(C.Structure):
         ("grad_bitmap", C.c_void_p),
         ("det_prev", C.c_void_p),
         ("phase", C.c_int32), ("reserved", C.c_int32),
+        ("block_order", C.c_void_p),
     ]
 
 
@@ -90,6 +91,7 @@ _PROTOS = {
                            [_VP] * 8 + [C.POINTER(C.c_int), _VP]),
     "sls_block_mask_bytes": (C.c_size_t, [C.c_uint64, C.c_int, C.c_int]),
     "sls_mapping_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "sls_block_order_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sls_mapping_workspace_bytes_cfg": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(SlsMappingConfig)]),
     "sls_mapping_step": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 7 + [C.c_int64, _VP, _VP, C.c_int] +
                          [_VP] * 4 + [C.POINTER(SlsMappingConfig), C.c_uint64, _VP, C.c_size_t, _VP,

@@ -84,7 +84,8 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr,
-                    int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr);
+                    int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr,
+                    bool no_launch = false);
 size_t knn_scratch_bytes(int M);
 int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
 

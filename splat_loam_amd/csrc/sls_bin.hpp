@@ -22,6 +22,8 @@ struct DirectBin {
     uint32_t *totals;       // bins words
     uint2 *serec;           // optional: per depth position the surfel's emission record {rectangle in one word, block box}
     int bins, nchunks, pos0;    // pos0: first depth position of chunk 0 (0, or -512: the repair's shifted windows)
+    int stride;             // words per row of cnt (>= nchunks; a multiple of kDirectGroup with the coarse table: a group's
+                            // counts of one tile are then one aligned 64-byte line)
     // optional (sls_mapping_step): coarse[group][tile] = the tile's instances in the chunks of group g (kDirectGroup
     // chunks each), summed with atomics by the counting kernels and ZEROED by the iteration's first kernel.  With it
     // bin_direct sums what lies in front of its chunk itself — the groups in front + the chunks of its own group — and

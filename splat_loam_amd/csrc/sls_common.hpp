@@ -355,6 +355,18 @@ struct AdamFuse {
     float *reg_accum;                     // optional: workspace scalar holding this iteration's regulariser sum
     uint64_t *grad_bitmap;                // optional (sparse exchange): bit per surfel with a non-zero gradient + 2 verdict words
     int grad_bitmap_words;                // (N + 63) / 64
+    // kernel B inside the backward tile kernel (sls_render_block.hip, FUSED = 2): its blocks' loss terms, three floats per
+    // block, are summed here — one wave of block 0, a fixed order — into words 2..5 of the status block before thread 0
+    // publishes it (loss_w: 1 / pixels, lambda_n / valid pixels, lambda_a / valid pixels)
+    const float *loss_partials;
+    int n_loss_partials;
+    float loss_w[3];
+    // and the launch order of the keyframe's NEXT tile backward (sls_consumer_dev.hpp: order_blocks_by_cost), by eight
+    // passenger workgroups behind the surfels': order_out[0] = the tag, the T * 16 block indices behind it
+    int order_T;
+    const uint32_t *order_cost;
+    uint32_t *order_out;
+    int publisher;          // set by launch_preprocess_bwd: a workgroup of its own does the status duties above
 };
 
 // Copy of an iteration's finished status block (8 words) into its pinned host mirror, by ONE lane.  The host polls

@@ -22,47 +22,10 @@
 
 namespace sls {
 
-// Blocks of one XCD (index i = tile slot * 16 + block, tile = ((slot >> 2) * 8 + xcd) * 4 + (slot & 3), the mapping
-// of tile_of_block) in the order of their backward cost, most expensive first: the launch drains when the queue is
-// empty, and it drains for as long as the last-started waves run — they should be the cheap ones.  The order is a
-// permutation whatever the costs are; only speed depends on it.
-__device__ void order_blocks_by_cost(const ConsumerArgs &a, int xcd)
-{
-    __shared__ uint32_t s_hist[256];
-    const int n_x = a.order_tiles * 2, tid = threadIdx.x;        // T * 16 / 8 blocks per XCD
-    s_hist[tid] = 0u;
-    __syncthreads();
-    for (int i = tid; i < n_x; i += 256) {
-        const int ts = i >> 4;
-        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
-        atomicAdd(&s_hist[255u - min(a.block_cost[tile * 16 + (i & 15)], 255u)], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the 256 bins (wave 0)
-    if (tid < 64) {
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = s_hist[tid * 4 + k]; sum += v[k]; }
-        uint32_t inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (tid >= off) inc += t; }
-        uint32_t base = inc - sum;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_hist[tid * 4 + k] = base; base += v[k]; }
-    }
-    __syncthreads();
-    for (int i = tid; i < n_x; i += 256) {
-        const int ts = i >> 4;
-        const int tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
-        const uint32_t bin = 255u - min(a.block_cost[tile * 16 + (i & 15)], 255u);
-        a.block_order[(size_t)xcd * n_x + atomicAdd(&s_hist[bin], 1u)] = (uint32_t)i;
-    }
-}
-
 __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a, int consumer_blocks_x, int consumer_blocks)
 {
     if ((int)blockIdx.x >= consumer_blocks) {          // the passenger workgroups
-        order_blocks_by_cost(a, (int)blockIdx.x - consumer_blocks);
+        order_blocks_by_cost(a.order_tiles, a.block_cost, a.block_order, (int)blockIdx.x - consumer_blocks);
         return;
     }
     const int bx = (int)blockIdx.x % consumer_blocks_x, by = (int)blockIdx.x / consumer_blocks_x;
@@ -70,51 +33,10 @@ __global__ __launch_bounds__(256) void consumer_b_kernel(ConsumerArgs a, int con
     const int r = by * 4 + (threadIdx.x >> 6);
     float lg = 0.0f, ln = 0.0f, la = 0.0f;
     if (c < a.W && r < a.H) {
-        const size_t P = (size_t)a.H * a.W, pix = (size_t)r * a.W + c;
-        const bool valid = a.valid[pix] == 1;
-        const float al = a.allmap[SLS_CH_ALPHA * P + pix];
-        const bool hit = al > 0.0f;
-        const float inv = hit ? 1.0f / al : 1.0f;
-        const float n0 = a.allmap[(SLS_CH_NORMAL + 0) * P + pix] * inv;
-        const float n1 = a.allmap[(SLS_CH_NORMAL + 1) * P + pix] * inv;
-        const float n2 = a.allmap[(SLS_CH_NORMAL + 2) * P + pix] * inv;
-        float s;
-        (void)surf_point(a, r, c, s);
-        float4 du = make_float4(0, 0, 0, 0), dv = du, nsd = du;
-        const bool interior = (r > 0) && (r < a.H - 1) && (c > 0) && (c < a.W - 1);
-        if (interior) {
-            float t;
-            const float3 pu = surf_point(a, r + 1, c, t), pd = surf_point(a, r - 1, c, t);
-            const float3 pr = surf_point(a, r, c + 1, t), pl = surf_point(a, r, c - 1, t);
-            const float u0 = pu.x - pd.x, u1 = pu.y - pd.y, u2 = pu.z - pd.z;
-            const float v0 = pr.x - pl.x, v1 = pr.y - pl.y, v2 = pr.z - pl.z;
-            const float c0 = u1 * v2 - u2 * v1, c1 = u2 * v0 - u0 * v2, c2 = u0 * v1 - u1 * v0;
-            const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
-            const float rden = 1.0f / fmaxf(len, 1e-12f);            // F.normalize eps
-            const float s0 = c0 * rden, s1 = c1 * rden, s2 = c2 * rden;
-            const float dot = n0 * s0 + n1 * s1 + n2 * s2;
-            nsd = make_float4(s0, s1, s2, dot);
-            if (valid) {
-                // dL/dn_surf = -lambda_n/Nv * alpha * n_hat ; through normalize ; through the cross product
-                const float k = -a.lambda_n * a.inv_nv * al;
-                float g0 = k * n0, g1 = k * n1, g2 = k * n2;
-                if (len > 1e-12f) {
-                    const float gd = g0 * s0 + g1 * s1 + g2 * s2;
-                    g0 = (g0 - gd * s0) * rden; g1 = (g1 - gd * s1) * rden; g2 = (g2 - gd * s2) * rden;
-                } else {
-                    g0 *= rden; g1 *= rden; g2 *= rden;
-                }
-                // cr = u x v : dL/du = v x g, dL/dv = g x u
-                du = make_float4(v1 * g2 - v2 * g1, v2 * g0 - v0 * g2, v0 * g1 - v1 * g0, 0.0f);
-                dv = make_float4(g1 * u2 - g2 * u1, g2 * u0 - g0 * u2, g0 * u1 - g1 * u0, 0.0f);
-            }
-        }
+        const size_t pix = (size_t)r * a.W + c;
+        float4 du, dv, nsd;
+        consumer_b_pixel(a, r, c, du, dv, nsd, lg, ln, la);
         a.du[pix] = du; a.dv[pix] = dv; a.ns[pix] = nsd;
-        if (valid) {
-            lg = fabsf(s - a.gt_depth[pix]);
-            ln = 1.0f - al * nsd.w;
-            la = -fmaxf(logf(al), -100.0f);                            // torch BCE clamps log at -100
-        }
     }
     // block reduction -> one atomic per block and term
     __shared__ float s_part[3][4];
@@ -179,7 +101,7 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed, ConsumerArgs *args_out_skip_c, int order_tiles,
-                    const uint32_t *block_cost, uint32_t *block_order)
+                    const uint32_t *block_cost, uint32_t *block_order, bool no_launch)
 {
     if (scratch_bytes < consumer_scratch_bytes(H, W)) {
         set_error("consumer scratch too small");
@@ -201,6 +123,15 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
     a.order_tiles = (order_tiles > 0 && order_tiles % 32 == 0 && block_cost && block_order && kTilePix / 16 == 16) ? order_tiles : 0;
     a.block_cost = block_cost;
     a.block_order = block_order;
+    if (no_launch) {
+        // kernel B runs inside the backward tile kernel (FUSED = 2 there): no plane is written, the blocks' loss terms —
+        // three floats per 16-pixel block — take the planes' place at the head of the scratch
+        if (!args_out_skip_c) { set_error("internal: the inline consumer needs the fused backward"); return SLS_E_ARG; }
+        a.partials = (float *)scratch;
+        a.order_tiles = 0;
+        *args_out_skip_c = a;
+        return SLS_OK;
+    }
     ScopedTimer tm(T_CONSUMER, st);
     (void)sums_zeroed;   // (the sums are written, not accumulated)
     const dim3 grid((W + 63) / 64, (H + 3) / 4);

@@ -48,14 +48,15 @@ int launch_render_bwd(const DevCam &, const uint32_t *, const uint32_t *, const 
                       uint32_t *det_max = nullptr, unsigned long long *det_acc = nullptr,
                       const uint32_t *block_order = nullptr, int vals_stride = 1, int block_masks_shape = -1,
                       bool order_in_handover = false, const uint8_t *det_prev = nullptr, const uint32_t *det_gex = nullptr,
-                      uint32_t *det_flag = nullptr);
+                      uint32_t *det_flag = nullptr, bool consumer_b_inline = false, uint32_t order_tag = 0u);
 size_t block_mask_bytes(uint64_t cap, int T);
 size_t consumer_scratch_bytes(int H, int W);
 int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, const uint8_t *valid,
                     const float *col_h, const float *row_h, float depth_ratio, float lambda_n, float lambda_a,
                     int n_valid, float *sums, float *dL_dallmap, void *scratch, size_t scratch_bytes,
                     hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr,
-                    int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr);
+                    int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr,
+                    bool no_launch = false);
 int launch_touched_bitmap(int N, const uint8_t *touched, const float *scaling_raw, float smax, float pen,
                           const uint32_t *status_block, uint64_t *bitmap, hipStream_t st);
 int launch_adam(const SlsAdamGroup *groups, int ngroups, double beta1, double beta2, double eps, int64_t step,
@@ -317,6 +318,13 @@ size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity)
     return carve(N, H, W, R_capacity, nullptr, true).total;      // fits either setting of cfg->deterministic
 }
 
+size_t sls_block_order_bytes(int H, int W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    const size_t T = (size_t)((W + kTileW - 1) / kTileW) * (size_t)((H + kTileH - 1) / kTileH);
+    return sizeof(uint32_t) * (1 + T * (size_t)(kTilePix / 16));
+}
+
 size_t sls_mapping_workspace_bytes_cfg(int N, int H, int W, uint64_t R_capacity, const SlsMappingConfig *cfg)
 {
     if (N < 0 || H <= 0 || W <= 0) return 0;
@@ -364,6 +372,17 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                          debug_state().fwd_variant == 3;
     SLS_REQUIRE(cfg->deterministic >= 0 && cfg->deterministic <= 2, "deterministic: 0 off, 1 two launches, 2 one launch with predicted scales");
     SLS_REQUIRE(cfg->deterministic != 2 || cfg->det_prev, "deterministic = 2 needs the keyframe's det_prev buffer");
+    // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
+    // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself ...
+    const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
+    // ... and with the keyframe's launch-order buffer kernel B's work too (SLS_NO_FUSED_B=1: never, for A/B runs)
+    static const bool no_fused_b = getenv("SLS_NO_FUSED_B") && getenv("SLS_NO_FUSED_B")[0] == '1';
+    const bool fuse_b = fuse_c && cfg->block_order != nullptr && !no_fused_b;
+    // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
+    // passenger workgroups — of the consumer's launch, or with fuse_b of the previous iteration's last launch): 8x2
+    // kernels, XCD-interleaved tile mapping (T % 32 == 0)
+    const bool order_bwd = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
+                           (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
     // cfg->phase: 0 = the whole iteration; 1 = up to the tile backward (+ the early gradient bitmap); 2 = the rest
     auto front = [&]() -> int {
         // (the status block is zeroed by thread 0 of preprocess_fwd, the iteration's first kernel)
@@ -391,11 +410,18 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         static const bool no_coarse = getenv("SLS_NO_COARSE_BIN") && getenv("SLS_NO_COARSE_BIN")[0] == '1';
         DirectBin db;
         if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1, !no_coarse);
+        // (the direct binning reads the emission records only — not the rectangles, the tile counts, the depths or the
+        //  block boxes as arrays of their own; a one-round repair whose window sort rides in the preprocess launch
+        //  computes its keys itself: 32 bytes per surfel that are not written.  SLS_FULL_PREPROCESS=1: all of them, A/B)
+        static const bool full_pre = getenv("SLS_FULL_PREPROCESS") && getenv("SLS_FULL_PREPROCESS")[0] == '1';
+        const bool trim = direct && !full_pre;
         int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
-                                       scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, w.rect, w.tiles, w.depth,
-                                       okeys, ovals, n_dev, st, (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
+                                       scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, trim ? nullptr : w.rect,
+                                       trim ? nullptr : w.tiles, trim ? nullptr : w.depth,
+                                       (trim && merged_sort && cfg->reuse_depth_order == 1) ? nullptr : okeys, ovals, n_dev, st,
+                                       (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
                                        merged_sort ? order : nullptr,
-                                       merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, w.sbox, direct ? 1 : 0,
+                                       merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, trim ? nullptr : w.sbox, direct ? 1 : 0,
                                        (direct && db.coarse) ? db.coarse : nullptr,
                                        (direct && db.coarse) ? (int)direct_coarse_words(dc, N) : 0);
         if (rc) return rc;
@@ -430,30 +456,26 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                                w.block_cost, bmask);
         if (rc) return rc;
         // ---- loss + dL/dallmap --------------------------------------------------------
-        // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
-        // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself.
-        const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
-        // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
-        // passenger workgroups of the consumer's launch): 8x2 kernels, XCD-interleaved tile mapping (T % 32 == 0)
-        const bool order_bwd = debug_state().bwd_variant == 3 && debug_state().fwd_variant == 3 &&
-                               (dc.GX * dc.GY) % 32 == 0 && kTileW == 16 && kTileH == 16;
+        // With the keyframe's own launch-order buffer kernel B is folded in as well (fuse_b, above): the loss stage has no
+        // launch; the order the backward walks is the one the keyframe's previous iteration left.
         ConsumerArgs cargs;
         rc = launch_consumer(H, W, w.allmap, gt_depth, valid, col_cs_half, row_cs_half, cfg->depth_ratio,
                              cfg->lambda_normal, cfg->lambda_alpha, n_valid, status_dev->loss_sums, w.dL_dallmap,
                              w.consumer_scratch, w.consumer_scratch_bytes, st, true, fuse_c ? &cargs : nullptr,
-                             order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order);
+                             order_bwd ? dc.GX * dc.GY : 0, w.block_cost, w.block_order, fuse_b);
         if (rc) return rc;
         // ---- backward -----------------------------------------------------------------
         // (two launches: both accumulators start from zero; one launch: det_acc is left zeroed by every deterministic
         //  iteration's preprocess_bwd where it was written — and the first deterministic iteration on a workspace is a
         //  two-launch one, which also sets the fields' default scales)
         if (det && !det_one) SLS_HIP_CHECK(hipMemsetAsync(w.det_max, 0, w.det_bytes, st));
-        const uint32_t *block_order = order_bwd ? w.block_order : nullptr;
+        const uint32_t *block_order = order_bwd ? (fuse_b ? cfg->block_order : w.block_order) : nullptr;
         rc = launch_render_bwd(dc, w.ranges, sorted_vals, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, w.dL_dallmap,
                                w.grec, st, w.block_masks, cfg->depth_ratio == 0.0f, touched,    // the consumer's dL/d(median, distortion) are 0 then
                                fuse_c ? &cargs : nullptr, (det && !det_one) ? w.det_max : nullptr, det ? w.det_acc : nullptr, block_order,
                                vals_stride, (int)debug_state().fwd_variant, false,
-                               det_one ? cfg->det_prev : nullptr, w.det_gex, &status_dev->overflow);
+                               det_one ? cfg->det_prev : nullptr, w.det_gex, &status_dev->overflow, fuse_b,
+                               (fuse_b && order_bwd) ? block_order_tag(dc.GX * dc.GY) : 0u);
         if (rc) return rc;
         if (cfg->phase == 1 && cfg->grad_bitmap)      // the bitmap EARLY: an all-gather of it can overlap phase 2
             return launch_touched_bitmap(N, touched, scaling_raw, cfg->scaling_max, cfg->scaling_max_penalty,
@@ -481,6 +503,16 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     if (det) {
         fuse.det_max = w.det_max; fuse.det_acc = (const long long *)w.det_acc;
         fuse.det_prev = cfg->det_prev; fuse.det_gex = w.det_gex; fuse.det_onepass = det_one ? 1 : 0;
+    }
+    if (fuse_b) {
+        // the tile backward's blocks left the loss terms (sls_consumer.hip: launch_consumer, no_launch) and the forward
+        // its blocks' costs: this launch sums the first and sorts the second for the keyframe's next iteration
+        fuse.loss_partials = (const float *)w.consumer_scratch;
+        fuse.n_loss_partials = dc.GX * dc.GY * (kTilePix / 16);
+        fuse.loss_w[0] = 1.0f / ((float)H * (float)W);
+        fuse.loss_w[1] = n_valid > 0 ? cfg->lambda_normal * (1.0f / (float)n_valid) : 0.0f;
+        fuse.loss_w[2] = n_valid > 0 ? cfg->lambda_alpha * (1.0f / (float)n_valid) : 0.0f;
+        if (order_bwd) { fuse.order_T = dc.GX * dc.GY; fuse.order_cost = w.block_cost; fuse.order_out = cfg->block_order; }
     }
     if (cfg->grad_bitmap && cfg->phase != 2) {      // (phase 2: phase 1 wrote the bitmap early — a superset, left alone)
         fuse.grad_bitmap = cfg->grad_bitmap;

@@ -9,6 +9,7 @@
 // is reproducible bit for bit by a CPU checker.
 #include <cstring>
 #include "sls_common.hpp"
+#include "sls_consumer_dev.hpp"
 #include "sls_resort.hpp"
 
 namespace sls {
@@ -324,8 +325,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
             }
         }
         radii[i] = r_out;
-        rect[i] = rc;
-        depth[i] = dep;
+        // (optional outputs: what the iteration's binning does not read is not written — sls_pipeline.hip)
+        if (rect) rect[i] = rc;
+        if (depth) depth[i] = dep;
         if (order_keys) {
             // Input of the depth-order sort.  Culled surfels are keyed by their range as well (they
             // emit nothing): a surfel that flips between visible and culled then keeps its place in
@@ -398,7 +400,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const DevCam &cam, const Reg
         __builtin_amdgcn_wave_barrier();      // (the slice is reused below)
     }
     if (i < N) {
-        tiles[i] = my_tiles;
+        if (tiles) tiles[i] = my_tiles;
         if (pa.sbox) pa.sbox[i] = my_tiles ? make_block_box(q4.x, q4.y, q4.z, q4.w, (cam.GX * kTileW) / 8) : 0u;
         if (tile_mask) tile_mask[i] = my_mask;
         // what the emission reads, in ONE 16-byte gather: the rectangle (16-bit fields) and the mask
@@ -485,26 +487,71 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
     const int *__restrict__ radii, float4 *grec, float *__restrict__ dmeans,
     float2 *__restrict__ dscales, float4 *__restrict__ drots, float *__restrict__ dopac)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {
-        if (af.reg_accum) {   // the regulariser was summed in the workspace: publish it, leave zero for the next iteration
-            af.status_src[6] = __float_as_uint(*af.reg_accum);     // (same type as the mirror's reads below: no aliasing games)
-            *af.reg_accum = 0.0f;
-        }
-        if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM collective
-            const uint32_t bits = af.status_src[1];
-            for (int g = 0; g < (af.void_count > 0 ? af.void_count : 1); ++g) {
-                af.void_flags[(size_t)g * af.void_stride + 0] = (bits & 1u) ? 1.0f : 0.0f;
-                af.void_flags[(size_t)g * af.void_stride + 1] = (bits & ~1u) ? 1.0f : 0.0f;
+    // Passenger workgroups come FIRST in the grid: they start with the launch and run beside the surfels' blocks.  Each
+    // is a chain of latencies (cold loads, barriers, a system-scope fence) with little work: at the end of the grid — or
+    // in front of a block's surfel work — it would outlast the launch at the reference's sizes (+3 us at 50 k surfels).
+    //   block 0 (af.publisher): the iteration's status — loss sums, regulariser, void flags, the pinned host mirror;
+    //   8 blocks (af.order_out): the launch order of the keyframe's next tile backward, one counting sort per XCD.
+    const int n_pub = af.publisher ? 1 : 0, n_ord = af.order_out ? 8 : 0;
+    if ((int)blockIdx.x < n_pub) {
+        if (af.loss_partials) {
+            // the tile backward's blocks left their pixels' loss terms (three arrays of n_loss_partials floats, a multiple
+            // of 16): the iteration's three sums and the pixel-loss total, in a fixed order — every thread a strided
+            // share of 16-byte loads (all in flight at once), then the wave, then the block's four waves
+            __shared__ float s_loss[3][4];
+            const int n4 = af.n_loss_partials / 4;
+            float t[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 *src = reinterpret_cast<const float4 *>(af.loss_partials + (size_t)k * af.n_loss_partials);
+#pragma unroll 8
+                for (int b = threadIdx.x; b < n4; b += 256) {
+                    const float4 v = src[b];
+                    t[k] += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                t[0] += __shfl_down(t[0], off, 64); t[1] += __shfl_down(t[1], off, 64); t[2] += __shfl_down(t[2], off, 64);
+            }
+            if ((threadIdx.x & 63) == 0) { s_loss[0][threadIdx.x >> 6] = t[0]; s_loss[1][threadIdx.x >> 6] = t[1]; s_loss[2][threadIdx.x >> 6] = t[2]; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float r[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r[k] = (s_loss[k][0] + s_loss[k][1]) + (s_loss[k][2] + s_loss[k][3]);
+                af.status_src[2] = __float_as_uint(r[0]); af.status_src[3] = __float_as_uint(r[1]); af.status_src[4] = __float_as_uint(r[2]);
+                af.status_src[5] = __float_as_uint(r[0] * af.loss_w[0] + af.loss_w[1] * r[1] + af.loss_w[2] * r[2]);
             }
         }
-        if (af.status_mirror) mirror_status_block(af.status_src, af.status_mirror);
-        if (af.grad_bitmap) {   // sparse exchange: this rank's verdict behind the bitmap (OR-reduced with the bitmap)
-            const uint32_t bits = af.status_src[1];
-            af.grad_bitmap[af.grad_bitmap_words] = (bits & 1u) ? 1ull : 0ull;
-            af.grad_bitmap[af.grad_bitmap_words + 1] = (bits & ~1u) ? 1ull : 0ull;
+        if (threadIdx.x == 0) {
+            if (af.reg_accum) {   // the regulariser was summed in the workspace: publish it, leave zero for the next iteration
+                af.status_src[6] = __float_as_uint(*af.reg_accum);     // (same type as the mirror's reads below: no aliasing games)
+                *af.reg_accum = 0.0f;
+            }
+            if (af.void_flags) {   // keyframe-parallel mode: the void bits as two floats that can ride a SUM collective
+                const uint32_t bits = af.status_src[1];
+                for (int g = 0; g < (af.void_count > 0 ? af.void_count : 1); ++g) {
+                    af.void_flags[(size_t)g * af.void_stride + 0] = (bits & 1u) ? 1.0f : 0.0f;
+                    af.void_flags[(size_t)g * af.void_stride + 1] = (bits & ~1u) ? 1.0f : 0.0f;
+                }
+            }
+            if (af.status_mirror) mirror_status_block(af.status_src, af.status_mirror);
+            if (af.grad_bitmap) {   // sparse exchange: this rank's verdict behind the bitmap (OR-reduced with the bitmap)
+                const uint32_t bits = af.status_src[1];
+                af.grad_bitmap[af.grad_bitmap_words] = (bits & 1u) ? 1ull : 0ull;
+                af.grad_bitmap[af.grad_bitmap_words + 1] = (bits & ~1u) ? 1ull : 0ull;
+            }
         }
+        return;
     }
+    if ((int)blockIdx.x < n_pub + n_ord) {
+        const int xcd = (int)blockIdx.x - n_pub;
+        order_blocks_by_cost(af.order_T, af.order_cost, af.order_out + 1, xcd);
+        if (xcd == 0 && threadIdx.x == 0) af.order_out[0] = block_order_tag(af.order_T);
+        return;
+    }
+    const int i = ((int)blockIdx.x - n_pub - n_ord) * 256 + threadIdx.x;
     if (i >= N) return;
     float dm[3] = { 0, 0, 0 };
     float2 ds = make_float2(0, 0);
@@ -758,9 +805,11 @@ int launch_preprocess_bwd(const DevCam &cam, int raw, float smax, float pen, int
     AdamFuse af;
     memset(&af, 0, sizeof(af));
     if (fuse) af = *fuse;
+    // (a block of its own for the status duties, if there are any: see the kernel)
+    af.publisher = (af.loss_partials || af.reg_accum || af.void_flags || af.status_mirror || af.grad_bitmap) ? 1 : 0;
     ScopedTimer tm(T_PREPROCESS_BWD, st);
     // (parameters are only written when af.enabled, which the caller sets for its own mutable tensors)
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(256), 0, st, cam, ra, af, N, const_cast<float *>(means),
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb + af.publisher + (af.order_out ? 8 : 0)), dim3(256), 0, st, cam, ra, af, N, const_cast<float *>(means),
                        (float2 *)const_cast<float *>(scales), (float4 *)const_cast<float *>(rots),
                        const_cast<float *>(opac), radii, (float4 *)const_cast<float *>(grec), dmeans, (float2 *)dscales,
                        (float4 *)drots, dopac);

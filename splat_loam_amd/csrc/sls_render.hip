@@ -22,7 +22,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
                             const uint32_t *block_order, int vals_stride, bool dense, const uint8_t *det_prev,
-                            const uint32_t *det_gex, uint32_t *det_flag);
+                            const uint32_t *det_gex, uint32_t *det_flag, bool consumer_b_inline, uint32_t order_tag);
 // Diagnostic switches are per PROCESS (sls_common.hpp: DebugState): torch runs a backward node on its autograd
 // device thread, not on the thread that called sls_debug_variant / sls_debug_wave_cycles, so per-thread state
 // would silently not reach sls_backward under loss.backward().  They are tuning / test aids only: the data path
@@ -55,7 +55,8 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                       const uint64_t *block_masks, bool no_median_dist_grad, uint8_t *touched,
                       const struct ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
                       const uint32_t *block_order, int vals_stride, int block_masks_shape, bool order_in_handover,
-                      const uint8_t *det_prev, const uint32_t *det_gex, uint32_t *det_flag)
+                      const uint8_t *det_prev, const uint32_t *det_gex, uint32_t *det_flag, bool consumer_b_inline,
+                      uint32_t order_tag)
 {
     // vals_stride: 1 = plain list of surfel indices, 2 = the tile sort's (surfel, block mask) pairs.
     // block_masks_shape: the pixel-block shape (sls_debug_variant numbering: 2 = 4x4, 3 = 8x2) of the forward that
@@ -70,7 +71,7 @@ int launch_render_bwd(const DevCam &cam, const uint32_t *ranges, const uint32_t 
                                    grec, block_masks, variant - 2, st, no_median_dist_grad,
                                    touched, fused_consumer, det_max, det_acc,
                                    (debug_state().bwd_variant == 3 || det_max || det_prev) ? block_order : nullptr, vals_stride, dense,
-                                   det_prev, det_gex, det_flag);
+                                   det_prev, det_gex, det_flag, consumer_b_inline, order_tag);
 }
 
 }  // namespace sls

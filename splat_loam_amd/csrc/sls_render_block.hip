@@ -740,9 +740,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 // ---------------------------------------------------------------------------
 // LEAN: the caller guarantees dL/d(median) = dL/d(distortion) = 0 (the mapper's loss at
 // depth_ratio = 0, gaussian_renderer/__init__.py:79-86): their terms are compiled out.
-// FUSED (sls_mapping_step, LEAN only): dL/dallmap is not read but computed per pixel from the consumer's
+// FUSED = 1 (sls_mapping_step, LEAN only): dL/dallmap is not read but computed per pixel from the consumer's
 // kernel-B planes (sls_consumer_dev.hpp) — consumer kernel C is not launched; block 0 also turns kernel B's
 // per-block loss partials into the iteration's loss sums.
+// FUSED = 2: kernel B is not launched either.  The block runs kernel B's per-pixel work itself for its 16 pixels and
+// the 2 (BW + BH) pixels around them — 36 lanes of the wave, one pixel each, the same device function — hands the
+// pieces over in LDS, and leaves its pixels' three loss terms in ca.partials (one array per term, summed by preprocess_bwd).
+// Same gradients bit for bit: one dependent launch and the three planes' round trip less.
 // DET (deterministic accumulation, SlsMappingConfig.deterministic / sls_backward_det): float atomics add in an
 // order that changes from run to run, so the last bits of the gradients do too.  Integer atomics commute:
 //   DET = 1: first launch — per (surfel, field) the LARGEST |contribution| (atomicMax on the float's bit
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 //            fixed-point value reaches 2^50 — the prediction was off by more than 2^22 — sets bit 3 of the iteration's
 //            overflow word: the iteration is void and the caller repeats it with the two launches above.
 // Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
-template <int BW, int BH, bool LEAN, bool FUSED, int DET, bool DENSE>
+template <int BW, int BH, bool LEAN, int FUSED, int DET, bool DENSE>
 __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
@@ -766,12 +770,13 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const float *__restrict__ dL_dallmap, float *__restrict__ grec, const uint64_t *__restrict__ blk_mask,
     uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
     uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order,
-    int vstride, const uint8_t *__restrict__ det_prev, const uint32_t *__restrict__ det_gex, uint32_t *__restrict__ det_flag)
+    int vstride, const uint8_t *__restrict__ det_prev, const uint32_t *__restrict__ det_gex, uint32_t *__restrict__ det_flag,
+    uint32_t order_tag)
 {
     static_assert(DET != 3 || DENSE, "the one-pass deterministic accumulation walks the forward's compact lists");
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
     SLS_TRACE_BEGIN();
-    if (FUSED && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
+    if (FUSED == 1 && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     // (record 64: all zeros, never active — pads the compacted list to a multiple of four, as in the forward)
@@ -786,10 +791,15 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     const int T = cam.GX * cam.GY;
     int tile, sub;
-    if (block_order) {
+    // (order_tag: the order is the keyframe's own buffer, tag first — walked only once an iteration has filled it.  Tag
+    //  and entry are requested together: the buffer has its full size either way)
+    const int oxcd = blockIdx.x % 8;
+    const uint32_t otag = (block_order && order_tag) ? block_order[0] : order_tag;
+    const uint32_t oidx = block_order ? block_order[(order_tag ? 1 : 0) + oxcd * (T * kPerTile / 8) + blockIdx.x / 8] : 0u;
+    if (block_order && otag == order_tag) {
         // the blocks of this XCD, most expensive first (bwd_block_order_kernel): b -> (XCD b % 8, rank b / 8)
-        const int xcd = blockIdx.x % 8;
-        const int i = (int)block_order[xcd * (T * kPerTile / 8) + blockIdx.x / 8];
+        const int xcd = oxcd;
+        const int i = (int)oidx;
         const int ts = i / kPerTile;
         tile = ((ts >> 2) * 8 + xcd) * 4 + (ts & 3);
         sub = i % kPerTile;
@@ -816,6 +826,78 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     // reduction -> field of the gradient record
     const int field = p < 8 ? (int)((0x73625410u >> (4 * p)) & 15u) : p;
     const uint32_t gex_field = DET == 3 ? det_gex[field] : 0u;          // the field's default scale (no history)
+    constexpr int kRing = 16 + 2 * BW + 2 * BH;
+    static_assert(kRing <= 64, "one lane per pixel of the block and its ring");
+    __shared__ float4 s_cb[FUSED == 2 ? 3 * kRing : 1];
+    ConsumerOwn cown;
+    if (FUSED == 2) {
+        static_assert(FUSED != 2 || (BW == 8 && BH == 2), "the inline stage's lane maps are written out for 8x2 blocks");
+        // (the pixel's own inputs of the gradient below: requested first, in flight during the stage)
+        cown = consumer_own_load(ca, min(py, cam.H - 1), min(px, cam.W - 1));
+        // stage 1: the surface points of the 60 pixels within two steps of the block — rows y0-2 .. y0+3 with 8, 10, 12,
+        // 12, 10, 8 pixels — one per lane, into a 6 x 12 grid in LDS (a point is needed by up to four stencils: computed
+        // once, with its division, instead of once per stencil)
+        __shared__ float4 s_pt[6 * 12];
+        {
+            int dr, dc;
+            if (lane < 8) { dr = -2; dc = lane; }
+            else if (lane < 18) { dr = -1; dc = lane - 9; }
+            else if (lane < 30) { dr = 0; dc = lane - 20; }
+            else if (lane < 42) { dr = 1; dc = lane - 32; }
+            else if (lane < 52) { dr = 2; dc = lane - 43; }
+            else { dr = 3; dc = lane - 52; }
+            const int r = y0 + dr, c = x0 + dc;
+            float4 pt = make_float4(0, 0, 0, 0);
+            if (lane < 60 && r >= 0 && r < cam.H && c >= 0 && c < cam.W) {
+                float sd;
+                const float3 pp = surf_point(ca, r, c, sd);
+                pt = make_float4(pp.x, pp.y, pp.z, sd);
+            }
+            if (lane < 60) s_pt[(dr + 2) * 12 + dc + 2] = pt;
+        }
+        // stage 2: kernel B's pieces for the block's pixels [0, 16) and the ring around them — the row above, the row
+        // below, the column left, the column right — one pixel per lane; its own inputs are requested before the barrier
+        int qr, qc;
+        if (lane < 16) { qr = y0 + lane / BW; qc = x0 + lane % BW; }
+        else if (lane < 16 + BW) { qr = y0 - 1; qc = x0 + lane - 16; }
+        else if (lane < 16 + 2 * BW) { qr = y0 + BH; qc = x0 + lane - 16 - BW; }
+        else if (lane < 16 + 2 * BW + BH) { qr = y0 + lane - 16 - 2 * BW; qc = x0 - 1; }
+        else { qr = y0 + lane - 16 - 2 * BW - BH; qc = x0 + BW; }
+        const bool has = lane < kRing && qr >= 0 && qr < cam.H && qc >= 0 && qc < cam.W;
+        bool bvalid = false;
+        float bal = 0.0f, bN0 = 0.0f, bN1 = 0.0f, bN2 = 0.0f, bgt = 0.0f;
+        if (has) {
+            const size_t P = (size_t)cam.H * cam.W, pix = (size_t)qr * cam.W + qc;
+            bvalid = ca.valid[pix] == 1;
+            bal = ca.allmap[SLS_CH_ALPHA * P + pix];
+            bN0 = ca.allmap[(SLS_CH_NORMAL + 0) * P + pix];
+            bN1 = ca.allmap[(SLS_CH_NORMAL + 1) * P + pix];
+            bN2 = ca.allmap[(SLS_CH_NORMAL + 2) * P + pix];
+            bgt = ca.gt_depth[pix];
+        }
+        __syncthreads();
+        float4 bu = make_float4(0, 0, 0, 0), bv = bu, bn = bu;
+        float lg = 0.0f, ln = 0.0f, la = 0.0f;
+        if (has) {
+            const int pi = (qr - y0 + 2) * 12 + (qc - x0 + 2);
+            const float4 po = s_pt[pi], pu = s_pt[pi + 12], pd = s_pt[pi - 12], pr = s_pt[pi + 1], pl = s_pt[pi - 1];
+            const bool interior = (qr > 0) && (qr < cam.H - 1) && (qc > 0) && (qc < cam.W - 1);
+            consumer_b_core(ca, bvalid, bal, bN0, bN1, bN2, po.w, bgt, interior, make_float3(pu.x, pu.y, pu.z),
+                            make_float3(pd.x, pd.y, pd.z), make_float3(pr.x, pr.y, pr.z), make_float3(pl.x, pl.y, pl.z),
+                            bu, bv, bn, lg, ln, la);
+        }
+        if (lane < kRing) { s_cb[lane] = bu; s_cb[kRing + lane] = bv; s_cb[2 * kRing + lane] = bn; }
+        if (lane >= 16) { lg = 0.0f; ln = 0.0f; la = 0.0f; }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            lg += __shfl_down(lg, off, 64); ln += __shfl_down(ln, off, 64); la += __shfl_down(la, off, 64);
+        }
+        if (lane == 0) {      // (three arrays, one per term: preprocess_bwd sums them with 16-byte loads)
+            const size_t nb = (size_t)T * kPerTile, blk = (size_t)(tile * kPerTile + sub);
+            ca.partials[blk] = lg; ca.partials[nb + blk] = ln; ca.partials[2 * nb + blk] = la;
+        }
+        __syncthreads();
+    }
     if (inside) {
         const float2 c = col_cs[px], r = row_cs[py];
         d01 = mk2(c.x * r.x, c.y * r.x); d2 = r.y;
@@ -827,7 +909,14 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         Tf = ps.x; M1 = ps.y; M2 = ps.z;
         if (FUSED) {
             float gpix[7];
-            consumer_pixel_grad(ca, py, px, gpix);
+            if (FUSED == 2) {
+                const int pr = p / BW, pc = p % BW;
+                const int iu = pr > 0 ? p - BW : 16 + pc, id = pr < BH - 1 ? p + BW : 16 + BW + pc;
+                const int il = pc > 0 ? p - 1 : 16 + 2 * BW + pr, ir = pc < BW - 1 ? p + 1 : 16 + 2 * BW + BH + pr;
+                consumer_pixel_grad_core(ca, py, px, cown, s_cb[iu], s_cb[id], s_cb[kRing + il], s_cb[kRing + ir], s_cb[2 * kRing + p], gpix);
+            } else {
+                consumer_pixel_grad(ca, py, px, gpix);
+            }
             dD = gpix[0]; dA = gpix[1]; dN01 = mk2(gpix[2], gpix[3]); dN2 = gpix[4];
         } else {
             dD = dL_dallmap[SLS_CH_DEPTH * P + pix];
@@ -1118,7 +1207,7 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
                             const uint64_t *block_masks, int shape, hipStream_t st, bool lean, uint8_t *touched,
                             const ConsumerArgs *fused_consumer, uint32_t *det_max, unsigned long long *det_acc,
                             const uint32_t *block_order, int vals_stride, bool dense, const uint8_t *det_prev,
-                            const uint32_t *det_gex, uint32_t *det_flag)
+                            const uint32_t *det_gex, uint32_t *det_flag, bool consumer_b_inline, uint32_t order_tag)
 {
     const int T = cam.GX * cam.GY;
     ScopedTimer tm(T_RENDER_BWD, st);
@@ -1138,28 +1227,29 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_, DENSE_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag)
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag, order_tag)
 #define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
     do { if (dense) SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, true); else SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, false); } while (0)
     if (det_prev) {
         // deterministic accumulation in ONE launch: predicted scales (8x2 kernel on the forward's compact lists only)
         SLS_REQUIRE(det_acc && det_gex && det_flag && shape == 1 && dense, "the one-pass deterministic accumulation needs the 8x2 kernel on the forward's compact lists");
         if (fused_consumer) { SLS_REQUIRE(lean, "the fused consumer gradient exists for the lean kernel only");
-                              SLS_BWD_LAUNCH(8, 2, true, true, 3, true); }
-        else if (lean) SLS_BWD_LAUNCH(8, 2, true, false, 3, true);
-        else SLS_BWD_LAUNCH(8, 2, false, false, 3, true);
+                              if (consumer_b_inline) SLS_BWD_LAUNCH(8, 2, true, 2, 3, true); else SLS_BWD_LAUNCH(8, 2, true, 1, 3, true); }
+        else if (lean) SLS_BWD_LAUNCH(8, 2, true, 0, 3, true);
+        else SLS_BWD_LAUNCH(8, 2, false, 0, 3, true);
     } else if (det_max) {
         // deterministic accumulation: two launches of the 8x2 kernel (maximum, then fixed-point sum)
         SLS_REQUIRE(det_acc && shape == 1, "deterministic accumulation exists for the 8x2 kernel");
         if (fused_consumer) { SLS_REQUIRE(lean, "the fused consumer gradient exists for the lean kernel only");
-                              SLS_BWD_BLOCK(8, 2, true, true, 1); SLS_BWD_BLOCK(8, 2, true, true, 2); }
-        else if (lean) { SLS_BWD_BLOCK(8, 2, true, false, 1); SLS_BWD_BLOCK(8, 2, true, false, 2); }
-        else { SLS_BWD_BLOCK(8, 2, false, false, 1); SLS_BWD_BLOCK(8, 2, false, false, 2); }
+                              if (consumer_b_inline) { SLS_BWD_BLOCK(8, 2, true, 2, 1); SLS_BWD_BLOCK(8, 2, true, 2, 2); }
+                              else { SLS_BWD_BLOCK(8, 2, true, 1, 1); SLS_BWD_BLOCK(8, 2, true, 1, 2); } }
+        else if (lean) { SLS_BWD_BLOCK(8, 2, true, 0, 1); SLS_BWD_BLOCK(8, 2, true, 0, 2); }
+        else { SLS_BWD_BLOCK(8, 2, false, 0, 1); SLS_BWD_BLOCK(8, 2, false, 0, 2); }
     } else if (fused_consumer) {
         SLS_REQUIRE(lean && shape == 1, "the fused consumer gradient exists for the lean 8x2 kernel only");
-        SLS_BWD_BLOCK(8, 2, true, true, 0);
-    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, false, 0); else SLS_BWD_BLOCK(4, 4, true, false, 0); }
-    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, false, 0); else SLS_BWD_BLOCK(4, 4, false, false, 0); }
+        if (consumer_b_inline) SLS_BWD_BLOCK(8, 2, true, 2, 0); else SLS_BWD_BLOCK(8, 2, true, 1, 0);
+    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, 0, 0); else SLS_BWD_BLOCK(4, 4, true, 0, 0); }
+    else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, 0, 0); else SLS_BWD_BLOCK(4, 4, false, 0, 0); }
 #undef SLS_BWD_LAUNCH
 #undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");

@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     if (DIRECT) {
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) {
             const uint32_t c = s_hist[d];
-            db.cnt[(size_t)d * db.nchunks + blockIdx.x] = c;
+            db.cnt[(size_t)d * db.stride + blockIdx.x] = c;
             if (db.coarse && c) atomicAdd(&db.coarse[(size_t)(blockIdx.x / kDirectGroup) * db.bins + d], c);
         }
         SLS_MT(3);
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
     __syncthreads();
     if ((int)threadIdx.x < db.bins) {
         const uint32_t c = s_hist[threadIdx.x];
-        db.cnt[(size_t)threadIdx.x * db.nchunks + blockIdx.x] = c;
+        db.cnt[(size_t)threadIdx.x * db.stride + blockIdx.x] = c;
         if (db.coarse && c) atomicAdd(&db.coarse[(size_t)(blockIdx.x / kDirectGroup) * db.bins + threadIdx.x], c);
     }
 }
@@ -862,15 +862,20 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
                     all += v;
                     front_g += g < g0 ? v : 0u;
                 }
-                const uint32_t *row = db.cnt + (size_t)d * db.nchunks + g0 * kDirectGroup;
+                // (the group's counts of this tile: one aligned 64-byte line, four 16-byte loads)
+                const uint4 *row = reinterpret_cast<const uint4 *>(db.cnt + (size_t)d * db.stride + g0 * kDirectGroup);
+                const int nin = chunk - g0 * kDirectGroup;          // chunks of the own group in front: 0..15
                 uint32_t front_c = 0u;
 #pragma unroll
-                for (int c = 0; c < kDirectGroup - 1; ++c) front_c += (g0 * kDirectGroup + c < chunk) ? row[c] : 0u;
+                for (int c = 0; c < kDirectGroup / 4; ++c) {
+                    const uint4 v = row[c];
+                    front_c += (4 * c < nin ? v.x : 0u) + (4 * c + 1 < nin ? v.y : 0u) + (4 * c + 2 < nin ? v.z : 0u) + (4 * c + 3 < nin ? v.w : 0u);
+                }
                 tot[q] = all;
                 ccol[q] = front_g + front_c;
             } else {
                 tot[q] = db.totals[d];
-                ccol[q] = db.cnt[(size_t)d * db.nchunks + chunk];
+                ccol[q] = db.cnt[(size_t)d * db.stride + chunk];
             }
         }
     }
@@ -1448,13 +1453,21 @@ static int direct_bins(const DevCam &cam)
 }
 // Can the direct binning serve this camera / size / capacity?  (tiles <= 512, D10 off, 16-bit rectangle fields, the
 // count table inside the sort's scratch; SLS_NO_DIRECT_BIN=1: never — the emission + radix pass, for A/B runs)
+// words per row of the count table that serve either chunking, with or without the coarse table
+static size_t direct_max_stride(int N)
+{
+    const size_t nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
+    return (nchunks + kDirectGroup - 1) / kDirectGroup * kDirectGroup;
+}
 bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap)
 {
     static const bool off = getenv("SLS_NO_DIRECT_BIN") != nullptr && getenv("SLS_NO_DIRECT_BIN")[0] == '1';
     if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX > 512 || cam.GY > 64) return false;    // (pack_rect32's fields)
     if (cam.GX * cam.GY > kDirectMaxBins) return false;
-    const size_t bins = (size_t)direct_bins(cam), nchunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
-    return (bins * nchunks + bins + direct_coarse_words(cam, N)) * sizeof(uint32_t) <= sort_core_bytes(cap);
+    // (its emission records carry the surfel's block box: images the box can describe)
+    if (!block_box_fits(cam.GX * kTileW, cam.H)) return false;
+    const size_t bins = (size_t)direct_bins(cam);
+    return (bins * direct_max_stride(N) + bins + direct_coarse_words(cam, N)) * sizeof(uint32_t) <= sort_core_bytes(cap);
 }
 // words of the coarse table (groups of kDirectGroup chunks x tiles), for either chunking
 size_t direct_coarse_words(const DevCam &cam, int N)
@@ -1469,13 +1482,13 @@ DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *s
     db.bins = direct_bins(cam);
     db.nchunks = repaired ? (N + kResortWindow / 2 + kResortWindow - 1) / kResortWindow : (N + kDirectChunk - 1) / kDirectChunk;
     db.pos0 = repaired ? -kResortWindow / 2 : 0;
+    db.stride = coarse ? (db.nchunks + kDirectGroup - 1) / kDirectGroup * kDirectGroup : db.nchunks;
     db.cnt = (uint32_t *)sort_scratch;
-    db.totals = db.cnt + (size_t)db.bins * db.nchunks;
+    db.totals = db.cnt + (size_t)db.bins * db.stride;
     db.serec = serec;
     // (the coarse table sits at a place that does not depend on the chunking: the iteration's first kernel zeroes it
     //  before the depth-order stage decides between repair and radix sort)
-    const size_t max_chunks = (size_t)(N + kDirectChunk / 2 + kDirectChunk - 1) / kDirectChunk;
-    db.coarse = coarse ? (uint32_t *)sort_scratch + (size_t)db.bins * max_chunks + db.bins : nullptr;
+    db.coarse = coarse ? (uint32_t *)sort_scratch + (size_t)db.bins * direct_max_stride(N) + db.bins : nullptr;
     return db;
 }
 

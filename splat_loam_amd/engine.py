@@ -127,6 +127,10 @@ class MappingEngine:
         # temporal re-sort: the workspace keeps the depth order of the last iteration; it is repaired
         # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
         self.reuse_depth_order = True
+        # the loss stage inside the tile backward (no launch of its own; the backward's launch order then comes from the
+        # keyframe's previous iteration): same gradients bit for bit.  SLS_NO_FUSED_B=1 in the library's environment
+        # switches it off as well (A/B runs)
+        self.inline_loss_stage = True
         self.repair_span = 256            # iterations an extra repair round stays on after a repair that did not reach
         self._repair_rounds, self._repair_until = 1, 0
         # single GPU: Adam is applied inside the backward; the flat gradient bucket is only filled when asked
@@ -263,7 +267,9 @@ class MappingEngine:
                 del self._orders[k]
             if len(self._orders) >= self.max_cached_orders:
                 self._orders.pop(next(iter(self._orders)))
-            ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None, weakref.ref(camera)]
+            # + the keyframe's launch order of the tile backward (SlsMappingConfig.block_order; zeros: none yet)
+            ent = [torch.empty((self.N,), dtype=torch.int32, device=self.dev), None, weakref.ref(camera),
+                   torch.zeros((int(lib.sls_block_order_bytes(H, W)) // 4,), dtype=torch.int32, device=self.dev)]
             self._orders[id(camera)] = ent
         age = self._enq - ent[1] if ent[1] is not None else None
         reuse = allow_reuse and self.reuse_depth_order and age is not None and age <= self.max_order_age_extra
@@ -293,6 +299,7 @@ class MappingEngine:
             cfg.deterministic = 1 if (self._det_two_pass_next or first_visit or not cfg.workspace_ready) else 2
             self._det_two_pass_next = False
         cfg.depth_order = ent[0].data_ptr()
+        cfg.block_order = ent[3].data_ptr() if self.inline_loss_stage else None
         cfg.status_mirror = mirror
         # keyframe-parallel mode: the void bits leave the step as two floats behind the gradient bucket
         cfg.void_flags_out = None if (apply_adam or self._dp is not None) else self.grads.data_ptr() + 4 * 10 * self.N

@@ -85,6 +85,17 @@ def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw, block_m
     _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed=23)
 
 
+@pytest.mark.gpu
+def test_engine_gradients_match_checker_chain_tall_image(device, oracle32):
+    """An image taller than the 128 rows a surfel's block box can describe: no block masks, and the binning whose
+    records carry the box (the direct one) must step aside.  160 rows over the same elevation span: a pixel pitch 2.5
+    times finer, and the normal term amplifies an image perturbation by 1 / (2 pitch) — the float32 checker itself is
+    7e-5 (max-norm) / 2e-2 (element-wise) from its float64 build on this scene.  Judged as at full size: fragile pixels
+    out of the loss, against what float32 itself costs, element-wise bar 5e-3."""
+    _check_engine_against_checker_chain(device, "tall", 6000, 160, 256, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25), 0,
+                                        seed=23, mask_fragile=oracle32, float64_too=True, elem_tol=5e-3)
+
+
 def test_engine_gradients_match_checker_chain_c3(device, oracle32):
     """the instantiations bench.py TIMES at the size it times them — BASELINE config 3, the bench
     scene itself (500 000 surfels, 64x2048, seed 0), `block_masks = 0`: the automatic rule switches the tile sort to
@@ -117,7 +128,8 @@ def _fragile_neighbourhood(oracle, raw, view, proj, H, W):
     return f | np.roll(f, 1, 0) | np.roll(f, -1, 0) | np.roll(f, 1, 1) | np.roll(f, -1, 1)
 
 
-def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1, float64_too=False):
+def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1, float64_too=False,
+                                        elem_tol=2e-3):
     """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
     chain.  Two comparisons:
       * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
@@ -153,11 +165,11 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
         same64 = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am, dtype=np.float64)
     # (float atomics: the gradients vary from run to run — every run has to meet the bar)
     for k, (st, g, _, eng, model, cam) in enumerate(runs):
-        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same, own64, same64)
+        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same, own64, same64, elem_tol)
     return runs[0][3]
 
 
-def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=None, same64=None):
+def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=None, same64=None, elem_tol=2e-3):
     # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image
     for c in range(5):
         scale = max(np.abs(own["allmap"][c]).max(), 1e-12)
@@ -192,7 +204,7 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=N
     for (tag, k), (e, er, e64, er64, n64, nr64) in report.items():
         if e64 is None:
             assert e <= RTOL, f"{name}: {tag} d{k} max-norm rel err {e:.3e} > {RTOL}"
-            assert er <= 2e-3, f"{name}: {tag} d{k} element-wise rel err {er:.3e}"
+            assert er <= elem_tol, f"{name}: {tag} d{k} element-wise rel err {er:.3e}"
         else:
             # At full size (2400-entry lists, 500 k surfels) two float32 evaluations of the same formulas — these
             # kernels and the checker's float32 build — differ by what float32 rounding and summation order cost; the
@@ -201,7 +213,7 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=N
             # checker as the float32 checker is (x1.5).
             assert e <= RTOL or e64 <= max(RTOL, 1.5 * n64), \
                 f"{name}: {tag} d{k} max-norm rel err {e:.3e} (float32 checker), {e64:.3e} (float64); float32 vs float64 checker {n64:.3e}"
-            assert er <= 2e-3 or er64 <= max(2e-3, 1.5 * nr64), \
+            assert er <= elem_tol or er64 <= max(elem_tol, 1.5 * nr64), \
                 f"{name}: {tag} d{k} element-wise rel err {er:.3e} (float32 checker), {er64:.3e} (float64); float32 vs float64 checker {nr64:.3e}"
     # the fused Adam consumed exactly these gradients: first step = -lr * sign(g) wherever |g| is not ~0
     lrs = {"xyz": 5e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
@@ -423,3 +435,56 @@ def test_cov3D_precomp_renders_the_same_surfels(device):
     with pytest.raises(Exception):
         rast(means3D=means, means2D=torch.zeros_like(means), opacities=opac, scales=scales, rotations=rots,
              cov3D_precomp=trans)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,hfov", [(32, 512, 360.0), (40, 500, 120.0)], ids=["wrap-32x512", "edges-40x500"])
+def test_loss_stage_inside_the_tile_backward(device, H, W, hfov):
+    """VERDICT r3 item 7.  With the keyframe's launch-order buffer (SlsMappingConfig.block_order) the loss stage has no
+    launch of its own: the tile backward computes kernel B's pieces for its pixels and the ring around them.  Same
+    device function, so the SAME gradients bit for bit (compared under the deterministic accumulation, where bits
+    are reproducible at all), on a first visit (no order yet) and on later ones (the order of the visit before);
+    the loss sums are added in another order: 1e-6.  40x500: partial tiles and an image with edges."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    scm = synth.make_scene(20000, H, W, seed=41, range_lo=2.0, range_hi=25.0)
+    if hfov != 360.0:
+        scm["K"] = synth.spherical_K(H, W, hfov_deg=hfov)
+    depth, valid = synth.make_targets(H, W, scm)
+    poses = synth.keyframe_poses(3)
+    cams = [Camera(scm["K"], depth, None, valid, poses[k], data_device=str(device)) for k in (1, 2)]
+    runs = []
+    for inline in (True, False, True):
+        m = SurfelModel.from_activated(scm["means"], scm["scales"], scm["rots"], scm["opac"], device=str(device))
+        e = MappingEngine(m, MappingConfig())
+        e.deterministic = True
+        e.keep_grads = True
+        e.inline_loss_stage = inline
+        trace = []
+        for it in range(6):
+            st = e.step(cams[it % 2])
+            trace.append((st["loss"], list(st["sums"]),
+                          {k: v.detach().cpu().numpy().copy() for k, v in e.grad_views().items()}))
+        runs.append((trace, [p.detach().cpu().numpy() for p in (m._xyz, m._scaling, m._rotation, m._opacity)]))
+    (ta, pa), (tb, pb), (tc, pc) = runs
+    for it in range(6):
+        for k in ta[it][2]:
+            assert np.array_equal(ta[it][2][k].view(np.uint32), tb[it][2][k].view(np.uint32)), f"iteration {it}: gradient {k}"
+        assert np.isclose(ta[it][0], tb[it][0], rtol=1e-6)
+        assert np.allclose(ta[it][1], tb[it][1], rtol=1e-6)
+        assert ta[it][0] == tc[it][0], "the inline path's loss sums: a fixed order, identical from run to run"
+    for a, b in zip(pa, pb):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "identical parameters after six iterations"
+    # the order buffers were filled: tag word + a permutation per XCD
+    ent = next(iter(e._orders.values()))
+    words = ent[3].cpu().numpy().view(np.uint32)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    if T % 32 == 0:
+        assert words[0] == 0x424F0000 + T
+        per = words[1:].reshape(8, T * 2)
+        for x in range(8):
+            assert np.array_equal(np.sort(per[x]), np.arange(T * 2, dtype=np.uint32))
+    else:
+        assert words[0] == 0
