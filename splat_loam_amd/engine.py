@@ -147,10 +147,11 @@ class MappingEngine:
         self._orders = {}
         self.max_order_age = 4
         # up to this age (iterations since the keyframe was last rendered) an order is still repaired — with one more
-        # round beyond max_order_age, two more beyond 12 — instead of rebuilt (SLS_ORDER_AGE_EXTRA; 24 since round 4:
-        # a repair round costs 14 us, the radix sort 90; -0.5 % per iteration at 500 k, -2.7 % at 50 k with the
-        # mapper's keyframe sampling)
-        self.max_order_age_extra = int(os.environ.get("SLS_ORDER_AGE_EXTRA", "24"))
+        # round beyond max_order_age, two more beyond 12, three more beyond SLS_ORDER_AGE_ROUND4 — instead of rebuilt
+        # (SLS_ORDER_AGE_EXTRA; a repair round costs 14 us, the radix sort 90; measured with the mapper's keyframe
+        # sampling: 24 against 12: -0.5 % per iteration at 500 k, -2.7 % at 50 k; 48 against 24: -1 % / -2.5 %)
+        self.max_order_age_extra = int(os.environ.get("SLS_ORDER_AGE_EXTRA", "48"))
+        self.order_age_round4 = int(os.environ.get("SLS_ORDER_AGE_ROUND4", "1000000"))
         self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0, "repeated_det": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
@@ -280,7 +281,8 @@ class MappingEngine:
             self._repair_until = self._enq + self.repair_span
         # an order older than max_order_age iterations gets one more round (the surfels have drifted further)
         reuse = min(self._repair_rounds + (1 if age is not None and age > self.max_order_age else 0)
-                    + (1 if age is not None and age > 12 else 0), 4) if reuse else 0
+                    + (1 if age is not None and age > 12 else 0)
+                    + (1 if age is not None and age > self.order_age_round4 else 0), 4) if reuse else 0
         self._enq += 1
         ent[1] = self._enq
         cfg = self._config(apply_adam, with_regulariser, reuse)
