@@ -451,7 +451,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_kernel(DevCam cam, RegArgs
 // the arithmetic of surfel_geom<true> — the others preprocess 512 surfels each.  The window sort is a chain of
 // latencies (gathers, LDS stages), the preprocess is VALU bound: side by side they cost little more than the
 // longer of the two, and the iteration has one dependent launch less.
-__global__ __launch_bounds__(512) void preprocess_fwd_resort_kernel(DevCam cam, RegArgs ra, int N, PreFwdArgs pa, int n_windows,
+// (six waves per SIMD = three workgroups per CU: at the 83 registers the compiler would take, a CU holds two — 2.9
+//  generations of workgroups at 500 k surfels instead of 1.9; the cap costs two spilled words)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void preprocess_fwd_resort_kernel(DevCam cam, RegArgs ra, int N, PreFwdArgs pa, int n_windows,
                                                                     const uint32_t *__restrict__ prev_order,
                                                                     uint64_t *__restrict__ comp)
 {

@@ -145,13 +145,7 @@ class MappingEngine:
         # reused by a new object once the old keyframe is gone)]; an order older than max_order_age
         # iterations gets an extra repair round, one older than max_order_age_extra is rebuilt from scratch
         self._orders = {}
-        self.max_order_age = 4
-        # up to this age (iterations since the keyframe was last rendered) an order is still repaired — with one more
-        # round beyond max_order_age, two more beyond 12, three more beyond SLS_ORDER_AGE_ROUND4 — instead of rebuilt
-        # (SLS_ORDER_AGE_EXTRA; a repair round costs 14 us, the radix sort 90; measured with the mapper's keyframe
-        # sampling: 24 against 12: -0.5 % per iteration at 500 k, -2.7 % at 50 k; 48 against 24: -1 % / -2.5 %)
-        self.max_order_age_extra = int(os.environ.get("SLS_ORDER_AGE_EXTRA", "48"))
-        self.order_age_round4 = int(os.environ.get("SLS_ORDER_AGE_ROUND4", "1000000"))
+        self._set_order_ages()
         self.max_cached_orders = 64
         self.stats = {"repeated_too_small": 0, "repeated_resort": 0, "repeated_exchange": 0, "repeated_det": 0}
         self._enq = 0                     # iterations enqueued so far (age of the cached depth orders)
@@ -237,6 +231,22 @@ class MappingEngine:
             self._repair_rounds = min(self._repair_rounds + 1, 3)
             self._repair_until = self._enq + self.repair_span
 
+    def _set_order_ages(self):
+        """The ages (iterations since the keyframe was last rendered) that decide how a keyframe's depth order is
+        brought up to date: one repair round up to `max_order_age`, two up to `order_age_round3`, three up to
+        `max_order_age_extra` (four beyond `order_age_round4`), a rebuild beyond.  A round reaches 512 POSITIONS, and
+        how many positions a surfel travels for the same change of depth grows with the number of surfels: measured
+        at 500 k surfels (4 / 12 / 48; looser values fail repairs, each costs a void iteration + a rebuild) and at
+        170 k / 50 k (12 / 32 / 200 without a failure, -1.5 % / -2.5 % per iteration with the mapper's keyframe
+        sampling), hence the scale with 500 k / N, capped at 3.  A repair round costs 14 us, the radix sort 90.
+        SLS_ORDER_AGE_ROUND2 / _ROUND3 / _ROUND4 / _EXTRA override."""
+        scale = min(max(500000.0 / max(self.N, 1), 1.0), 3.0)
+        env = os.environ.get
+        self.max_order_age = int(env("SLS_ORDER_AGE_ROUND2", str(int(4 * scale))))
+        self.order_age_round3 = int(env("SLS_ORDER_AGE_ROUND3", str(int(12 * scale))))
+        self.max_order_age_extra = int(env("SLS_ORDER_AGE_EXTRA", str(int(48 * scale))))
+        self.order_age_round4 = int(env("SLS_ORDER_AGE_ROUND4", "1000000"))
+
     def _params(self):
         m = self.model
         ps = (m._xyz, m._scaling, m._rotation, m._opacity)
@@ -281,7 +291,7 @@ class MappingEngine:
             self._repair_until = self._enq + self.repair_span
         # an order older than max_order_age iterations gets one more round (the surfels have drifted further)
         reuse = min(self._repair_rounds + (1 if age is not None and age > self.max_order_age else 0)
-                    + (1 if age is not None and age > 12 else 0)
+                    + (1 if age is not None and age > self.order_age_round3 else 0)
                     + (1 if age is not None and age > self.order_age_round4 else 0), 4) if reuse else 0
         self._enq += 1
         ent[1] = self._enq
@@ -781,6 +791,7 @@ class MappingEngine:
         self._sx = None
         self._dp = None                               # re-sharded at the next keyframe-parallel step
         self.N = n_new
+        self._set_order_ages()
         self.grads = torch.zeros((10 * n_new + 2,), dtype=torch.float32, device=self.dev)
         self.workspace = None                        # sized by N: rebuilt at the next step
         self._orders.clear()                         # surfel indices changed: every kept depth order is void

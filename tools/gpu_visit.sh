@@ -4,4 +4,5 @@ TAG=${1:-r04x}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-VARIANTS="_ SLS_ORDER_AGE_EXTRA=96 SLS_ORDER_AGE_EXTRA=96+SLS_ORDER_AGE_ROUND4=40 SLS_ORDER_AGE_EXTRA=200+SLS_ORDER_AGE_ROUND4=40" REPS=2 KERNELS=sort_hist bash tools/ab_env.sh > gpurun_out/${TAG}_ab.txt 2>&1; cut -c1-600 gpurun_out/${TAG}_ab.txt
+VARIANTS="_ SLS_ORDER_AGE_ROUND2=4+SLS_ORDER_AGE_ROUND3=12+SLS_ORDER_AGE_EXTRA=48" REPS=2 KERNELS=resort bash tools/ab_env.sh > gpurun_out/${TAG}_ab.txt 2>&1; cut -c1-600 gpurun_out/${TAG}_ab.txt
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4
