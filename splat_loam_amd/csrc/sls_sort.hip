@@ -857,10 +857,21 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
                 // in front + the chunks of its own group in front (raw counts; all loads independent)
                 const int ngroups = (db.nchunks + kDirectGroup - 1) / kDirectGroup, g0 = chunk / kDirectGroup;
                 uint32_t all = 0u, front_g = 0u;
-                for (int g = 0; g < ngroups; ++g) {
-                    const uint32_t v = db.coarse[(size_t)g * BINS + d];
-                    all += v;
-                    front_g += g < g0 ? v : 0u;
+                // (sixteen loads in flight at a time: written as a plain loop the compiler waits for every pair of
+                //  them — sixteen L2 round trips one after the other at BASELINE config 3, 5 us of the launch)
+                for (int gb = 0; gb < ngroups; gb += 16) {
+                    uint32_t v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {     // (uniform row, lane offset d: one address register for all)
+                        const int grow = __builtin_amdgcn_readfirstlane(min(gb + k, ngroups - 1));
+                        v[k] = (db.coarse + (size_t)grow * BINS)[d];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t w = gb + k < ngroups ? v[k] : 0u;
+                        all += w;
+                        front_g += gb + k < g0 ? w : 0u;
+                    }
                 }
                 // (the group's counts of this tile: one aligned 64-byte line, four 16-byte loads)
                 const uint4 *row = reinterpret_cast<const uint4 *>(db.cnt + (size_t)d * db.stride + g0 * kDirectGroup);

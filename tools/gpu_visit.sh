@@ -4,5 +4,9 @@ TAG=${1:-r04x}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-VARIANTS="_ SLS_ORDER_AGE_ROUND2=4+SLS_ORDER_AGE_ROUND3=12+SLS_ORDER_AGE_EXTRA=48" REPS=2 KERNELS=resort bash tools/ab_env.sh > gpurun_out/${TAG}_ab.txt 2>&1; cut -c1-600 gpurun_out/${TAG}_ab.txt
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4
+cp splat_loam_amd/libsls_hip.so /tmp/keep.so
+VARIANTS="w6 all" bash tools/ab_sizes.sh > gpurun_out/${TAG}_ab.txt 2>&1; cut -c1-300 gpurun_out/${TAG}_ab.txt
+cp /tmp/keep.so splat_loam_amd/libsls_hip.so
+cp gpurun_tmp_all.so splat_loam_amd/libsls_hip.so
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
+cp /tmp/keep.so splat_loam_amd/libsls_hip.so
