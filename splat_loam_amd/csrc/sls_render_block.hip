@@ -786,16 +786,23 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     __shared__ uint4 s_ex[DET == 3 ? 65 : 1];    // DET = 3: the predicted-scale bytes (16 fields) of the round's entries
     // DENSE: blk_mask is the compact-list hand-over of a forward with the same block shape (the launcher checks what
     // it can, the tag settles it: another producer's buffer is not walked)
-    if (DENSE && blk_mask[0] != block_mask_tag(BW)) return;
+    const int T = cam.GX * cam.GY;
+    // The three words that decide where this block works — the hand-over's tag, the launch order's tag (order_tag: the
+    // order is the keyframe's own buffer, walked only once an iteration has filled it; it has its full size either
+    // way) and the block's entry in it — are requested TOGETHER: one memory round trip at the head of the block, not
+    // three one after the other.
+    const int oxcd = blockIdx.x % 8;
+    const uint64_t tagw = DENSE ? blk_mask[0] : 0ull;
+    // (unconditional loads — from `ranges`, always there, where there is no order: a load under a condition is a
+    //  branch with a wait of its own)
+    const uint32_t *ob = block_order ? block_order : reinterpret_cast<const uint32_t *>(ranges);
+    const uint32_t otag_w = ob[0];
+    const uint32_t oidx = ob[block_order ? (order_tag ? 1 : 0) + oxcd * (T * kPerTile / 8) + (int)blockIdx.x / 8 : 0];
+    const uint32_t otag = (block_order && order_tag) ? otag_w : order_tag;
+    if (DENSE && tagw != block_mask_tag(BW)) return;
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
-    const int T = cam.GX * cam.GY;
     int tile, sub;
-    // (order_tag: the order is the keyframe's own buffer, tag first — walked only once an iteration has filled it.  Tag
-    //  and entry are requested together: the buffer has its full size either way)
-    const int oxcd = blockIdx.x % 8;
-    const uint32_t otag = (block_order && order_tag) ? block_order[0] : order_tag;
-    const uint32_t oidx = block_order ? block_order[(order_tag ? 1 : 0) + oxcd * (T * kPerTile / 8) + blockIdx.x / 8] : 0u;
     if (block_order && otag == order_tag) {
         // the blocks of this XCD, most expensive first (bwd_block_order_kernel): b -> (XCD b % 8, rank b / 8)
         const int xcd = oxcd;
@@ -834,6 +841,27 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         static_assert(FUSED != 2 || (BW == 8 && BH == 2), "the inline stage's lane maps are written out for 8x2 blocks");
         // (the pixel's own inputs of the gradient below: requested first, in flight during the stage)
         cown = consumer_own_load(ca, min(py, cam.H - 1), min(px, cam.W - 1));
+        // stage 2 (below) = kernel B's pieces for the block's pixels [0, 16) and the ring around them — the row above, the
+        // row below, the column left, the column right — one pixel per lane; its own inputs are requested here, before
+        // stage 1 computes
+        int qr, qc;
+        if (lane < 16) { qr = y0 + lane / BW; qc = x0 + lane % BW; }
+        else if (lane < 16 + BW) { qr = y0 - 1; qc = x0 + lane - 16; }
+        else if (lane < 16 + 2 * BW) { qr = y0 + BH; qc = x0 + lane - 16 - BW; }
+        else if (lane < 16 + 2 * BW + BH) { qr = y0 + lane - 16 - 2 * BW; qc = x0 - 1; }
+        else { qr = y0 + lane - 16 - 2 * BW - BH; qc = x0 + BW; }
+        const bool has = lane < kRing && qr >= 0 && qr < cam.H && qc >= 0 && qc < cam.W;
+        uint32_t bvalid = 0u;      // (the byte as loaded: a comparison here would wait for it before stage 1's loads leave)
+        float bal = 0.0f, bN0 = 0.0f, bN1 = 0.0f, bN2 = 0.0f, bgt = 0.0f;
+        if (has) {
+            const size_t P = (size_t)cam.H * cam.W, pix = (size_t)qr * cam.W + qc;
+            bvalid = ca.valid[pix];
+            bal = ca.allmap[SLS_CH_ALPHA * P + pix];
+            bN0 = ca.allmap[(SLS_CH_NORMAL + 0) * P + pix];
+            bN1 = ca.allmap[(SLS_CH_NORMAL + 1) * P + pix];
+            bN2 = ca.allmap[(SLS_CH_NORMAL + 2) * P + pix];
+            bgt = ca.gt_depth[pix];
+        }
         // stage 1: the surface points of the 60 pixels within two steps of the block — rows y0-2 .. y0+3 with 8, 10, 12,
         // 12, 10, 8 pixels — one per lane, into a 6 x 12 grid in LDS (a point is needed by up to four stencils: computed
         // once, with its division, instead of once per stencil)
@@ -855,26 +883,9 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             }
             if (lane < 60) s_pt[(dr + 2) * 12 + dc + 2] = pt;
         }
-        // stage 2: kernel B's pieces for the block's pixels [0, 16) and the ring around them — the row above, the row
-        // below, the column left, the column right — one pixel per lane; its own inputs are requested before the barrier
-        int qr, qc;
-        if (lane < 16) { qr = y0 + lane / BW; qc = x0 + lane % BW; }
-        else if (lane < 16 + BW) { qr = y0 - 1; qc = x0 + lane - 16; }
-        else if (lane < 16 + 2 * BW) { qr = y0 + BH; qc = x0 + lane - 16 - BW; }
-        else if (lane < 16 + 2 * BW + BH) { qr = y0 + lane - 16 - 2 * BW; qc = x0 - 1; }
-        else { qr = y0 + lane - 16 - 2 * BW - BH; qc = x0 + BW; }
-        const bool has = lane < kRing && qr >= 0 && qr < cam.H && qc >= 0 && qc < cam.W;
-        bool bvalid = false;
-        float bal = 0.0f, bN0 = 0.0f, bN1 = 0.0f, bN2 = 0.0f, bgt = 0.0f;
-        if (has) {
-            const size_t P = (size_t)cam.H * cam.W, pix = (size_t)qr * cam.W + qc;
-            bvalid = ca.valid[pix] == 1;
-            bal = ca.allmap[SLS_CH_ALPHA * P + pix];
-            bN0 = ca.allmap[(SLS_CH_NORMAL + 0) * P + pix];
-            bN1 = ca.allmap[(SLS_CH_NORMAL + 1) * P + pix];
-            bN2 = ca.allmap[(SLS_CH_NORMAL + 2) * P + pix];
-            bgt = ca.gt_depth[pix];
-        }
+        // (keeps the byte a register until here: the compiler otherwise compares it where it is loaded — and waits for
+        //  it, a full round trip, before stage 1's loads are issued)
+        asm volatile("" : "+v"(bvalid));
         __syncthreads();
         float4 bu = make_float4(0, 0, 0, 0), bv = bu, bn = bu;
         float lg = 0.0f, ln = 0.0f, la = 0.0f;
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             const int pi = (qr - y0 + 2) * 12 + (qc - x0 + 2);
             const float4 po = s_pt[pi], pu = s_pt[pi + 12], pd = s_pt[pi - 12], pr = s_pt[pi + 1], pl = s_pt[pi - 1];
             const bool interior = (qr > 0) && (qr < cam.H - 1) && (qc > 0) && (qc < cam.W - 1);
-            consumer_b_core(ca, bvalid, bal, bN0, bN1, bN2, po.w, bgt, interior, make_float3(pu.x, pu.y, pu.z),
+            consumer_b_core(ca, bvalid == 1u, bal, bN0, bN1, bN2, po.w, bgt, interior, make_float3(pu.x, pu.y, pu.z),
                             make_float3(pd.x, pd.y, pd.z), make_float3(pr.x, pr.y, pr.z), make_float3(pl.x, pl.y, pl.z),
                             bu, bv, bn, lg, ln, la);
         }

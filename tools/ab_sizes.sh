@@ -11,7 +11,7 @@ for shape in "500000 64 2048" "170000 64 1024" "50000 64 1024"; do
       timeout 60 python bench.py --no-cpu-baseline --no-extras --n $1 --height $2 --width $3 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print('$1 $2x$3 $v', d['value'], d['ms_per_step'], {k: v['avg_us'] for k, v in d['kernels'].items() if 'preprocess' in k or 'bin_' in k})" || echo "$1 $2x$3 $v FAILED"
+print('$1 $2x$3 $v', d['value'], d['ms_per_step'], {k: v['avg_us'] for k, v in d['kernels'].items() if 'render' in k})" || echo "$1 $2x$3 $v FAILED"
     done
   done
 done
