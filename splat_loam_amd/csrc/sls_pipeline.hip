@@ -411,14 +411,14 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         DirectBin db;
         if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1, !no_coarse);
         // (the direct binning reads the emission records only — not the rectangles, the tile counts, the depths or the
-        //  block boxes as arrays of their own; a one-round repair whose window sort rides in the preprocess launch
-        //  computes its keys itself: 32 bytes per surfel that are not written.  SLS_FULL_PREPROCESS=1: all of them, A/B)
+        //  block boxes as arrays of their own; a repair whose window sort rides in the preprocess launch computes its
+        //  keys itself: 32 bytes per surfel that are not written.  SLS_FULL_PREPROCESS=1: all of them, A/B)
         static const bool full_pre = getenv("SLS_FULL_PREPROCESS") && getenv("SLS_FULL_PREPROCESS")[0] == '1';
         const bool trim = direct && !full_pre;
         int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                        scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, trim ? nullptr : w.rect,
                                        trim ? nullptr : w.tiles, trim ? nullptr : w.depth,
-                                       (trim && merged_sort && cfg->reuse_depth_order == 1) ? nullptr : okeys, ovals, n_dev, st,
+                                       (trim && merged_sort) ? nullptr : okeys, ovals, n_dev, st,
                                        (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec,
                                        merged_sort ? order : nullptr,
                                        merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, trim ? nullptr : w.sbox, direct ? 1 : 0,

@@ -644,58 +644,78 @@ __global__ __launch_bounds__(kResortThreads) void resort_sort_kernel(int N, cons
     resort_sort_window((int)blockIdx.x, N, prev_order, [&](uint32_t g) { return keys_by_surfel[g]; }, comp, s_pairs);
 }
 
-// Second repair round, first half (reuse_depth_order = 2): after one round the array is sorted inside every
-// SHIFTED window, so an aligned window is again two sorted halves — merged here (10 stages instead of the 55
-// of a sort); followed by resort_merge_kernel once more.  Every round lets a surfel travel another window.
-__global__ __launch_bounds__(kResortThreads) void resort_merge_aligned_kernel(int N, const uint32_t *__restrict__ order,
-                                                                              const uint32_t *__restrict__ keys_by_surfel,
-                                                                              uint64_t *__restrict__ comp)
-{
-    __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
-    const int base = blockIdx.x * kResortWindow, o0 = 2 * (int)threadIdx.x;
-    uint64_t e[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pos = base + bitonic_src(o0 + q);
-        const uint32_t g = order[min(pos, N - 1)];
-        const uint32_t k = keys_by_surfel[g];
-        e[q] = pos < N ? (((uint64_t)k << 32) | g) : ~0ull;       // padding behind the end sorts last
-    }
-    bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
-    if (base + o0 < N) comp[base + o0] = e[0];
-    if (base + o0 + 1 < N) comp[base + o0 + 1] = e[1];
-}
-
 // window b covers positions [b*W - W/2, b*W + W/2): second half of sorted window b-1, first half of b
 // Also produces level 1 of the scan of tiles_touched (the sums of the four aligned 256-blocks a
 // window covers), which saves the gather_block_sums launch.
-template <bool DIRECT>
+// PRE (a further repair round in ONE launch): `comp` is sorted inside every SHIFTED window (the previous round wrote the
+// merged pairs back, comp_out), so the two aligned windows b-1 and b this window straddles are two sorted halves each:
+// the workgroup merges both itself (10 stages each instead of the 55 of a sort; every aligned window is merged by the
+// two workgroups that need it), hands them over in LDS and goes on with its own window — the second half of b-1, the
+// first of b.  Every round lets a surfel travel another window, at one dependent launch per round.
+// comp_out: the merged (key, surfel) pairs by position, for the round that follows (in place where !PRE: a workgroup
+// reads and writes its own window only; another buffer where PRE: the neighbours read what this one would overwrite).
+template <bool DIRECT, bool PRE>
 __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, const uint64_t *__restrict__ comp,
                                                                       uint32_t *__restrict__ order,
                                                                       uint64_t *__restrict__ edges,
                                                                       const uint32_t *__restrict__ tiles,
                                                                       uint32_t *__restrict__ block_sums, int GX,
-                                                                      const uint2 *__restrict__ erec_box, DirectBin db)
+                                                                      const uint2 *__restrict__ erec_box, DirectBin db,
+                                                                      uint64_t *comp_out)
 {
     // DIRECT: instead of level 1 of the scan, step 1 of the direct binning (above): the window is a chunk
     static_assert(kResortWindow == 1024 && kResortThreads == 512, "a 256-block of positions = two waves of pairs");
     __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
     __shared__ uint32_t s_part[4][2];          // [256-block of the window][wave inside it]
     __shared__ uint32_t s_hist[DIRECT ? kDirectMaxBins : 1];
+    __shared__ uint64_t s_win[PRE ? 2 * kResortWindow : 1];
     if (DIRECT) {
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) s_hist[d] = 0u;   // (the network's barriers come before its use)
     }
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2, o0 = 2 * (int)threadIdx.x;
     SLS_MT(0);
     uint64_t e[2];
+    if (PRE) {
+        uint64_t f[2][2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pos = base + bitonic_src(o0 + q);
-        const uint64_t c = comp[min(max(pos, 0), N - 1)];
-        e[q] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
+        for (int a = 0; a < 2; ++a) {
+            const int abase = ((int)blockIdx.x - 1 + a) * kResortWindow;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int pos = abase + bitonic_src(o0 + q);
+                const uint64_t c = comp[min(max(pos, 0), N - 1)];
+                f[a][q] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            bitonic_pairs<kResortWindow>(f[a][0], f[a][1], s_pairs);
+            s_win[a * kResortWindow + o0] = f[a][0];
+            s_win[a * kResortWindow + o0 + 1] = f[a][1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int o = bitonic_src(o0 + q);        // position inside this (shifted) window
+            e[q] = o < kResortWindow / 2 ? s_win[kResortWindow / 2 + o] : s_win[kResortWindow + o - kResortWindow / 2];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pos = base + bitonic_src(o0 + q);
+            const uint64_t c = comp[min(max(pos, 0), N - 1)];
+            e[q] = pos < 0 ? 0ull : (pos < N ? c : ~0ull);
+        }
     }
     bitonic_pairs<kResortWindow>(e[0], e[1], s_pairs);
     SLS_MT(1);
+    if (comp_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pos = base + o0 + q;
+            if (pos >= 0 && pos < N) comp_out[pos] = e[q];
+        }
+    }
     uint32_t v = 0;
     if (DIRECT) {
         uint2 er[2];
@@ -1208,7 +1228,8 @@ static int bits_for(uint32_t max_value)
 size_t order_scratch_bytes(int N)
 {
     const size_t n = (size_t)(N > 0 ? N : 1);
-    return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n) + 16;
+    // (+ the repair's second pair buffer behind its window edges inside the sort's scratch: 8 n + 16 (n / 1024 + 3) bytes)
+    return sizeof(uint32_t) * (3 * n + (n + 255) / 256 + 64) + sort_scratch_bytes(n) + 16 + n / 32 + 128;
 }
 
 // where preprocess may write the sort input directly (saves the depth_keys launch)
@@ -1275,24 +1296,28 @@ int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, ui
         }
         const DirectBin no_db = { nullptr, nullptr, nullptr, 0, 0, 0 };
         const bool count_here = direct != nullptr && handoff != nullptr;
-        // (the LAST merge counts: after it the order is final)
-#define SLS_MERGE(last_)                                                                                                     \
+        // the pairs of the rounds that follow ping-pong between comp and a second buffer behind the edges
+        uint64_t *comp2 = edges + 2 * (size_t)nB + 2;
+        // (the LAST merge counts: after it the order is final; every earlier one hands its merged pairs on)
+#define SLS_MERGE(PRE_, last_, in_, out_)                                                                                    \
         do {                                                                                                                 \
             if (count_here && (last_))                                                                                       \
-                hipLaunchKernelGGL(resort_merge_kernel<true>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
-                                   order, edges, tiles, block_sums, GX, (const uint2 *)erec_box, *direct);                                  \
+                hipLaunchKernelGGL((resort_merge_kernel<true, PRE_>), dim3(nB), dim3(kResortThreads), 0, st, N,               \
+                                   (const uint64_t *)(in_), order, edges, tiles, block_sums, GX, (const uint2 *)erec_box,      \
+                                   *direct, (uint64_t *)(out_));                                                              \
             else                                                                                                             \
-                hipLaunchKernelGGL(resort_merge_kernel<false>, dim3(nB), dim3(kResortThreads), 0, st, N, (const uint64_t *)comp, \
-                                   order, edges, tiles, block_sums, GX, (const uint2 *)erec_box, no_db);                                    \
+                hipLaunchKernelGGL((resort_merge_kernel<false, PRE_>), dim3(nB), dim3(kResortThreads), 0, st, N,              \
+                                   (const uint64_t *)(in_), order, edges, tiles, block_sums, GX, (const uint2 *)erec_box,      \
+                                   no_db, (uint64_t *)(out_));                                                                \
         } while (0)
-        SLS_MERGE(reuse_order <= 1);
+        SLS_MERGE(false, reuse_order <= 1, comp, reuse_order > 1 ? comp : nullptr);
         SLS_LAUNCH_CHECK("resort_merge_kernel");
+        uint64_t *cin = comp, *cout = comp2;
         for (int round = 1; round < reuse_order; ++round) {   // (reuse_order = 2: one more round, twice the reach)
-            hipLaunchKernelGGL(resort_merge_aligned_kernel, dim3(nA), dim3(kResortThreads), 0, st, N, (const uint32_t *)order,
-                               (const uint32_t *)keys, comp);
-            SLS_LAUNCH_CHECK("resort_merge_aligned_kernel");
-            SLS_MERGE(round + 1 == reuse_order);
-            SLS_LAUNCH_CHECK("resort_merge_kernel");
+            const bool last = round + 1 == reuse_order;
+            SLS_MERGE(true, last, cin, last ? nullptr : cout);
+            SLS_LAUNCH_CHECK("resort_merge_kernel (further round)");
+            uint64_t *t = cin; cin = cout; cout = t;
         }
 #undef SLS_MERGE
         if (count_here) {

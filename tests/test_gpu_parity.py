@@ -762,7 +762,7 @@ def test_depth_order_repair_rounds(device):
     assert amp is not None
     f = torch.tensor(1 + amp * noise, dtype=torch.float32, device=device)[:, None]
     engines = []
-    for rounds in (0, 1, 2):
+    for rounds in (0, 1, 2, 3, 4):      # (3, 4: the further rounds' pairs ping-pong between two buffers)
         m = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=str(device))
         e = MappingEngine(m, MappingConfig())
         e.reuse_depth_order = rounds > 0
@@ -778,7 +778,8 @@ def test_depth_order_repair_rounds(device):
     assert engines[0][0].stats["repeated_resort"] == 0
     assert engines[1][0].stats["repeated_resort"] == 1, "one round cannot reach: void + repeat with the full sort"
     assert engines[1][0]._repair_rounds == 2, "and the engine repairs with two rounds from then on"
-    assert engines[2][0].stats["repeated_resort"] == 0, "two rounds reach"
+    for k in (2, 3, 4):
+        assert engines[k][0].stats["repeated_resort"] == 0, "two (and more) rounds reach"
     for ls in losses[1:]:
         for a, b in zip(losses[0], ls):
             assert abs(a - b) <= 1e-5 * abs(a), losses
