@@ -242,7 +242,7 @@ typedef struct SlsMappingConfig {
     float lr_xyz, lr_opacity, lr_scaling, lr_rotation;
     int32_t apply_adam;   /* 0: gradients only (all-reduce them, then sls_adam_step) */
     int32_t reuse_depth_order; /* 0: sort from scratch.  2 (up to 4): as 1 with that many repair rounds, each of which
-                                * lets a surfel travel one more window of 1024 positions (+16 us per extra round).
+                                * lets a surfel travel one more window of 1024 positions (one more launch, +9 us, per extra round).
                                 * 1: the workspace still holds the depth order of the previous iteration on the
                                 * SAME keyframe and surfel set: repair it (windowed re-sort + verification)
                                 * instead of sorting from scratch.  If the repair does not reach the exact

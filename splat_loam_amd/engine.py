@@ -238,7 +238,7 @@ class MappingEngine:
         how many positions a surfel travels for the same change of depth grows with the number of surfels: measured
         at 500 k surfels (4 / 12 / 48; looser values fail repairs, each costs a void iteration + a rebuild) and at
         170 k / 50 k (12 / 32 / 200 without a failure, -1.5 % / -2.5 % per iteration with the mapper's keyframe
-        sampling), hence the scale with 500 k / N, capped at 3.  A repair round costs 14 us, the radix sort 90.
+        sampling), hence the scale with 500 k / N, capped at 3.  A further repair round costs 9 us, the radix sort 90.
         SLS_ORDER_AGE_ROUND2 / _ROUND3 / _ROUND4 / _EXTRA override."""
         scale = min(max(500000.0 / max(self.N, 1), 1.0), 3.0)
         env = os.environ.get
