@@ -788,6 +788,19 @@ def test_depth_order_repair_rounds(device):
         assert np.array_equal(e._orders[id(cam)][0].cpu().numpy(), o0)
 
 
+def test_depth_order_repair_at_awkward_sizes(device):
+    """tools/repair_fuzz.py: below one window, at window edges, odd counts — one to four repair rounds (the further
+    ones in one launch each, their pairs ping-ponging between two buffers), the loss stage inside the tile backward and
+    apart: under deterministic accumulation every configuration walks the SAME trajectory, orders and parameters bit
+    for bit."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "repair_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "repair_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(dev=str(device), verbose=False) == 0
+
+
 @pytest.mark.parametrize("fwd_variant,bwd_variant", [(2, 2), (2, 3), (3, 2), (3, 3)],
                          ids=["block4x4", "block4x4-fwd", "block4x4-bwd", "block8x2"])
 def test_tile_kernel_variants_agree_with_checker(device, oracle32, fwd_variant, bwd_variant):
