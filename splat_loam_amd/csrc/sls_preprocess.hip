@@ -157,23 +157,21 @@ struct RegArgs {
     int n_zero_words;         // counts, summed with atomics two kernels later): surfel thread i clears words i, i + N, ...
 };
 
-// EXACT (forward): the scales enter the extents of the tile rectangle — library expf for those.
+// The scales go through the library expf in BOTH directions: forward they enter the extents of the tile rectangle
+// (integers), and the regulariser's test `max(s) >= scaling_max` (slam/mapper.py:190-195) must come out the same in the
+// forward's loss value, in the backward's gradient and in torch's own exp — Mapper.densify clamps new scales AT
+// scaling_max (slam/mapper.py:113-117), so whole generations of surfels sit on that edge (golden G7: 2408 of 2453;
+// exp(log(0.1f)) is one ulp below 0.1f in the library, on it with the hardware exp2 — with the fast form here the backward
+// priced them all while the forward and the reference priced none).  `EXACT` is kept for the call sites' documentation.
 template <bool EXACT>
 __device__ __forceinline__ void activate(const RegArgs &ra, float2 &s, float4 &q, float &o)
 {
     if (!ra.raw) return;
     const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    float inv;
-    if (EXACT) {
-        s.x = expf(s.x); s.y = expf(s.y);
-        // (opacity and rotation reach float outputs only)
-        o = frcp(1.0f + __expf(-o));
-        inv = frcp(fmaxf(fsqrt(n2), 1e-12f));
-    } else {
-        s.x = __expf(s.x); s.y = __expf(s.y);
-        o = frcp(1.0f + __expf(-o));
-        inv = frcp(fmaxf(fsqrt(n2), 1e-12f));
-    }
+    s.x = expf(s.x); s.y = expf(s.y);
+    // (opacity and rotation reach float outputs only)
+    o = frcp(1.0f + __expf(-o));
+    const float inv = frcp(fmaxf(fsqrt(n2), 1e-12f));
     q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv;
 }
 

@@ -12,6 +12,9 @@ from . import _abi
 
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
+    from . import rasterizer
+    if rasterizer._PENDING_HOOK is not None:      # (SLS_FUSED_MAPPER=1: Mapper.densify calls this before the first optimize)
+        rasterizer._PENDING_HOOK()
     if not points.is_cuda:
         raise RuntimeError("distCUDA2 needs a ROCm device tensor (libsls_hip.so); there is no CPU fallback")
     lib = _abi.lib()

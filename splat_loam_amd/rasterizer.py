@@ -406,10 +406,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         return dmeans, None, dopac, dscales, drots, None, None
 
 
+# set by fused_mapper.maybe_install() while its run-time binding of Mapper.optimize waits for the class to exist
+# (SLS_FUSED_MAPPER=1; slam/mapper.py imports this module before its class statement runs); None otherwise
+_PENDING_HOOK = None
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
+        if _PENDING_HOOK is not None:
+            _PENDING_HOOK()
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         _need_cuda(positions, "positions")

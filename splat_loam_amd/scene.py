@@ -81,6 +81,43 @@ class SurfelModel:
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    # -- the surfel set changes between keyframes (Mapper.densify / Mapper.prune) ---------------------------------
+    _GROUP_ATTR = {"xyz": "_xyz", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
+
+    def _replace_parameters(self, make_new, carry_state) -> None:
+        """Every group's tensor is replaced by `make_new(name, old)`; `carry_state(old_state, new_param)` returns the
+        Adam state the new tensor starts with (None: none — the optimizer initialises it lazily at step 0)."""
+        for group in (self.optimizer.param_groups if self.optimizer is not None else
+                      [{"name": n, "params": [getattr(self, a)]} for n, a in self._GROUP_ATTR.items()]):
+            old = group["params"][0]
+            new = nn.Parameter(make_new(group["name"], old.detach()).contiguous().requires_grad_(True))
+            if self.optimizer is not None:
+                state = self.optimizer.state.pop(old, None)
+                kept = carry_state(state, new) if state else None
+                if kept is not None:
+                    self.optimizer.state[new] = kept
+                group["params"][0] = new
+            setattr(self, self._GROUP_ATTR[group["name"]], new)
+
+    def densification_postfix(self, new_xyz, new_opacity, new_scaling, new_rotation) -> None:
+        """Appends surfels (scene/gaussian_model.py:258-316, `cat_tensors_to_optimizer`): a parameter that has Adam
+        moments keeps them, the new rows' moments start at zero, the step count goes on."""
+        extra = {"xyz": new_xyz, "opacity": new_opacity, "scaling": new_scaling, "rotation": new_rotation}
+
+        def carry(state, new):
+            pad = lambda m: torch.cat((m, torch.zeros((new.shape[0] - m.shape[0],) + tuple(m.shape[1:]), dtype=m.dtype,
+                                                      device=m.device)))
+            return {"step": state["step"], "exp_avg": pad(state["exp_avg"]), "exp_avg_sq": pad(state["exp_avg_sq"])}
+        self._replace_parameters(lambda name, old: torch.cat((old, extra[name].to(old))), carry)
+
+    def prune_points(self, mask: torch.Tensor) -> None:
+        """Removes the surfels marked in `mask` (scene/gaussian_model.py:237-256, 258-265).  The Adam state does NOT
+        survive: the reference's `_prune_optimizer` files the new parameter's state under the group's NAME, where
+        torch.optim.Adam never looks, so every prune — i.e. every keyframe's `update_model` — restarts Adam at step 0
+        with zero moments (golden G7 pins this through the parameter trajectories)."""
+        keep = ~mask.reshape(-1).bool()
+        self._replace_parameters(lambda name, old: old[keep], lambda state, new: None)
+
     def training_setup(self, position_lr=5e-4, opacity_lr=5e-2, scaling_lr=5e-3, rotation_lr=1e-3, fused=True):
         """4 groups, eps 1e-15 (scene/gaussian_model.py:97-121; lrs utils/config_utils.py:180-183)."""
         groups = [

@@ -15,6 +15,10 @@ G3  build_rotation / inverse_sigmoid / matrix_to_quaternion /
 G5  Mapper.optimize (slam/mapper.py:140-214) for 3 Adam iterations with the
     reference's GaussianModel.training_setup, on top of the CPU checker injected
     as `diff_surfel_spherical_rasterization` -> parameter trajectories
+G7  Mapper.update_model stage by stage (slam/mapper.py:33-47: densify -> optimize -> prune) over THREE keyframes of a
+    ray-cast room, 21 iterations each, on the CPU checker, with `distCUDA2` = a brute-force 3-NN: inputs, the
+    rendered alpha the densification looks at, the drawn pixels, the drawn keyframes, the surfel set after every
+    stage.  Replayed by tests/test_fused_mapper.py (CPU: the cold stages; GPU: the whole thing on MappingEngine).
 """
 import os
 import sys
@@ -30,6 +34,14 @@ sys.path.insert(0, REF)
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def brute_force_dist2(points):
+    """simple-knn's contract (slam/mapper.py:113-115): per point the mean squared distance to its 3 nearest others"""
+    p = points.detach().double()
+    d2 = torch.cdist(p, p) ** 2
+    d2.fill_diagonal_(float("inf"))
+    return d2.topk(3, dim=1, largest=False).values.mean(dim=1).float()
+
+
 def install_stubs():
     from oracle import torch_function as tf
     m = types.ModuleType("diff_surfel_spherical_rasterization")
@@ -38,7 +50,7 @@ def install_stubs():
     sys.modules["diff_surfel_spherical_rasterization"] = m
     knn = types.ModuleType("simple_knn")
     knn_c = types.ModuleType("simple_knn._C")
-    knn_c.distCUDA2 = lambda x: (_ for _ in ()).throw(RuntimeError("not used"))
+    knn_c.distCUDA2 = brute_force_dist2
     sys.modules["simple_knn"], sys.modules["simple_knn._C"] = knn, knn_c
     gs = types.ModuleType("gsaligner")
 
@@ -249,11 +261,104 @@ def g6():
     np.savez_compressed(os.path.join(OUT, "g6_slam_rules.npz"), **out)
 
 
+class _Recorder:
+    """stands in for Mapper.data_logger: keeps the one image densify() logs — the drawn pixels (slam/mapper.py:97)"""
+    def __init__(self):
+        self.images = {}
+
+    def log_image(self, name, img):
+        self.images[name] = img.clone()
+
+    def __getattr__(self, _):
+        return lambda *a, **k: None
+
+
+def g7():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gaussian_renderer
+    from test_aligner import pose_of, room_scan
+    from scene.cameras import Camera
+    from scene.frame import Frame
+    from slam.local_model import LocalModel
+    from slam.mapper import Mapper
+    from utils.config_utils import Configuration
+    from splat_loam_amd import slam_rules, synth
+    H, W, n_kf = 32, 256, 3
+    K = synth.spherical_K(H, W)
+    cfg = Configuration()
+    cfg.device = "cpu"
+    cfg.logging.enable = False
+    m = cfg.mapping                                        # configs/kitti/kitti-00-odom.yaml, fewer iterations
+    m.num_iterations = 20                                  # the loop runs num_iterations + 1 = 21 times
+    m.densify_threshold_egeom, m.densify_threshold_opacity, m.densify_percentage = -1.0, 0.2, 0.3
+    m.prob_view_last_keyframe = 0.4                        # (kitti.yaml's; kitti-00 draws uniformly)
+    m.pruning_min_opacity, m.pruning_min_size = 0.0, 0.0   # (the opacity threshold is set per keyframe below)
+    m.opt_lambda_alpha, m.opt_lambda_normal, m.opt_scaling_max, m.opt_scaling_max_penalty = 0.4, 0.5, 0.1, 1.0
+    cfg.opt.depth_ratio = 0.0
+    lm = LocalModel(cfg)                                   # GaussianModel("cpu") + training_setup(cfg)
+    gm = lm.get_gmodel
+    mapper = Mapper(cfg)
+    mapper.register_model(lm)
+    rec = mapper.data_logger = _Recorder()
+    snap = lambda: np.concatenate([getattr(gm, a).detach().numpy().reshape(gm._xyz.shape[0], -1)
+                                   for a in ("_xyz", "_opacity", "_scaling", "_rotation")], axis=1).astype(np.float32)
+    out = {"K": K, "H": H, "W": W, "n_keyframes": n_kf, "num_iterations": m.num_iterations,
+           "lr": np.array([cfg.opt.position_lr, cfg.opt.opacity_lr, cfg.opt.scaling_lr, cfg.opt.rotation_lr]),
+           "cfg": np.array([m.densify_threshold_opacity, m.densify_percentage, m.prob_view_last_keyframe,
+                            m.opt_lambda_alpha, m.opt_lambda_normal, m.opt_scaling_max, m.opt_scaling_max_penalty])}
+    torch.manual_seed(7)
+    for k in range(n_kf):
+        pose = pose_of([0.45 * k, 0.10 * k, 0.0], yaw_deg=4.0 * k).astype(np.float32)
+        depth, pts = room_scan(K.astype(np.float64), H, W, pose.astype(np.float64))
+        valid = (depth > 0.5)
+        valid[:2, 10 * k:10 * k + 7] = False                # a few pixels without a measurement
+        depth = np.where(valid, depth, 0.0).astype(np.float32)
+        normal = np.where(valid[..., None], -pts / np.maximum(np.linalg.norm(pts, axis=-1, keepdims=True), 1e-9), 0.0)
+        normal = np.ascontiguousarray(normal.transpose(2, 0, 1), np.float32)     # scene/preprocessing.py:112: -unit(point)
+        cam = Camera(K, depth[None], normal, valid[None].astype(np.uint8), world_T_lidar=pose, data_device="cpu")
+        frame = Frame(cam, float(k), "cpu", model_T_frame=pose)
+        lm.insert_keyframe(frame)
+        tag = f"_k{k}"
+        out.update({"pose" + tag: pose, "depth" + tag: depth[None], "normal" + tag: normal,
+                    "valid" + tag: valid[None].astype(np.uint8)})
+        if k > 0:     # what densify() looks at (slam/mapper.py:52-61), rendered by the reference's render() just before
+            with torch.no_grad():
+                out["alpha" + tag] = gaussian_renderer.render(cam, gm, cfg.opt.depth_ratio)["rend_alpha"].numpy().copy()
+        mapper.densify(frame, initialize_model=(k == 0))
+        out["drawn" + tag] = rec.images["frame/densify_mask"].numpy().astype(bool)
+        out["added" + tag] = snap()[-int(out["drawn" + tag].sum()):]      # (the rows in front = the set after the last prune)
+        np.random.seed(100 + k)
+        mapper.optimize()
+        np.random.seed(100 + k)      # the same draws once more, for the record (np.random.choice over n consumes the same stream)
+        p = slam_rules.keyframe_probabilities(k + 1, m.prob_view_last_keyframe)
+        out["kf_draws" + tag] = np.array([np.random.choice(k + 1, p=p) for _ in range(m.num_iterations + 1)])
+        out["after_optimize" + tag] = snap()
+        # prune below an opacity threshold placed in the widest gap of the opacities between 0.80 and 0.88, so that the
+        # decision does not hang on the last bits of a trajectory
+        op = np.sort(gm.get_opacity.detach().numpy().reshape(-1))
+        band = op[(op > 0.80) & (op < 0.88)]
+        gaps = np.diff(band)
+        j = int(np.argmax(gaps))
+        m.pruning_min_opacity = float(0.5 * (band[j] + band[j + 1]))
+        out["prune_threshold" + tag] = np.float64(m.pruning_min_opacity)
+        out["prune_margin" + tag] = np.float64(0.5 * gaps[j])
+        before = gm.get_opacity.detach().numpy().reshape(-1)
+        mapper.prune()
+        out["pruned" + tag] = before < np.float32(m.pruning_min_opacity)
+        assert np.array_equal(snap(), out["after_optimize" + tag][~out["pruned" + tag]])     # (so it is not stored)
+        states = [gm.optimizer.state.get(g["params"][0]) for g in gm.optimizer.param_groups]
+        assert all(s is None or len(s) == 0 for s in states), "the prune leaves the new parameters without Adam state"
+        print(f"  keyframe {k}: +{int(out['drawn' + tag].sum())} -> {out['after_optimize' + tag].shape[0]} surfels, "
+              f"pruned {int(out['pruned' + tag].sum())} below {m.pruning_min_opacity:.5f} (margin {out['prune_margin' + tag]:.1e}), "
+              f"draws {out['kf_draws' + tag].tolist()}")
+    np.savez_compressed(os.path.join(OUT, "g7_update_model.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
     for name in which:
         globals()[name]()
         print("wrote", name)
