@@ -47,6 +47,7 @@ extern "C" {
 #define SLS_E_ARG (-1)      /* bad argument (null pointer, negative size, ...) */
 #define SLS_E_HIP (-2)      /* a HIP runtime call or kernel launch failed      */
 #define SLS_E_SCRATCH (-3)  /* scratch buffer too small                         */
+#define SLS_E_UNSUPPORTED (-4) /* this entry point does not serve the configuration: use the one it names */
 
 /* Camera of one LiDAR keyframe.  Filled by sls_camera_from_matrices from the
  * two matrices the reference passes in GaussianRasterizationSettings
@@ -204,6 +205,40 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R,
                      float *dL_dmeans3D, float *dL_dscales, float *dL_drotations, float *dL_dopacities,
                      const uint64_t *block_masks, int block_masks_shape, void *det_scratch, size_t det_scratch_bytes,
                      void *stream);
+
+/* ---- forward / backward in ONE call each, against a capacity (no host read of R) ---------------------------
+ * What `GaussianRasterizer` runs by default (gaussian_renderer/__init__.py:26,40-47; slam/mapper.py:201): the kernels
+ * of sls_mapping_step behind the staged interface's contract.  The instance buffers are sized for `R_capacity` (the
+ * caller's guess: last call's R with head room); the status block (R, bit 0 of `overflow`: capacity too small, bit 1:
+ * the repaired depth order was not exact) reaches `status_mirror` (pinned HOST memory, optional) from a launch of its
+ * own between the binning and the tile forward, words 0..6 before word 7: the caller arms words 0 and 7 with a value
+ * the device never writes (0xFFFFFFFF) and polls them while the tile forward runs; a non-zero `overflow` means the
+ * outputs are void — repeat with more room resp. with reuse_rounds = 0.
+ * depth_order (N uint32, caller-kept PER CAMERA, may be null with reuse_rounds = 0): receives the depth order;
+ * reuse_rounds 1..4 repairs the order found there (from this camera's previous call) instead of sorting from scratch
+ * — verified exact on the device, bit 1 otherwise.  list_pairs as in stage 2.
+ * workspace: sls_forward_ws_bytes(N, H, W, R_capacity) bytes, 256-byte aligned, alive until the backward has run;
+ * workspace_ready = 0 on its first use (a region of it must start from zero; forward and backward leave it so).
+ * radii (N int32), allmap (7*H*W floats): tensors of the caller's own.  *sorted_list / *sorted_stride /
+ * *block_masks_shape: what sls_backward_ws wants back (pointers into the workspace).
+ * Serves what the direct binning serves (<= 512 tiles, images the block boxes describe, D10 off): otherwise
+ * SLS_E_UNSUPPORTED, and the staged forward is the way. */
+struct SlsMappingStatus;
+size_t sls_forward_ws_bytes(int N, int H, int W, uint64_t R_capacity);
+int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
+                   const float *opacities, const float *col_cs, const float *row_cs, uint64_t R_capacity,
+                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int32_t *radii,
+                   float *allmap, void *workspace, size_t workspace_bytes, struct SlsMappingStatus *status_dev,
+                   struct SlsMappingStatus *status_mirror, const uint32_t **sorted_list, int *sorted_stride,
+                   int *block_masks_shape, void *stream);
+/* The backward of that forward: tile backward (it marks the surfels it reaches) + the projection's backward, which
+ * reads — and clears — only the marked surfels' gradient records: no 64 N-byte memset per call.  Float atomics
+ * (sls_backward_det on the staged buffers is the bit-reproducible alternative). */
+int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
+                    const int32_t *radii, const float *col_cs, const float *row_cs, const float *dL_dallmap,
+                    uint64_t R_capacity, void *workspace, size_t workspace_bytes, const uint32_t *sorted_list,
+                    int sorted_stride, int block_masks_shape, float *dL_dmeans3D, float *dL_dscales,
+                    float *dL_drotations, float *dL_dopacities, void *stream);
 
 /* ---- fused consumer of allmap: render() post-processing + mapper loss ------
  * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of

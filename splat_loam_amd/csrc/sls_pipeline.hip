@@ -312,6 +312,121 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
                                  dL_dscales, dL_drotations, dL_dopacities, st, &fuse);
 }
 
+// ---- the drop-in forward without the host read of R --------------------------------------------------------------
+// A tiny launch between the binning and the tile forward: the status block (R, void bits) into pinned host memory, so
+// that the host knows whether the capacity sufficed while the tile forward is still running.
+__global__ void status_mirror_kernel(const uint32_t *status, uint32_t *mirror)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) mirror_status_block(status, mirror);
+}
+
+size_t sls_forward_ws_bytes(int N, int H, int W, uint64_t R_capacity)
+{
+    if (N < 0 || H <= 0 || W <= 0) return 0;
+    return carve(N, H, W, R_capacity, nullptr, false).total;
+}
+
+int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
+                   const float *opacities, const float *col_cs, const float *row_cs, uint64_t R_capacity,
+                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int32_t *radii,
+                   float *allmap, void *workspace, size_t workspace_bytes, SlsMappingStatus *status_dev,
+                   SlsMappingStatus *status_mirror, const uint32_t **sorted_list, int *sorted_stride,
+                   int *block_masks_shape, void *stream)
+{
+    SLS_REQUIRE(cam && status_dev && workspace && sorted_list && sorted_stride && block_masks_shape, "null pointer");
+    SLS_REQUIRE(N > 0, "N must be positive");
+    SLS_REQUIRE(means3D && scales && rotations && opacities && col_cs && row_cs && radii && allmap, "null pointer");
+    SLS_REQUIRE(R_capacity > 0 && R_capacity < (1ull << 32), "bad instance capacity");
+    SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    SLS_REQUIRE(reuse_rounds >= 0 && reuse_rounds <= 4, "reuse_rounds: 0 from scratch, 1..4 repair rounds");
+    SLS_REQUIRE(reuse_rounds == 0 || depth_order, "a repair needs the camera's previous depth order");
+    SLS_REQUIRE(list_pairs >= 0 && list_pairs <= 2, "list_pairs: 0 auto, 1 whenever possible, 2 never");
+    const int H = cam->H, W = cam->W;
+    const DevCam dc = make_devcam(*cam);
+    const uint32_t cap = (uint32_t)R_capacity;
+    if (!bin_direct_possible(dc, N, cap) || debug_state().fwd_variant != 3 || debug_state().bwd_variant != 3) {
+        set_error("sls_forward_ws serves what the direct binning serves (<= 512 tiles, D10 off, default tile kernels): use the staged forward");
+        return SLS_E_UNSUPPORTED;
+    }
+    const MapWs w = carve(N, H, W, R_capacity, workspace, false);
+    if (workspace_bytes < w.total) {
+        set_error("forward workspace too small: %zu < %zu", workspace_bytes, w.total);
+        return SLS_E_SCRATCH;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (!workspace_ready) {     // the gradient records and the touched marks start from zero; the backward leaves them so
+        ScopedTimer tm(T_GREC_MEMSET, st);
+        SLS_HIP_CHECK(hipMemsetAsync(w.reg_accum, 0, w.zero_bytes, st));
+    }
+    uint32_t *okeys, *ovals, *n_dev;
+    uint32_t *order = depth_order ? depth_order : w.order;
+    depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
+    static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
+    const bool merged_sort = reuse_rounds >= 1 && !no_merge;
+    DirectBin db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, reuse_rounds >= 1, true);
+    // (as in sls_mapping_step: the direct binning reads the emission records only)
+    int rc = launch_preprocess_fwd(dc, 0, 0.0f, 0.0f, nullptr, N, means3D, scales, rotations, opacities, w.rec, radii,
+                                   nullptr, nullptr, nullptr, merged_sort ? nullptr : okeys, ovals, n_dev, st,
+                                   (uint32_t *)status_dev, col_cs, row_cs, w.tmask, w.erec, merged_sort ? order : nullptr,
+                                   merged_sort ? resort_comp_buffer(N, w.order_scratch) : nullptr, nullptr, 1, db.coarse,
+                                   (int)direct_coarse_words(dc, N));
+    if (rc) return rc;
+    ScanHandoff handoff = { nullptr, 0, nullptr, 0 };
+    rc = launch_depth_order_scan(N, w.depth, w.tiles, order, w.offsets, &status_dev->R, w.order_scratch,
+                                 w.order_scratch_bytes, 1, st, reuse_rounds, &status_dev->overflow, &handoff, merged_sort,
+                                 &db, (const int4 *)w.erec, dc.GX);
+    if (rc) return rc;
+    const uint2 *bmask = nullptr;
+    rc = launch_bin_direct(dc, N, cap, db, handoff.counted != 0, order, w.erec, nullptr, nullptr, w.sort_scratch, w.vals,
+                           w.ranges, &status_dev->R, &status_dev->overflow, handoff.resort_windows, handoff.resort_edges,
+                           &bmask, list_pairs, st);
+    if (rc) return rc;
+    if (status_mirror) {
+        hipLaunchKernelGGL(status_mirror_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)status_dev, (uint32_t *)status_mirror);
+        SLS_LAUNCH_CHECK("status_mirror_kernel");
+    }
+    const uint32_t *list = bmask ? (const uint32_t *)bmask : w.vals;
+    *sorted_list = list;
+    *sorted_stride = bmask ? 2 : 1;
+    *block_masks_shape = (int)debug_state().fwd_variant;
+    return launch_render_fwd(dc, w.ranges, list, w.rec, col_cs, row_cs, allmap, w.pix_state, w.pix_contrib, nullptr, st,
+                             true, w.block_masks, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, bmask, true);
+}
+
+int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
+                    const int32_t *radii, const float *col_cs, const float *row_cs, const float *dL_dallmap,
+                    uint64_t R_capacity, void *workspace, size_t workspace_bytes, const uint32_t *sorted_list,
+                    int sorted_stride, int block_masks_shape, float *dL_dmeans3D, float *dL_dscales,
+                    float *dL_drotations, float *dL_dopacities, void *stream)
+{
+    SLS_REQUIRE(cam && workspace && sorted_list, "null pointer");
+    SLS_REQUIRE(N > 0, "N must be positive");
+    SLS_REQUIRE(means3D && scales && rotations && radii && col_cs && row_cs && dL_dallmap && dL_dmeans3D && dL_dscales &&
+                    dL_drotations && dL_dopacities,
+                "null pointer");
+    SLS_REQUIRE(sorted_stride == 1 || sorted_stride == 2, "sorted_stride: 1 (plain list) or 2 ((surfel, block mask) pairs)");
+    const MapWs w = carve(N, cam->H, cam->W, R_capacity, workspace, false);
+    if (workspace_bytes < w.total) {
+        set_error("forward workspace too small: %zu < %zu", workspace_bytes, w.total);
+        return SLS_E_SCRATCH;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const DevCam dc = make_devcam(*cam);
+    // the tile backward marks the surfels it reaches; the projection's backward reads — and clears — only their records:
+    // no 64 N-byte memset per call
+    int rc = launch_render_bwd(dc, w.ranges, sorted_list, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, dL_dallmap,
+                               w.grec, st, block_masks_shape ? w.block_masks : nullptr,
+                               (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, w.touched, nullptr, nullptr, nullptr, nullptr,
+                               sorted_stride, block_masks_shape, true);
+    if (rc) return rc;
+    AdamFuse fuse;
+    memset(&fuse, 0, sizeof(fuse));
+    fuse.clear_grec = 1;
+    fuse.touched = w.touched;
+    return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, w.grec, dL_dmeans3D,
+                                 dL_dscales, dL_drotations, dL_dopacities, st, &fuse);
+}
+
 size_t sls_mapping_workspace_bytes(int N, int H, int W, uint64_t R_capacity)
 {
     if (N < 0 || H <= 0 || W <= 0) return 0;

@@ -310,9 +310,10 @@ def _list_and_keys(s: ForwardState, T: int) -> None:
 
 
 def deterministic_mode() -> bool:
-    """SLS_DETERMINISTIC=1: gradient records are accumulated with integer atomics (bit-identical gradients from
-    run to run, about one extra tile-backward); default: float atomics, whose order changes between runs."""
-    return os.environ.get("SLS_DETERMINISTIC", "0") == "1"
+    """SLS_DETERMINISTIC=1 or 2: gradient records are accumulated with integer atomics (bit-identical gradients from
+    run to run, about one extra tile-backward; the staged interface has the two-launch scheme only, so 2 — MappingEngine's
+    one-launch scheme — means 1 here); default: float atomics, whose order changes between runs."""
+    return os.environ.get("SLS_DETERMINISTIC", "0") in ("1", "2")
 
 
 def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallmap, deterministic=None):
@@ -344,6 +345,191 @@ def rasterize_backward(state: ForwardState, means3D, scales, rotations, dL_dallm
                                 state.block_masks_shape, _stream(dev)),
                "sls_backward")
     return out.view("dmeans"), out.view("dscales"), out.view("drots"), out.view("dopac"), out.view("grec")
+
+
+# ---------------------------------------------------------------------------
+# The default path of GaussianRasterizer: sls_forward_ws / sls_backward_ws — one native call each, sized by a capacity
+# instead of a host read of R in the middle of the forward, the camera's previous depth order repaired instead of
+# sorted anew, gradient records cleared where they are read.  Same kernels as sls_mapping_step; same results as the
+# staged calls (tests/test_gpu_parity.py::test_workspace_path_matches_staged_path).
+# ---------------------------------------------------------------------------
+class _WsEntry:
+    """Per (device, N, H, W, flags): one workspace, the status block + its pinned mirror, the capacity guess; per
+    camera (the matrix-cache key): the depth order of its last call."""
+    __slots__ = ("ws", "ws_ptr", "ws_bytes", "cap", "ready", "busy", "status", "mirror", "mirror_np", "orders", "calls",
+                 "rounds", "rounds_until", "stats")
+
+
+_WS_CACHE: "OrderedDict[tuple, _WsEntry]" = OrderedDict()
+_WS_CACHE_MAX = 4
+_WS_ORDERS_MAX = 64
+_SENTINEL = -1          # 0xFFFFFFFF as int32: the device never writes it into words 0 and 7 of the status block
+
+
+def workspace_path_enabled() -> bool:
+    """SLS_STAGED_FORWARD=1: GaussianRasterizer goes through sls_forward_stage1/2 + sls_backward (A/B runs, and what
+    callers of rasterize_forward() — the tests — look at buffer by buffer)."""
+    return os.environ.get("SLS_STAGED_FORWARD", "0") != "1"
+
+
+def _ws_entry(dev, N, H, W, lean) -> _WsEntry:
+    key = (str(dev), N, H, W, bool(lean))
+    e = _WS_CACHE.get(key)
+    if e is not None:
+        _WS_CACHE.move_to_end(key)
+        return e
+    e = _WsEntry()
+    e.ws, e.cap, e.ready, e.busy = None, 0, False, False
+    e.status = torch.zeros((8,), dtype=torch.int32, device=dev)
+    e.mirror = torch.zeros((8,), dtype=torch.int32).pin_memory()
+    e.mirror_np = e.mirror.numpy()
+    e.orders, e.calls, e.rounds, e.rounds_until = OrderedDict(), 0, 1, 0
+    e.stats = {"too_small": 0, "repair_failed": 0, "from_scratch": 0, "repaired": 0}
+    # (the surfel set changed — Mapper.densify / prune between keyframes: the old size's workspace will not be asked
+    #  for again; one still held by a forward awaiting its backward stays until that has run)
+    for old in [k for k, v in _WS_CACHE.items() if k[0] == key[0] and k[2:] == key[2:] and k[1] != N and not v.busy]:
+        del _WS_CACHE[old]
+    _WS_CACHE[key] = e
+    while len(_WS_CACHE) > _WS_CACHE_MAX:
+        _WS_CACHE.popitem(last=False)
+    return e
+
+
+def _ws_alloc(e: _WsEntry, dev, N, H, W, cap) -> None:
+    nbytes = int(_abi.lib().sls_forward_ws_bytes(N, H, W, cap))
+    e.ws = None
+    e.ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=dev)
+    e.ws_ptr = (e.ws.data_ptr() + 255) & ~255
+    e.ws_bytes, e.cap, e.ready = nbytes, int(cap), False
+
+
+class WsState:
+    """What the backward needs from a workspace forward (the buffers themselves live in the entry's workspace)."""
+    __slots__ = ("cam", "entry", "N", "R", "cap", "radii", "allmap", "list_ptr", "stride", "shape", "ws", "ws_ptr", "ws_bytes")
+
+
+def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
+                         keep_for_backward: bool = True) -> Optional[WsState]:
+    """Returns None where sls_forward_ws does not apply (more than 512 tiles, D10 on, the workspace of this size still
+    held by a forward whose backward has not run): the caller takes the staged path."""
+    lib = _abi.lib()
+    dev = means3D.device
+    N = int(means3D.shape[0])
+    if N == 0:
+        return None
+    ce = get_camera(settings, dev)
+    cam = ce.cam
+    H, W = cam.H, cam.W
+    tw, th = _abi.tile_size()
+    T = ((W + tw - 1) // tw) * ((H + th - 1) // th)
+    if T > 512 or cam.tile_cull_min >= 2:
+        return None
+    e = _ws_entry(dev, N, H, W, bool(cam.flags & 1))
+    if e.busy:
+        return None
+    st = _stream(dev)
+    if e.ws is None:
+        _ws_alloc(e, dev, N, H, W, max(4 * N, 1 << 16))
+    # the camera's previous depth order (the matrix cache's key says "same camera"): repaired while young enough, with
+    # MappingEngine's ages (a repair that does not reach the exact order voids the forward, which is then repeated
+    # from scratch — the caller never sees an inexact list)
+    okey = id(ce)
+    ent = e.orders.get(okey)
+    if ent is None or ent[2] is not ce:
+        ent = [torch.empty((N,), dtype=torch.int32, device=dev), None, ce]
+        e.orders[okey] = ent
+        while len(e.orders) > _WS_ORDERS_MAX:
+            e.orders.popitem(last=False)
+    else:
+        e.orders.move_to_end(okey)
+    scale = min(max(500000.0 / N, 1.0), 3.0)
+    age = None if ent[1] is None else e.calls - ent[1]
+    if e.rounds > 1 and e.calls >= e.rounds_until:
+        e.rounds, e.rounds_until = e.rounds - 1, e.calls + 256
+    reuse = 0
+    if age is not None and age <= int(48 * scale) and os.environ.get("SLS_NO_ORDER_REUSE", "0") != "1":
+        reuse = min(e.rounds + (1 if age > int(4 * scale) else 0) + (1 if age > int(12 * scale) else 0), 4)
+    radii = torch.empty((N,), dtype=torch.int32, device=dev)
+    allmap = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+    lst, stride, shape = C.c_void_p(0), C.c_int(1), C.c_int(0)
+    row = e.mirror_np
+    while True:
+        row[0] = _SENTINEL
+        row[7] = _SENTINEL
+        rc = lib.sls_forward_ws(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
+                                opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), e.cap,
+                                ent[0].data_ptr(), reuse, list_pairs_mode(), 1 if e.ready else 0, radii.data_ptr(),
+                                allmap.data_ptr(), e.ws_ptr, e.ws_bytes, e.status.data_ptr(), e.mirror.data_ptr(),
+                                C.byref(lst), C.byref(stride), C.byref(shape), st)
+        if rc == -4:                      # SLS_E_UNSUPPORTED
+            return None
+        _abi.check(rc, "sls_forward_ws")
+        e.ready = True
+        spins = 0
+        while row[7] == _SENTINEL or row[0] == _SENTINEL:       # (the tile forward is running meanwhile)
+            spins += 1
+            if spins > 2_000_000:
+                torch.cuda.current_stream(dev).synchronize()
+                if row[7] == _SENTINEL or row[0] == _SENTINEL:
+                    raise RuntimeError("the forward's status never reached its host mirror")
+        R, flags = int(row[0]) & 0xFFFFFFFF, int(row[1])
+        if flags == 0:
+            break
+        if flags & 1:                     # capacity too small: more room (the old workspace drains on the stream first)
+            e.stats["too_small"] += 1
+            _ws_alloc(e, dev, N, H, W, int(R * 1.3) + 1024)
+        if flags & 2:                     # the repair did not reach the exact order: from scratch, and one more round for a while
+            e.stats["repair_failed"] += 1
+            e.rounds, e.rounds_until = min(e.rounds + 1, 3), e.calls + 256
+        reuse = 0
+    e.stats["repaired" if reuse else "from_scratch"] += 1
+    e.stats["R"] = R
+    e.calls += 1
+    ent[1] = e.calls
+    if settings.debug:
+        torch.cuda.synchronize(dev)
+    s = WsState()
+    s.cam, s.entry, s.N, s.R, s.cap, s.radii, s.allmap = ce, e, N, R, e.cap, radii, allmap
+    s.list_ptr, s.stride, s.shape = int(lst.value), int(stride.value), int(shape.value)
+    s.ws, s.ws_ptr, s.ws_bytes = e.ws, e.ws_ptr, e.ws_bytes
+    if keep_for_backward:
+        e.busy = True                     # released by the backward (or when the autograd node dies without one)
+    return s
+
+
+def rasterize_backward_ws(state: WsState, means3D, scales, rotations, dL_dallmap):
+    lib = _abi.lib()
+    dev = means3D.device
+    N, ce = state.N, state.cam
+    dL = _f32c(dL_dallmap)
+    out = _Arena(dev, (("dmeans", "f32", (N, 3)), ("dscales", "f32", (N, 2)), ("drots", "f32", (N, 4)), ("dopac", "f32", (N, 1))))
+    try:
+        _abi.check(lib.sls_backward_ws(C.byref(ce.cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
+                                       state.radii.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), dL.data_ptr(),
+                                       state.cap, state.ws_ptr, state.ws_bytes, state.list_ptr, state.stride, state.shape,
+                                       out.ptr("dmeans"), out.ptr("dscales"), out.ptr("drots"), out.ptr("dopac"),
+                                       _stream(dev)), "sls_backward_ws")
+    except Exception:
+        state.entry.ready = False         # (whatever state the records are in: the next forward clears them)
+        raise
+    return out.view("dmeans"), out.view("dscales"), out.view("drots"), out.view("dopac")
+
+
+class _WsLease:
+    """Held by the autograd context of a workspace forward: gives the workspace back when the backward has run — or when
+    the graph is dropped without one (render() under no_grad never takes a lease)."""
+    __slots__ = ("state",)
+
+    def __init__(self, state):
+        self.state = state
+
+    def release(self):
+        st, self.state = self.state, None
+        if st is not None and st.entry.ws is st.ws:
+            st.entry.busy = False
+
+    def __del__(self):
+        self.release()
 
 
 def frame_from_precomp(cov3D_precomp: torch.Tensor):
@@ -385,9 +571,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         if scales is None or rotations is None:
             raise ValueError("scales and rotations are required")
         m, o, s_, r = map(_f32c, (means3D.detach(), opacities.detach(), scales.detach(), rotations.detach()))
-        st = rasterize_forward(raster_settings, m, o, s_, r)
-        ctx.state = st
+        for name, t in (("means3D", m), ("opacities", o), ("scales", s_), ("rotations", r)):
+            _need_cuda(t, name)
+        if m.shape != (m.shape[0], 3) or s_.shape != (m.shape[0], 2) or r.shape != (m.shape[0], 4) or o.numel() != m.shape[0]:
+            raise ValueError("expected means3D (N,3), scales (N,2), rotations (N,4), opacities (N,1)")
+        needs_grad = any(ctx.needs_input_grad[:5])
         ctx.debug = bool(raster_settings.debug)
+        ctx.lease = None
+        st = None
+        # default: one native call against a capacity (sls_forward_ws); the staged calls where that does not apply, for
+        # the deterministic accumulation (sls_backward_det works on the staged buffers) and with SLS_STAGED_FORWARD=1
+        if workspace_path_enabled() and not (needs_grad and deterministic_mode()):
+            st = rasterize_forward_ws(raster_settings, m, o, s_, r, keep_for_backward=needs_grad)
+            if st is not None and needs_grad:
+                ctx.lease = _WsLease(st)
+        if st is None:
+            st = rasterize_forward(raster_settings, m, o, s_, r)
+        ctx.state = st
         ctx.save_for_backward(m, s_, r)
         ctx.mark_non_differentiable(st.radii)
         # allmap is returned as a fresh tensor the caller may overwrite in place
@@ -400,7 +600,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         st = ctx.state
         if grad_allmap is None:
             grad_allmap = torch.zeros_like(st.allmap)
-        dmeans, dscales, drots, dopac, _ = rasterize_backward(st, m, s_, r, grad_allmap)
+        if isinstance(st, WsState):
+            if ctx.lease is None or ctx.lease.state is None:
+                raise RuntimeError("the rasterizer's backward ran twice on one forward (retain_graph): its buffers are "
+                                   "gone; set SLS_STAGED_FORWARD=1 for a graph that is walked more than once")
+            try:
+                dmeans, dscales, drots, dopac = rasterize_backward_ws(st, m, s_, r, grad_allmap)
+            finally:
+                ctx.lease.release()
+        else:
+            dmeans, dscales, drots, dopac, _ = rasterize_backward(st, m, s_, r, grad_allmap)
         if ctx.debug:
             torch.cuda.synchronize(m.device)
         return dmeans, None, dopac, dscales, drots, None, None

@@ -184,6 +184,40 @@ def test_binding_installs_itself(tmp_path, order, flag):
     assert lines[-1] == "reference loop"
 
 
+REAL_SCRIPT = """
+import os, sys, types
+sys.path.insert(0, {root!r}); sys.path.insert(0, "/root/reference")
+os.environ["SLS_FUSED_MAPPER"] = "1"
+for name in ("plyfile", "rerun"):                       # (imports of the checkout that the image lacks; nothing the mapper runs)
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["rerun"].__path__ = []
+sys.modules["rerun.blueprint"] = sys.modules["rerun"].blueprint = types.ModuleType("rerun.blueprint")
+sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+try:
+    import omegaconf
+except ImportError:
+    oc = types.ModuleType("omegaconf"); oc.OmegaConf = type("OmegaConf", (), {{}}); sys.modules["omegaconf"] = oc
+import slam.mapper as sm                                 # the reference's own module, unmodified
+import gaussian_renderer
+assert gaussian_renderer.GaussianRasterizer.__module__ == "splat_loam_amd.rasterizer"
+before = hasattr(sm.Mapper.optimize, "_sls_original")
+try:
+    gaussian_renderer.GaussianRasterizer(raster_settings=None)
+finally:
+    print(before, hasattr(sm.Mapper.optimize, "_sls_original"), sm.Mapper.optimize._sls_original.__qualname__)
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/slam"), reason="needs the Splat-LOAM checkout (build container only)")
+def test_binding_installs_on_the_reference_checkout():
+    """The same against the reference's OWN slam/mapper.py (read where it lies, nothing copied): importing it pulls in
+    gaussian_renderer -> this repo's rasterizer module, which requests the binding; the first GaussianRasterizer() —
+    every render() builds one — finds `Mapper` defined and replaces its `optimize`."""
+    out = subprocess.run([sys.executable, "-c", REAL_SCRIPT.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "False True Mapper.optimize", out.stdout
+
+
 @pytest.mark.gpu
 def test_g7_update_model_through_the_engine(device):
     """VERDICT r04 item 1(a).  The three keyframes on the GPU, stage by stage as `fused_mapper.update_model` runs them:

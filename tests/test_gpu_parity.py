@@ -298,6 +298,74 @@ def test_autograd_function_matches_raw_calls(device):
         assert np.abs(g - r).max() / scale <= 1e-5, k   # float atomics reorder sums between runs
 
 
+@pytest.mark.parametrize("N,H,W,kw,pairs", [(6000, 32, 256, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25), "1"),
+                                            (6000, 32, 256, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25), "2"),
+                                            (50000, 64, 1024, {}, "2"), (50000, 64, 1024, {}, "1"),
+                                            (5000, 40, 200, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25), "2"),
+                                            (500000, 64, 2048, {}, "0")],
+                         ids=["small-pairs", "small-plain", "c2-plain", "c2-pairs", "ragged-plain", "c3-auto"])
+def test_workspace_path_matches_staged_path(device, monkeypatch, N, H, W, kw, pairs):
+    """VERDICT r04 item 1(c).  GaussianRasterizer's default path — sls_forward_ws / sls_backward_ws: one call each, a
+    capacity instead of the host read of R, the camera's previous depth order repaired, gradient records cleared where
+    they are read — against the staged calls on the same inputs: radii and allmap to the BIT (the forward has no
+    atomics; the list is the same list whether sorted or repaired), gradients to 5e-6 of their scale (float atomics on both sides: two runs of ONE path differ by 1e-6 already).
+    Five calls on one camera with the surfels moving in between: from-scratch sort, then repairs; then a capacity that
+    is too small (the forward repeats itself with more room) and a graph dropped without a backward.  `pairs`: the list
+    form (SLS_BLOCK_MASKS) — the automatic rule looks at the capacity here and at R there, and the two forward kernels
+    it chooses between agree to rounding only, so the form is pinned except at C3, where both rules choose pairs."""
+    monkeypatch.setenv("SLS_BLOCK_MASKS", pairs)
+    from splat_loam_amd import rasterizer
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc, view, proj = scene_and_camera(N, H, W, seed=31, **kw)
+    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device), False, False)
+    rng = np.random.default_rng(5)
+    dL = torch.tensor(rng.normal(size=(7, H, W)).astype(np.float32), device=device)
+    base = {k: torch.tensor(sc[k], device=device) for k in ("means", "scales", "rots", "opac")}
+    rasterizer._WS_CACHE.clear()
+
+    def run(t, staged):
+        monkeypatch.setenv("SLS_STAGED_FORWARD", "1" if staged else "0")
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        radii, allmap = GaussianRasterizer(raster_settings=settings)(
+            means3D=leaves["means"], means2D=torch.zeros_like(leaves["means"]), opacities=leaves["opac"],
+            scales=leaves["scales"], rotations=leaves["rots"], cov3D_precomp=None)
+        out = (radii.clone(), allmap.clone())
+        (allmap * dL).sum().backward()
+        return out, {k: v.grad.clone() for k, v in leaves.items()}
+
+    for it in range(5):
+        t = dict(base)
+        t["means"] = base["means"] + 3e-4 * it * torch.tensor(rng.normal(size=(N, 3)).astype(np.float32), device=device)
+        (r_ws, a_ws), g_ws = run(t, staged=False)
+        (r_st, a_st), g_st = run(t, staged=True)
+        assert torch.equal(r_ws, r_st) and torch.equal(a_ws, a_st), f"call {it}"
+        for k in g_st:
+            scale = float(g_st[k].abs().max())
+            assert float((g_ws[k] - g_st[k]).abs().max()) <= 5e-6 * scale, (it, k)
+    ent = next(iter(rasterizer._WS_CACHE.values()))
+    assert ent.stats["from_scratch"] >= 1 and ent.stats["repaired"] + ent.stats["repair_failed"] >= 4 and ent.stats["repaired"] >= 2 and not ent.busy, ent.stats
+    # a capacity that is too small: the forward notices on the device, takes more room and repeats itself
+    rasterizer._ws_alloc(ent, device, N, H, W, max(ent.stats["R"] // 2, 4096))
+    (r_ws, a_ws), _ = run(base, staged=False)
+    (r_st, a_st), _ = run(base, staged=True)
+    assert ent.stats["too_small"] >= 1 and ent.cap >= ent.stats["R"] and torch.equal(a_ws, a_st) and torch.equal(r_ws, r_st)
+    # no_grad takes no lease; a graph that is dropped without a backward gives the workspace back
+    monkeypatch.setenv("SLS_STAGED_FORWARD", "0")
+    with torch.no_grad():
+        _, a_ng = GaussianRasterizer(raster_settings=settings)(means3D=base["means"], means2D=base["means"], opacities=base["opac"],
+                                                             scales=base["scales"], rotations=base["rots"])
+    assert torch.equal(a_ng, a_st) and not ent.busy
+    m = base["means"].clone().requires_grad_(True)
+    _, a_kept = GaussianRasterizer(raster_settings=settings)(means3D=m, means2D=m, opacities=base["opac"], scales=base["scales"], rotations=base["rots"])
+    assert ent.busy
+    # ... while it is held, another forward of the same size takes the staged path instead of waiting
+    _, a_other = GaussianRasterizer(raster_settings=settings)(means3D=m, means2D=m, opacities=base["opac"], scales=base["scales"], rotations=base["rots"])
+    assert torch.equal(a_other, a_st)
+    del a_kept, a_other
+    import gc; gc.collect()
+    assert not ent.busy
+
+
 def test_cpu_tensors_are_refused():
     from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     s = GaussianRasterizationSettings(8, 16, 1.0, torch.eye(4), torch.eye(4), False, False)
