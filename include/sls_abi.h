@@ -140,11 +140,14 @@ int sls_forward_stage1(const SlsCamera *cam, int N,
  * pair: R uint32 each (ping-pong).  keys64_out (optional, R uint64): the 64-bit keys
  * (tile << 32 | depth bits) the list is ordered by (asks for the two-array sort: no pairs then).
  * The sorted list of surfel indices comes back as (*sorted_list, *sorted_stride): entry j is
- * (*sorted_list)[j * *sorted_stride] — stride 1: a plain array (vals or vals_tmp; *sorted_in_tmp says which, and
- * which of tile_keys / tile_keys_tmp holds the sorted tile ids when the sort kept them); stride 2: the
+ * (*sorted_list)[j * *sorted_stride] — stride 1: a plain array (vals or vals_tmp; *sorted_in_tmp says which); stride 2: the
  * (surfel, block mask) pairs inside sort_scratch (block_box given, lists long enough or list_pairs = 1, at most
  * 2048 tiles): sort_scratch then has to stay alive as long as the list is used (the backward, the caller).
  * list_pairs: 0 = pairs where R >= 1500 T (the rule of sls_mapping_step), 1 = whenever possible, 2 = never.
+ * tile_keys / tile_keys_tmp are SCRATCH: the sorted tile ids are NOT an output.  Where the direct binning serves the
+ * image (<= 512 tiles, D10 off — every size the reference meets) nothing is written to them, nor to vals_tmp, and
+ * tiles_touched / offsets / total_dev / tile_mask are not read; a caller that wants the keys the list is ordered by
+ * passes keys64_out (or derives them from ranges + list + depth, as splat_loam_amd/rasterizer.py:_list_and_keys does).
  * ranges: T*2 uint32 with T = ceil(W/tw)*ceil(H/th).  allmap: 7*H*W floats;
  * pix_state: H*W float4 {T_final, M1, M2, 0}; pix_contrib: H*W uint2
  * {n_contrib, median_contrib}; tile_consumed: T uint32 (list entries consumed

@@ -799,7 +799,13 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     const uint32_t otag_w = ob[0];
     const uint32_t oidx = ob[block_order ? (order_tag ? 1 : 0) + oxcd * (T * kPerTile / 8) + (int)blockIdx.x / 8 : 0];
     const uint32_t otag = (block_order && order_tag) ? otag_w : order_tag;
-    if (DENSE && tagw != block_mask_tag(BW)) return;
+    if (DENSE && tagw != block_mask_tag(BW)) {
+        // the hand-over was written by a forward of another block shape (debug variants switched between the two
+        // launches): nothing here can be trusted — say so (bit 4 of the iteration's void word: the engine raises) instead
+        // of dropping the block's gradients and loss terms silently
+        if (det_flag && threadIdx.x == 0) atomicOr(det_flag, 16u);
+        return;
+    }
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
     const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     int tile, sub;

@@ -302,6 +302,10 @@ class MappingEngine:
             if first_visit:
                 for k in [k for k, e in self._det_prev.items() if e[1]() is None]:
                     del self._det_prev[k]
+                # (bounded like the depth orders: 16 N bytes per keyframe; an evicted keyframe's next visit is a
+                #  two-launch iteration, as a first visit is)
+                while len(self._det_prev) >= self.max_cached_orders:
+                    self._det_prev.pop(next(iter(self._det_prev)))
                 dent = [torch.zeros((self.N, 16), dtype=torch.uint8, device=self.dev), weakref.ref(camera)]
                 self._det_prev[id(camera)] = dent
             cfg.det_prev = dent[0].data_ptr()
@@ -348,8 +352,15 @@ class MappingEngine:
         size follows the measured size of the union of the touched sets: up at once (50 % + 4096 slots of head room
         — keyframes of a window reach sets of different size, and an iteration voided by a union that outgrew the
         collective costs more than a few hundred KB on the wire), down by 3 % per iteration."""
-        if st.get("det_mispredicted"):
-            self._det_two_pass_next = True            # the repeat (and with it the defaults' refresh) in two launches
+        # One-launch deterministic mode: the repeat of ANY voided iteration runs the two-launch scheme.  A misprediction
+        # (bit 3) is what calls for it, but the keyframe-parallel verdicts fold every bit above bit 0 into bit 1 on their
+        # way through the collectives, so the host cannot tell it from a failed repair there — and a one-launch repeat
+        # with the same parameters and the same predictions would mispredict again, for ever (ADVICE r04).
+        if st["overflow"] and self.deterministic == 2:
+            self._det_two_pass_next = True            # (and with it the defaults' refresh)
+        if st.get("handover_mismatch"):
+            raise RuntimeError("the tile backward found a forward -> backward hand-over written by another tile-kernel variant "
+                               "(sls_debug_variant switched between the two launches): the iteration's gradients are void")
         if self._sx is not None and (not st["overflow"] or st["exchange_too_small"]):
             want = int(st["exchange_count"] * 1.5) + 4096
             self._sx["send"] = int(min(self.N, max(want, int(self._sx["send"] * 0.97))))
@@ -363,7 +374,7 @@ class MappingEngine:
         # instance buffers were too small, bit 1 = the repaired depth order was not exact
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
                 "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
-                "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
+                "handover_mismatch": bool(flags & 16), "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
@@ -375,7 +386,7 @@ class MappingEngine:
         R, flags = int(h[0]) & 0xFFFFFFFF, int(h[1])
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
                 "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
-                "exchange_count": int(h[7]) & 0xFFFFFFFF,
+                "handover_mismatch": bool(flags & 16), "exchange_count": int(h[7]) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 

@@ -53,6 +53,15 @@ def test_latest_bench_line_has_the_contract_fields():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
 
 
+def test_bench_is_split_into_headline_support_and_extras():
+    """the measured path stays auditable — bench.py is the headline (scene, timed loop, per-kernel
+    events, the line), the counters / roofline / CPU leg and the secondary measurements live next to it."""
+    n = lambda f: sum(1 for _ in open(os.path.join(ROOT, f)))
+    assert n("bench.py") <= 380 and os.path.exists(os.path.join(ROOT, "bench_support.py")) and os.path.exists(os.path.join(ROOT, "bench_extras.py"))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "oracle" not in src.replace("bench_support", ""), "the headline file does not touch the checker (bench_support's cpu_baselines does)"
+
+
 def test_profiles_of_the_latest_round_are_committed():
     path, _ = _latest()
     tag = os.path.basename(path).split("_")[0]
@@ -63,16 +72,12 @@ def test_profiles_of_the_latest_round_are_committed():
 def test_replayed_counters_belong_to_this_build():
     """`roofline.traffic` / `roofline.valu` are replayed from committed rocprofv3 --pmc passes (rocprofv3 cannot wrap
     the process it is called from).  The passes record the hash of the kernel sources they were measured on
-    (bench.kernel_source_hash); the NEWEST committed passes must carry the hash of the sources in the tree — change a
-    kernel without re-profiling and this fails (and bench.py prints "stale": true)."""
+    (bench_support.kernel_source_hash); the NEWEST committed passes must carry the hash of the sources in the tree —
+    change a kernel without re-profiling and this fails (and bench.py prints "stale": true)."""
     import sys
     sys.path.insert(0, ROOT)
-    argv, sys.argv = sys.argv, ["bench.py"]
-    try:
-        import bench
-    finally:
-        sys.argv = argv
-    now = bench.kernel_source_hash()
+    import bench_support
+    now = bench_support.kernel_source_hash()
     for pattern in ("*pmc_traffic.json", "*pmc_sq.json"):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
         assert files, pattern

@@ -1102,6 +1102,63 @@ def _engine_rccl_rank(rank, port, out_dir, dp_mode):
     dist.destroy_process_group()
 
 
+def _det2_misprediction_rank(rank, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from splat_loam_amd import synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.mapping import MappingConfig
+    from splat_loam_amd.scene import Camera, SurfelModel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=31, range_lo=2.0, range_hi=15.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[0], data_device="cuda:0")
+    out = {}
+    for tag, exchange, dp_mode, sync in (("single", False, "allreduce", True), ("single_lagged", False, "allreduce", "lagged"),
+                                         ("allreduce", True, "allreduce", True), ("sparse", True, "sparse", True),
+                                         ("rs_ag_lagged", True, "rs_ag", "lagged")):
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device="cuda:0")
+        eng = MappingEngine(model, MappingConfig())
+        eng.dp_mode, eng.exchange_at_world_1, eng.deterministic = dp_mode, exchange, 2
+        for _ in range(3):
+            eng.step(cam)
+        before = sum(eng.stats.values())
+        eng._det_prev[id(cam)][0].fill_(1)       # predictions 2^100 too small: every field of every surfel overflows its scale
+        if sync == "lagged":
+            eng.step(cam, sync="lagged"); eng.step(cam, sync="lagged"); eng.flush()
+        else:
+            eng.step(cam); eng.step(cam)
+        out[tag + "_repeats"] = sum(eng.stats.values()) - before
+        out[tag + "_t"] = eng.t
+        out[tag + "_xyz"] = model._xyz.detach().cpu().numpy()
+    np.savez(os.path.join(out_dir, "det2.npz"), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_launch_deterministic_mode_survives_a_misprediction(device, tmp_path):
+    """ADVICE r04 (medium).  SLS_DETERMINISTIC=2 predicts every field's fixed-point scale from the keyframe's previous
+    iteration; a misprediction voids the iteration (bit 3).  The keyframe-parallel verdicts fold that bit into bit 1, so
+    the host could not tell it from a failed repair and repeated the iteration in ONE launch again — same parameters,
+    same predictions, same misprediction: step() never returned.  Now the repeat of any voided deterministic iteration
+    takes two launches.  Forced here by overwriting the predictions, on one GPU and through the three exchange
+    schemes in a one-rank RCCL group, synchronous and lagged: five iterations each, one of them repeated, and the
+    same parameters whichever way the gradients travelled."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_det2_misprediction_rank, args=(port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "det2.npz")
+    for tag in ("single", "single_lagged", "allreduce", "sparse", "rs_ag_lagged"):
+        assert int(r[tag + "_t"]) == 5, tag
+        assert int(r[tag + "_repeats"]) >= 1, f"{tag}: the poisoned predictions did not void an iteration"
+        assert np.isfinite(r[tag + "_xyz"]).all()
+        assert np.abs(r[tag + "_xyz"] - r["single_xyz"]).max() <= 1e-6 * np.abs(r["single_xyz"]).max(), tag
+
+
 @pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce", "sparse", "sparse-overlapped"])
 def test_engine_exchange_through_rccl_world_1(device, tmp_path, dp_mode, monkeypatch):
     """The keyframe-parallel exchange executed by RCCL itself (backend "nccl", one rank, one GPU): reduce_scatter_tensor

@@ -39,7 +39,7 @@ for line in open("gpurun_out/pmc_sq.txt"):
         rows.setdefault(m.group(1).split("<")[0], {})[m.group(2)] = int(m.group(3))
 import sys
 sys.path.insert(0, ".")
-from bench import kernel_source_hash
+from bench_support import kernel_source_hash
 out = {"kernel_source_hash": kernel_source_hash(),
        "note": "SQ counters per launch, tools/one_iter.py (first 4 iterations of the bench scene); SQ_*_CYCLES / ACTIVE / WAIT "
                "count SIMD issue slots (4 clocks), SQ_BUSY_CYCLES is summed over the 32 shader engines", "kernels": {}}

@@ -32,7 +32,7 @@ f_corr = read_true / (adam["FETCH_SIZE_KiB_per_launch"] * 1024)
 w_corr = write_true / (adam["WRITE_SIZE_KiB_per_launch"] * 1024)
 import sys
 sys.path.insert(0, ".")
-from bench import kernel_source_hash
+from bench_support import kernel_source_hash
 res = {"kernel_source_hash": kernel_source_hash(),
        "calibration": {"kernel": "adam_kernel", "true_read_bytes": read_true, "true_write_bytes": write_true,
                        "fetch_factor": f_corr, "write_factor": w_corr,
