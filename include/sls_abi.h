@@ -222,6 +222,7 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R,
  * — verified exact on the device, bit 1 otherwise.  list_pairs as in stage 2.
  * workspace: sls_forward_ws_bytes(N, H, W, R_capacity) bytes, 256-byte aligned, alive until the backward has run;
  * workspace_ready = 0 on its first use (a region of it must start from zero; forward and backward leave it so).
+ * want_backward = 0 (render() under no_grad: Mapper.densify, the tracker): no forward -> backward hand-over is written.
  * radii (N int32), allmap (7*H*W floats): tensors of the caller's own.  *sorted_list / *sorted_stride /
  * *block_masks_shape: what sls_backward_ws wants back (pointers into the workspace).
  * Serves what the direct binning serves (<= 512 tiles, images the block boxes describe, D10 off): otherwise
@@ -230,18 +231,20 @@ struct SlsMappingStatus;
 size_t sls_forward_ws_bytes(int N, int H, int W, uint64_t R_capacity);
 int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
                    const float *opacities, const float *col_cs, const float *row_cs, uint64_t R_capacity,
-                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int32_t *radii,
-                   float *allmap, void *workspace, size_t workspace_bytes, struct SlsMappingStatus *status_dev,
+                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int want_backward,
+                   int32_t *radii, float *allmap, void *workspace, size_t workspace_bytes, struct SlsMappingStatus *status_dev,
                    struct SlsMappingStatus *status_mirror, const uint32_t **sorted_list, int *sorted_stride,
                    int *block_masks_shape, void *stream);
 /* The backward of that forward: tile backward (it marks the surfels it reaches) + the projection's backward, which
- * reads — and clears — only the marked surfels' gradient records: no 64 N-byte memset per call.  Float atomics
+ * reads — and clears — only the marked surfels' gradient records: no 64 N-byte memset per call.  block_order (optional;
+ * sls_block_order_bytes(H, W) bytes, zero-initialised, caller-kept PER CAMERA): the tile backward walks its pixel blocks
+ * most expensive first in the order this camera's previous backward left there, and leaves the next one.  Float atomics
  * (sls_backward_det on the staged buffers is the bit-reproducible alternative). */
 int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
                     const int32_t *radii, const float *col_cs, const float *row_cs, const float *dL_dallmap,
                     uint64_t R_capacity, void *workspace, size_t workspace_bytes, const uint32_t *sorted_list,
-                    int sorted_stride, int block_masks_shape, float *dL_dmeans3D, float *dL_dscales,
-                    float *dL_drotations, float *dL_dopacities, void *stream);
+                    int sorted_stride, int block_masks_shape, uint32_t *block_order, float *dL_dmeans3D,
+                    float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream);
 
 /* ---- fused consumer of allmap: render() post-processing + mapper loss ------
  * Computes, from allmap (7*H*W, NOT modified), the three per-pixel loss terms of

@@ -99,10 +99,10 @@ _PROTOS = {
     "sls_backward": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 7 + [C.c_int] + [_VP] * 11 +
                      [C.c_int, _VP]),
     "sls_forward_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_uint64]),
-    "sls_forward_ws": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 6 + [C.c_uint64, _VP, C.c_int, C.c_int, C.c_int, _VP, _VP,
+    "sls_forward_ws": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 6 + [C.c_uint64, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP,
                                  _VP, C.c_size_t, _VP, _VP, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
     "sls_backward_ws": (C.c_int, [C.POINTER(SlsCamera), C.c_int] + [_VP] * 7 + [C.c_uint64, _VP, C.c_size_t, _VP, C.c_int, C.c_int] +
-                        [_VP] * 5),
+                        [_VP] * 6),
     "sls_backward_det_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_backward_det": (C.c_int, [C.POINTER(SlsCamera), C.c_int, C.c_uint64] + [_VP] * 7 + [C.c_int] + [_VP] * 10 +
                          [C.c_int, _VP, C.c_size_t, _VP]),

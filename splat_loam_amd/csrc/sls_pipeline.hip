@@ -328,8 +328,8 @@ size_t sls_forward_ws_bytes(int N, int H, int W, uint64_t R_capacity)
 
 int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
                    const float *opacities, const float *col_cs, const float *row_cs, uint64_t R_capacity,
-                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int32_t *radii,
-                   float *allmap, void *workspace, size_t workspace_bytes, SlsMappingStatus *status_dev,
+                   uint32_t *depth_order, int reuse_rounds, int list_pairs, int workspace_ready, int want_backward,
+                   int32_t *radii, float *allmap, void *workspace, size_t workspace_bytes, SlsMappingStatus *status_dev,
                    SlsMappingStatus *status_mirror, const uint32_t **sorted_list, int *sorted_stride,
                    int *block_masks_shape, void *stream)
 {
@@ -388,16 +388,20 @@ int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const floa
     const uint32_t *list = bmask ? (const uint32_t *)bmask : w.vals;
     *sorted_list = list;
     *sorted_stride = bmask ? 2 : 1;
-    *block_masks_shape = (int)debug_state().fwd_variant;
+    // a forward nobody differentiates (render() under no_grad: Mapper.densify, the tracker) writes no hand-over; one
+    // that is leaves the backward its blocks' compact lists and their costs (sorted into the camera's launch order by
+    // passengers of the backward's last kernel, for the camera's NEXT backward: as sls_mapping_step does)
+    *block_masks_shape = want_backward ? (int)debug_state().fwd_variant : 0;
     return launch_render_fwd(dc, w.ranges, list, w.rec, col_cs, row_cs, allmap, w.pix_state, w.pix_contrib, nullptr, st,
-                             true, w.block_masks, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, nullptr, bmask, true);
+                             true, want_backward ? w.block_masks : nullptr, (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0,
+                             want_backward ? w.block_cost : nullptr, bmask, false);
 }
 
 int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const float *scales, const float *rotations,
                     const int32_t *radii, const float *col_cs, const float *row_cs, const float *dL_dallmap,
                     uint64_t R_capacity, void *workspace, size_t workspace_bytes, const uint32_t *sorted_list,
-                    int sorted_stride, int block_masks_shape, float *dL_dmeans3D, float *dL_dscales,
-                    float *dL_drotations, float *dL_dopacities, void *stream)
+                    int sorted_stride, int block_masks_shape, uint32_t *block_order, float *dL_dmeans3D,
+                    float *dL_dscales, float *dL_drotations, float *dL_dopacities, void *stream)
 {
     SLS_REQUIRE(cam && workspace && sorted_list, "null pointer");
     SLS_REQUIRE(N > 0, "N must be positive");
@@ -414,15 +418,22 @@ int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const flo
     const DevCam dc = make_devcam(*cam);
     // the tile backward marks the surfels it reaches; the projection's backward reads — and clears — only their records:
     // no 64 N-byte memset per call
+    // the blocks most expensive first per XCD, in the order this camera's PREVIOUS backward left in the caller's buffer
+    // (its tag word says whether one has: a first visit walks the natural order)
+    const int T = dc.GX * dc.GY;
+    const bool order_bwd = block_order != nullptr && block_masks_shape == 3 && debug_state().bwd_variant == 3 &&
+                           T % 32 == 0 && kTileW == 16 && kTileH == 16;
     int rc = launch_render_bwd(dc, w.ranges, sorted_list, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, dL_dallmap,
                                w.grec, st, block_masks_shape ? w.block_masks : nullptr,
-                               (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, w.touched, nullptr, nullptr, nullptr, nullptr,
-                               sorted_stride, block_masks_shape, true);
+                               (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, w.touched, nullptr, nullptr, nullptr,
+                               order_bwd ? block_order : nullptr, sorted_stride, block_masks_shape, false, nullptr, nullptr,
+                               nullptr, false, order_bwd ? block_order_tag(T) : 0u);
     if (rc) return rc;
     AdamFuse fuse;
     memset(&fuse, 0, sizeof(fuse));
     fuse.clear_grec = 1;
     fuse.touched = w.touched;
+    if (order_bwd) { fuse.order_T = T; fuse.order_cost = w.block_cost; fuse.order_out = block_order; }
     return launch_preprocess_bwd(dc, 0, 0.0f, 0.0f, N, means3D, scales, rotations, nullptr, radii, w.grec, dL_dmeans3D,
                                  dL_dscales, dL_drotations, dL_dopacities, st, &fuse);
 }

@@ -405,7 +405,8 @@ def _ws_alloc(e: _WsEntry, dev, N, H, W, cap) -> None:
 
 class WsState:
     """What the backward needs from a workspace forward (the buffers themselves live in the entry's workspace)."""
-    __slots__ = ("cam", "entry", "N", "R", "cap", "radii", "allmap", "list_ptr", "stride", "shape", "ws", "ws_ptr", "ws_bytes")
+    __slots__ = ("cam", "entry", "N", "R", "cap", "radii", "allmap", "list_ptr", "stride", "shape", "ws", "ws_ptr", "ws_bytes",
+                 "block_order")
 
 
 def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opacities, scales, rotations,
@@ -436,7 +437,9 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
     okey = id(ce)
     ent = e.orders.get(okey)
     if ent is None or ent[2] is not ce:
-        ent = [torch.empty((N,), dtype=torch.int32, device=dev), None, ce]
+        # [depth order, call it was last written at, the camera entry, the tile backward's launch order (zeros: none yet)]
+        ent = [torch.empty((N,), dtype=torch.int32, device=dev), None, ce,
+               torch.zeros((int(lib.sls_block_order_bytes(H, W)) // 4,), dtype=torch.int32, device=dev)]
         e.orders[okey] = ent
         while len(e.orders) > _WS_ORDERS_MAX:
             e.orders.popitem(last=False)
@@ -458,7 +461,8 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
         row[7] = _SENTINEL
         rc = lib.sls_forward_ws(C.byref(cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                 opacities.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), e.cap,
-                                ent[0].data_ptr(), reuse, list_pairs_mode(), 1 if e.ready else 0, radii.data_ptr(),
+                                ent[0].data_ptr(), reuse, list_pairs_mode(), 1 if e.ready else 0,
+                                1 if keep_for_backward else 0, radii.data_ptr(),
                                 allmap.data_ptr(), e.ws_ptr, e.ws_bytes, e.status.data_ptr(), e.mirror.data_ptr(),
                                 C.byref(lst), C.byref(stride), C.byref(shape), st)
         if rc == -4:                      # SLS_E_UNSUPPORTED
@@ -491,7 +495,7 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
     s = WsState()
     s.cam, s.entry, s.N, s.R, s.cap, s.radii, s.allmap = ce, e, N, R, e.cap, radii, allmap
     s.list_ptr, s.stride, s.shape = int(lst.value), int(stride.value), int(shape.value)
-    s.ws, s.ws_ptr, s.ws_bytes = e.ws, e.ws_ptr, e.ws_bytes
+    s.ws, s.ws_ptr, s.ws_bytes, s.block_order = e.ws, e.ws_ptr, e.ws_bytes, ent[3]
     if keep_for_backward:
         e.busy = True                     # released by the backward (or when the autograd node dies without one)
     return s
@@ -507,7 +511,7 @@ def rasterize_backward_ws(state: WsState, means3D, scales, rotations, dL_dallmap
         _abi.check(lib.sls_backward_ws(C.byref(ce.cam), N, means3D.data_ptr(), scales.data_ptr(), rotations.data_ptr(),
                                        state.radii.data_ptr(), ce.col_cs.data_ptr(), ce.row_cs.data_ptr(), dL.data_ptr(),
                                        state.cap, state.ws_ptr, state.ws_bytes, state.list_ptr, state.stride, state.shape,
-                                       out.ptr("dmeans"), out.ptr("dscales"), out.ptr("drots"), out.ptr("dopac"),
+                                       state.block_order.data_ptr(), out.ptr("dmeans"), out.ptr("dscales"), out.ptr("drots"), out.ptr("dopac"),
                                        _stream(dev)), "sls_backward_ws")
     except Exception:
         state.entry.ready = False         # (whatever state the records are in: the next forward clears them)
