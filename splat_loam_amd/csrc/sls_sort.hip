@@ -152,6 +152,34 @@ __device__ __forceinline__ void count_rect_tiles(uint32_t r32, int GX, uint32_t 
     }
 }
 
+// The same for a whole wave (call it from uniform control flow, r32 = 0 for lanes without a surfel).  A lane walks its
+// own rectangle while that is small; rectangles of more than kBigRect tiles — a surfel within a metre of the sensor covers
+// a quarter of the image and more: 420 of 500 k at the bench scene's last keyframe, all of them in the first chunks of the
+// depth order — are walked by the 64 lanes TOGETHER, one rectangle after the other: a lane that walks 512 tiles alone
+// keeps its wave for 512 dependent LDS atomics (20 us) while 63 lanes wait, and its neighbours' rectangles hit the
+// same words at the same moment (profiles/r05a_bin_tail.txt).
+constexpr uint32_t kBigRect = 48;
+__device__ __forceinline__ void count_rect_tiles_wave(uint32_t r32, int GX, uint32_t *s_hist)
+{
+    const uint32_t ncols = (r32 >> 9) & 1023u, t = ncols * (r32 >> 25);
+    uint64_t big = __ballot(t > kBigRect);
+    if (t <= kBigRect) count_rect_tiles(r32, GX, s_hist);
+    const int lane = (int)(threadIdx.x & 63u);
+    while (big) {
+        const int src = (int)__builtin_ctzll(big);
+        big &= big - 1ull;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r32, src);
+        const uint32_t nc = (r >> 9) & 1023u, n = nc * (r >> 25);
+        const float inc = __builtin_amdgcn_rcpf((float)nc);
+        for (uint32_t k = (uint32_t)lane; k < n; k += 64u) {
+            const uint32_t ky = (uint32_t)(((float)k + 0.5f) * inc);      // (k / ncols: see bin_direct_kernel)
+            int tx = (int)(r & 511u) + (int)(k - ky * nc);
+            if (tx >= GX) tx -= GX;
+            atomicAdd(&s_hist[((int)((r >> 19) & 63u) + (int)ky) * GX + tx], 1u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
@@ -732,7 +760,7 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         for (int q = 0; q < 2; ++q) {
             const int pos = base + o0 + q;
             if (pos >= 0 && pos < N) db.serec[pos] = er[q];
-            count_rect_tiles(er[q].x, GX, s_hist);
+            count_rect_tiles_wave(er[q].x, GX, s_hist);
         }
     } else {
 #pragma unroll
@@ -781,11 +809,12 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
     if ((int)threadIdx.x < db.bins) s_hist[threadIdx.x] = 0u;
     __syncthreads();
     const int pos = blockIdx.x * kDirectChunk + (int)threadIdx.x;
+    uint2 er = make_uint2(0u, 0u);
     if (pos < N) {
-        const uint2 er = load_emit_record(erec_box, rect, sbox, order[pos]);
+        er = load_emit_record(erec_box, rect, sbox, order[pos]);
         if (db.serec) db.serec[pos] = er;
-        count_rect_tiles(er.x, GX, s_hist);
     }
+    count_rect_tiles_wave(er.x, GX, s_hist);
     __syncthreads();
     if ((int)threadIdx.x < db.bins) {
         const uint32_t c = s_hist[threadIdx.x];
@@ -925,9 +954,9 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     __syncthreads();
     SLS_BT(1);
     // per-wave counts (the order inside a wave does not matter for counting: every lane walks its own rectangle)
-    count_rect_tiles(er.x, GX, s_cur + w * BINS);
+    count_rect_tiles_wave(er.x, GX, s_cur + w * BINS);
 #pragma unroll
-    for (int m = 0; m < SPLIT - 1; ++m) count_rect_tiles(front[m], GX, s_pre);
+    for (int m = 0; m < SPLIT - 1; ++m) count_rect_tiles_wave(front[m], GX, s_pre);
     SLS_BT(2);
     // digit bases: exclusive scan of the tile totals (PER consecutive ones per thread)
     uint32_t loc[PER], dsum = 0;
@@ -977,6 +1006,29 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     uint32_t *const cur = s_cur + w * BINS;
     uint32_t carry = 0u;                          // (owner of the slot before this round) + 1
     for (uint32_t q0 = 0; q0 < S; q0 += 64u) {
+        if (carry) {
+            // A round whose 64 slots all belong to the surfel the previous round ended in — most rounds of a rectangle of
+            // hundreds of tiles — needs no owner search and no ranking: 64 consecutive tiles of ONE rectangle are 64
+            // different tiles, each takes its tile's cursor as it stands.  (The near end of the depth order at the bench
+            // scene's last keyframes: 222 rounds in the heaviest wave, 9 elsewhere — profiles/r05a_bin_tail.txt.)
+            const uint4 oc = s_lane[w][carry - 1u];
+            const uint32_t ncc = (oc.x >> 9) & 1023u;
+            if (oc.w + ncc * (oc.x >> 25) >= q0 + 64u) {
+                const uint32_t k = q0 + (uint32_t)lane - oc.w;
+                const uint32_t ky = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)ncc));
+                int tx = (int)(oc.x & 511u) + (int)(k - ky * ncc);
+                if (tx >= GX) tx -= GX;
+                const uint32_t tile = (uint32_t)(((int)((oc.x >> 19) & 63u) + (int)ky) * GX + tx);
+                const uint32_t p = cur[tile];
+                cur[tile] = p + 1u;
+                if (p < cap) {
+                    if (PAIRS) bm.out[p] = make_uint2(oc.z, block_mask_of(bm, tile, oc.y));
+                    else vals_out[p] = oc.z;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
         s_mark[w][lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         if (t != 0u && first - q0 < 64u) s_mark[w][first - q0] = (uint32_t)lane + 1u;     // (unsigned: first >= q0 too)

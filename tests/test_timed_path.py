@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+C4_CLAUSE = ("xyz", "rotation")      # element-wise only (2.2e-3 / 3.3e-3 against a bar of 2e-3; max-norm <= 9.4e-6 on every tensor)
+
+
 def reference_iteration(raw, K, view, proj, H, W, gt_depth, valid, cfg, allmap_value=None, dtype=np.float32):
     """Loss and raw-parameter gradients of one mapping iteration through the checker.  `allmap_value`: evaluate the
     consumer at THIS allmap (e.g. the engine's) while the gradient still flows into the checker's backward."""
@@ -79,10 +82,29 @@ def _raw_scene(N, H, W, seed, hfov_deg=360.0, **kw):
     ("c2_50k_64x1024", 50000, 64, 1024, {}),
     # no wrap-around, H and W not multiples of the tile: block boxes at the image's edges, partial tiles
     ("ragged_no_wrap", 5000, 40, 200, dict(hfov_deg=120.0, range_lo=2.0, range_hi=15.0, scale_hi=0.25)),
-], ids=["small", "c2", "ragged-no-wrap"])
+    # BASELINE config 4's size: a local model at its default limit of 150 k surfels
+    # (utils/config_utils.py:119) on the Newer College geometry, 128 x 1024 — 128 rows: the tallest image the block
+    # boxes describe, eight tile rows
+    ("c4_150k_128x1024", 150000, 128, 1024, {}),
+], ids=["small", "c2", "ragged-no-wrap", "c4"])
 @pytest.mark.parametrize("block_masks", [2, 1], ids=["window-rounds", "dense-rounds"])
-def test_engine_gradients_match_checker_chain(device, name, N, H, W, kw, block_masks):
-    _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed=23)
+def test_engine_gradients_match_checker_chain(device, oracle32, name, N, H, W, kw, block_masks):
+    if name.startswith("c4"):
+        # (128 rows over the same elevation span: half C2's pixel pitch, and the normal term amplifies an image
+        #  perturbation by 1 / (2 pitch) — judged as the other full-size cases are: fragile pixels out of the loss, against
+        #  what float32 itself costs, the tensors that need the float64 clause named)
+        import oracle.torch_function as otf
+        oracle32.set_threads(oracle32.max_threads())
+        for dt in (np.float32, np.float64):
+            otf._oracle(dt).set_threads(oracle32.max_threads())
+        otf.BACKWARD_THREADS = oracle32.max_threads()
+        try:
+            _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed=23, mask_fragile=oracle32,
+                                                float64_too=True, clause_for=C4_CLAUSE)
+        finally:
+            otf.BACKWARD_THREADS = 1
+        return
+    _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed=23, fragile_from=oracle32)
 
 
 @pytest.mark.gpu
@@ -93,7 +115,7 @@ def test_engine_gradients_match_checker_chain_tall_image(device, oracle32):
     7e-5 (max-norm) / 2e-2 (element-wise) from its float64 build on this scene.  Judged as at full size: fragile pixels
     out of the loss, against what float32 itself costs, element-wise bar 5e-3."""
     _check_engine_against_checker_chain(device, "tall", 6000, 160, 256, dict(range_lo=2.0, range_hi=15.0, scale_hi=0.25), 0,
-                                        seed=23, mask_fragile=oracle32, float64_too=True, elem_tol=5e-3)
+                                        seed=23, mask_fragile=oracle32, float64_too=True, elem_tol=5e-3, clause_for=("xyz", "opacity", "scaling", "rotation"))
 
 
 def test_engine_gradients_match_checker_chain_c3(device, oracle32):
@@ -101,7 +123,11 @@ def test_engine_gradients_match_checker_chain_c3(device, oracle32):
     scene itself (500 000 surfels, 64x2048, seed 0), `block_masks = 0`: the automatic rule switches the tile sort to
     (surfel, block mask) pairs (2400-entry lists, the forward's 320-entry ring wrapping many times, 9-round blocks),
     i.e. render_fwd_dense_kernel<8,2,false,LEAN>, render_bwd_block_kernel<8,2,LEAN,FUSED,0,DENSE> and the fused
-    Adam of sls_mapping_step against the checker chain, the checker on every host thread."""
+    Adam of sls_mapping_step against the checker chain, the checker on every host thread.
+    Which tensors pass only through the float64 clause is printed and pinned (`clause_for`): at this size the own-allmap
+    comparison of dxyz (1.9e-5 max-norm against the float32 checker, which is itself 2.5e-5 from its float64 build — as
+    is the engine) and of the rotations (element-wise 3.9e-3 against a bar of 2e-3; max-norm 8.7e-6); every same-allmap
+    comparison, and opacity / scaling either way, meet 1e-5 / 2e-3 against the float32 checker outright."""
     import oracle.torch_function as otf
     oracle32.set_threads(oracle32.max_threads())
     for dt in (np.float32, np.float64):     # (the autograd wrapper's own instances: one shared library per precision)
@@ -109,7 +135,7 @@ def test_engine_gradients_match_checker_chain_c3(device, oracle32):
     otf.BACKWARD_THREADS = oracle32.max_threads()
     try:
         eng = _check_engine_against_checker_chain(device, "c3_500k_64x2048", 500000, 64, 2048, {}, 0, seed=0,
-                                                  mask_fragile=oracle32, repeats=3, float64_too=True)
+                                                  mask_fragile=oracle32, repeats=3, float64_too=True, clause_for=("xyz", "rotation"))
     finally:
         otf.BACKWARD_THREADS = 1
     # the automatic rule did choose the dense kernels: capacity >= 1500 instances per tile
@@ -129,7 +155,7 @@ def _fragile_neighbourhood(oracle, raw, view, proj, H, W):
 
 
 def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, seed, mask_fragile=None, repeats=1, float64_too=False,
-                                        elem_tol=2e-3):
+                                        elem_tol=2e-3, fragile_from=None, clause_for=()):
     """VERDICT r1 item 1(a).  Engine (LEAN+FUSED backward, raw=1 preprocess, consumer in the kernel) vs the CPU
     chain.  Two comparisons:
       * `same-allmap`: the float64 consumer is evaluated at the ENGINE's allmap, so both sides differentiate the
@@ -145,12 +171,17 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
     pose = synth.keyframe_poses(2)[1]
     view, proj = synth.camera_matrices(sc["K"], pose)
     cfg = MappingConfig()
+    # the checker's fragile pixels (a discrete decision within 1e-4 of its threshold) and the pixels whose normal stencil
+    # reads them: the only places where the timed path's image may differ from the checker's by more than the bar
+    fragile = None
+    if mask_fragile is not None or fragile_from is not None:
+        fragile = _fragile_neighbourhood(mask_fragile if mask_fragile is not None else fragile_from, raw, view, proj, H, W)
     if mask_fragile is not None:
         # at full size a few hundred pixels are fragile: the two sides may take a different discrete decision there, and
         # in the own-allmap comparison each then differentiates a different function of those pixels.  They (and the
         # pixels whose normal stencil reads them) are taken out of the loss on BOTH sides, as every forward / backward
         # parity test zeroes dL/dallmap there.
-        drop = _fragile_neighbourhood(mask_fragile, raw, view, proj, H, W)
+        drop = fragile
         valid[0, drop] = 0
         print(f"\n[{name}] {int(drop.sum())} of {H * W} pixels (fragile + their stencil neighbours) taken out of the loss")
     runs = [_engine_once(device, raw, sc["K"], pose, depth, valid, cfg, block_masks) for _ in range(repeats)]
@@ -165,17 +196,31 @@ def _check_engine_against_checker_chain(device, name, N, H, W, kw, block_masks, 
         same64 = reference_iteration(raw, sc["K"], view, proj, H, W, depth[0], valid[0] == 1, cfg, allmap_value=am, dtype=np.float64)
     # (float atomics: the gradients vary from run to run — every run has to meet the bar)
     for k, (st, g, _, eng, model, cam) in enumerate(runs):
-        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same, own64, same64, elem_tol)
+        _assert_engine_matches_chain(f"{name}#{k}" if repeats > 1 else name, st, g, am, model, raw, own, same, own64, same64, elem_tol,
+                                     fragile=fragile, clause_for=clause_for)
     return runs[0][3]
 
 
-def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=None, same64=None, elem_tol=2e-3):
-    # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image
+def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=None, same64=None, elem_tol=2e-3, fragile=None,
+                                 clause_for=()):
+    # forward of the timed path: the raw-parameter preprocess + tile forward give the checker's image.  Max-norm 1e-5 per
+    # plane everywhere but at the checker's fragile pixels (+ stencil neighbours), where a discrete decision may fall the
+    # other way: those stay within 5e-2 and are at most 2 % of the image; element-wise, every value above 1e-3 of its
+    # plane's maximum agrees to 1e-3 relative — ten times tighter than the max-norm bar implies at that floor; the normal
+    # planes are sums of signed terms, measured 2.2e-4 on plane 4 at C2
     for c in range(5):
-        scale = max(np.abs(own["allmap"][c]).max(), 1e-12)
-        e = np.abs(am[c].astype(np.float64) - own["allmap"][c]) / scale
-        frac_bad = float((e > RTOL).mean())
-        assert frac_bad <= 0.02, f"{name}: allmap ch{c}: {frac_bad:.4f} of the pixels off by more than {RTOL}"
+        ref = own["allmap"][c].astype(np.float64)
+        scale = max(np.abs(ref).max(), 1e-12)
+        e = np.abs(am[c].astype(np.float64) - ref) / scale
+        off = e > RTOL
+        assert float(off.mean()) <= 0.02, f"{name}: allmap ch{c}: {off.mean():.4f} of the pixels off by more than {RTOL}"
+        assert float(e.max()) <= 5e-2, f"{name}: allmap ch{c}: a pixel off by {e.max():.2e} of the plane's scale"
+        if fragile is not None:
+            assert not (off & ~fragile).any(), \
+                f"{name}: allmap ch{c}: {int((off & ~fragile).sum())} pixels off by more than {RTOL} that are neither fragile in the checker nor next to such a pixel (worst {e[~fragile].max():.2e})"
+            big = (np.abs(ref) > 1e-3 * scale) & ~fragile
+            rel = np.abs(am[c].astype(np.float64) - ref)[big] / np.abs(ref)[big]
+            assert rel.max() <= 1e-3, f"{name}: allmap ch{c}: element-wise relative error {rel.max():.2e}"
     assert abs(st["loss"] - same["loss"]) <= 2e-5 * abs(same["loss"]), (st, same["loss"])
     assert abs(st["loss_reg"] - same["reg"]) <= 1e-5 * max(abs(same["reg"]), 1e-6)
     rot = raw["rotation"].astype(np.float64)
@@ -201,6 +246,7 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=N
     print(f"\n[{name}] engine vs checker chain (max-norm rel, worst element-wise rel above 1e-3 of max"
           + ("; then the engine vs the float64 checker and the float32 checker vs the float64 one" if same64 is not None else "") + "): "
           + "; ".join(f"{t}/{k}: " + ", ".join(f"{v:.1e}" for v in vals if v is not None) for (t, k), vals in report.items()))
+    needed = []
     for (tag, k), (e, er, e64, er64, n64, nr64) in report.items():
         if e64 is None:
             assert e <= RTOL, f"{name}: {tag} d{k} max-norm rel err {e:.3e} > {RTOL}"
@@ -210,18 +256,27 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=N
             # kernels and the checker's float32 build — differ by what float32 rounding and summation order cost; the
             # float64 build says how much that is (tools/c3_noise.py: the float32 checker itself is 0.3..1.7e-5 from
             # it).  The engine passes if it meets the bar against the float32 checker, or is as close to the float64
-            # checker as the float32 checker is (x1.5).
+            # checker as the float32 checker is (x1.5) — and the test says which tensors NEEDED that second clause and
+            # fails if one did that the caller had not named (`clause_for`: rotations at C3; everything on the tall image,
+            # whose pixel pitch amplifies the normal term 2.5 times)
+            if not (e <= RTOL and er <= elem_tol):
+                needed.append((tag, k, f"{e:.2e}", f"{er:.2e}"))
+                assert k in clause_for, f"{name}: {tag} d{k} meets the bar only through the float64 clause ({e:.3e} max-norm, {er:.3e} element-wise against the float32 checker)"
             assert e <= RTOL or e64 <= max(RTOL, 1.5 * n64), \
                 f"{name}: {tag} d{k} max-norm rel err {e:.3e} (float32 checker), {e64:.3e} (float64); float32 vs float64 checker {n64:.3e}"
             assert er <= elem_tol or er64 <= max(elem_tol, 1.5 * nr64), \
                 f"{name}: {tag} d{k} element-wise rel err {er:.3e} (float32 checker), {er64:.3e} (float64); float32 vs float64 checker {nr64:.3e}"
+    if same64 is not None:
+        print(f"[{name}] tensors that passed through the float64 clause only: {needed if needed else 'none'}")
     # the fused Adam consumed exactly these gradients: first step = -lr * sign(g) wherever |g| is not ~0
     lrs = {"xyz": 5e-4, "opacity": 5e-2, "scaling": 5e-3, "rotation": 1e-3}
     for k, p in (("xyz", model._xyz), ("opacity", model._opacity), ("scaling", model._scaling), ("rotation", model._rotation)):
         gg = g[k]
         sure = np.abs(gg) > 1e-6 * np.abs(gg).max()
         step = p.detach().cpu().numpy() - raw[k]
-        assert np.allclose(step[sure], (-lrs[k] * np.sign(gg))[sure], rtol=1e-3, atol=1e-9), k
+        # (the parameter is rounded to float32 after the step: half a unit in its last place on top of the step's 1e-3)
+        slack = 1e-3 * lrs[k] + np.spacing(np.abs(raw[k]).astype(np.float32))
+        assert (np.abs(step + lrs[k] * np.sign(gg)) <= slack)[sure].all(), k
 
 
 def test_g5_reference_trajectory_through_engine(device):
