@@ -158,7 +158,7 @@ __device__ __forceinline__ void count_rect_tiles(uint32_t r32, int GX, uint32_t 
 // depth order — are walked by the 64 lanes TOGETHER, one rectangle after the other: a lane that walks 512 tiles alone
 // keeps its wave for 512 dependent LDS atomics (20 us) while 63 lanes wait, and its neighbours' rectangles hit the
 // same words at the same moment (profiles/r05a_bin_tail.txt).
-constexpr uint32_t kBigRect = 48;
+constexpr uint32_t kBigRect = 128;
 __device__ __forceinline__ void count_rect_tiles_wave(uint32_t r32, int GX, uint32_t *s_hist)
 {
     const uint32_t ncols = (r32 >> 9) & 1023u, t = ncols * (r32 >> 25);
@@ -1005,27 +1005,47 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t *const cur = s_cur + w * BINS;
     uint32_t carry = 0u;                          // (owner of the slot before this round) + 1
+    const bool long_wave = S >= 1024u;            // (a wave of far surfels never meets the case below: spare it the test)
     for (uint32_t q0 = 0; q0 < S; q0 += 64u) {
-        if (carry) {
-            // A round whose 64 slots all belong to the surfel the previous round ended in — most rounds of a rectangle of
-            // hundreds of tiles — needs no owner search and no ranking: 64 consecutive tiles of ONE rectangle are 64
-            // different tiles, each takes its tile's cursor as it stands.  (The near end of the depth order at the bench
-            // scene's last keyframes: 222 rounds in the heaviest wave, 9 elsewhere — profiles/r05a_bin_tail.txt.)
+        if (long_wave && carry) {
+            // Rounds whose 64 slots all belong to the surfel the previous round ended in — most rounds of a rectangle of
+            // hundreds of tiles — need no owner search and no ranking: consecutive tiles of ONE rectangle are different
+            // tiles, each takes its tile's cursor as it stands.  And since they are different tiles, four such rounds
+            // read their cursors together before any of them is written back: one LDS round trip per four rounds.
+            // (The near end of the depth order at the bench scene's last keyframes: 222 rounds in the heaviest wave, 9
+            //  elsewhere — profiles/r05a_bin_tail.txt.)
             const uint4 oc = s_lane[w][carry - 1u];
-            const uint32_t ncc = (oc.x >> 9) & 1023u;
-            if (oc.w + ncc * (oc.x >> 25) >= q0 + 64u) {
-                const uint32_t k = q0 + (uint32_t)lane - oc.w;
-                const uint32_t ky = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)ncc));
-                int tx = (int)(oc.x & 511u) + (int)(k - ky * ncc);
-                if (tx >= GX) tx -= GX;
-                const uint32_t tile = (uint32_t)(((int)((oc.x >> 19) & 63u) + (int)ky) * GX + tx);
-                const uint32_t p = cur[tile];
-                cur[tile] = p + 1u;
-                if (p < cap) {
-                    if (PAIRS) bm.out[p] = make_uint2(oc.z, block_mask_of(bm, tile, oc.y));
-                    else vals_out[p] = oc.z;
+            const uint32_t ncc = (oc.x >> 9) & 1023u, end = oc.w + ncc * (oc.x >> 25);
+            if (end >= q0 + 64u) {
+                const float inc = __builtin_amdgcn_rcpf((float)ncc);
+                const int otx = (int)(oc.x & 511u), oty = (int)((oc.x >> 19) & 63u);
+                auto tile_at = [&](uint32_t k) -> uint32_t {
+                    const uint32_t ky = (uint32_t)(((float)k + 0.5f) * inc);
+                    int tx = otx + (int)(k - ky * ncc);
+                    if (tx >= GX) tx -= GX;
+                    return (uint32_t)((oty + (int)ky) * GX + tx);
+                };
+                auto put = [&](uint32_t p, uint32_t tile) {
+                    if (p < cap) {
+                        if (PAIRS) bm.out[p] = make_uint2(oc.z, block_mask_of(bm, tile, oc.y));
+                        else vals_out[p] = oc.z;
+                    }
+                };
+                uint32_t k = q0 + (uint32_t)lane - oc.w;
+                for (; q0 + 256u <= end; q0 += 256u, k += 256u) {
+                    const uint32_t t0 = tile_at(k), t1 = tile_at(k + 64u), t2 = tile_at(k + 128u), t3 = tile_at(k + 192u);
+                    const uint32_t p0 = cur[t0], p1 = cur[t1], p2 = cur[t2], p3 = cur[t3];
+                    cur[t0] = p0 + 1u; cur[t1] = p1 + 1u; cur[t2] = p2 + 1u; cur[t3] = p3 + 1u;
+                    put(p0, t0); put(p1, t1); put(p2, t2); put(p3, t3);
+                }
+                for (; q0 + 64u <= end; q0 += 64u, k += 64u) {
+                    const uint32_t t0 = tile_at(k);
+                    const uint32_t p0 = cur[t0];
+                    cur[t0] = p0 + 1u;
+                    put(p0, t0);
                 }
                 __builtin_amdgcn_wave_barrier();
+                q0 -= 64u;           // (the loop's own increment follows)
                 continue;
             }
         }

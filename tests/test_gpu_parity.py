@@ -434,6 +434,44 @@ def test_hip_against_the_float64_autograd_formulation(device, oracle64, oracle32
         assert np.abs(got - want).max() <= RTOL * np.abs(want).max(), (name, "float32 checker")
 
 
+def test_binning_with_rectangles_that_cover_the_image(device, oracle32, monkeypatch):
+    """VERDICT r04 item 4.  Surfels within a metre of the sensor have tile rectangles of hundreds of tiles (up to all 512
+    at 64x2048) and sit together at the front of the depth order: one wave of bin_direct_kernel then has hundreds of
+    rounds where the others have ten (profiles/r05a_bin_tail.txt).  The kernels count such rectangles with the whole
+    wave and emit their single-owner rounds without ranking; this scene — 20 k surfels from 0.25 m out, 2 300 of them
+    with more than 48 tiles — checks that the lists stay the checker's to the bit: staged calls (gather_count +
+    bin_direct), the one-call path from scratch, and repaired (resort_merge's counting)."""
+    from splat_loam_amd import _abi, rasterizer, synth
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    N, H, W = 20000, 64, 2048
+    sc = synth.make_scene(N, H, W, seed=77, range_lo=0.25, range_hi=20.0, scale_lo=0.03, scale_hi=0.2)
+    view, proj = synth.camera_matrices(sc["K"], synth.keyframe_poses(2)[1])
+    cam = oracle32.camera(H, W, view, proj, tile=_abi.tile_size())
+    oracle32.set_threads(oracle32.max_threads())
+    ost = oracle32.forward(cam, sc["means"], sc["scales"], sc["rots"], sc["opac"])
+    tiles = ost["pre"]["tiles"]
+    assert (tiles > 48).sum() >= 1000 and tiles.max() >= 400, (int((tiles > 48).sum()), int(tiles.max()))
+    for pairs in ("2", "1"):
+        monkeypatch.setenv("SLS_BLOCK_MASKS", pairs)
+        st, t = hip_forward(device, sc, view, proj, H, W, list_pairs=int(pairs))
+        assert st.R == ost["binned"]["R"]
+        assert np.array_equal(u32(st.vals), ost["binned"]["vals"]) and np.array_equal(u32(st.ranges), ost["binned"]["ranges"])
+        assert np.array_equal(st.keys.cpu().numpy().view(np.uint64), ost["binned"]["keys"])
+        # the one-call path: from scratch, then twice repaired (surfels nudged), against the staged image to the bit
+        rasterizer._WS_CACHE.clear()
+        monkeypatch.setenv("SLS_STAGED_FORWARD", "0")
+        settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device), False, False)
+        for it in range(3):
+            means = t["means"] + 1e-4 * it
+            with torch.no_grad():
+                _, a_ws = GaussianRasterizer(raster_settings=settings)(means3D=means, means2D=means, opacities=t["opac"], scales=t["scales"], rotations=t["rots"])
+            sc_it = dict(sc); sc_it["means"] = means.cpu().numpy()
+            st_it, _ = hip_forward(device, sc_it, view, proj, H, W, list_pairs=int(pairs))
+            assert torch.equal(a_ws, st_it.allmap), (pairs, it)
+        ent = next(iter(rasterizer._WS_CACHE.values()))
+        assert ent.stats["repaired"] >= 1, ent.stats
+
+
 def test_cpu_tensors_are_refused():
     from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     s = GaussianRasterizationSettings(8, 16, 1.0, torch.eye(4), torch.eye(4), False, False)
