@@ -63,7 +63,7 @@ typedef float sls_real;
 #define SLS_PIO2 SLS_R(1.57079632679489661923)
 
 /* atan(a) for a in [0,1]:  a * P(a*a), P = degree-8 Chebyshev fit of
- * atan(sqrt(s))/sqrt(s) on s in [0,1] (tools/fit_atan.py). */
+ * atan(sqrt(s))/sqrt(s) on s in [0,1] (a least-squares fit made in round 1; its accuracy is pinned by tests/test_oracle.py::test_det_atan2_accuracy). */
 SLS_HD sls_real sls_atan_unit(sls_real a)
 {
     const sls_real s = a * a;

@@ -27,7 +27,7 @@
 namespace sls {
 
 #ifdef SLS_TRACE
-// Experiment build only (make FAST='$(COMMON) -munsafe-fp-atomics -DSLS_TRACE', tools/wave_trace.py): every wave of
+// Experiment build only (make FAST='$(COMMON) -munsafe-fp-atomics -DSLS_TRACE'; read back with sls_debug_wave_cycles, profiles/r03l_wave_trace*.txt): every wave of
 // the tile kernels records when it ran (100 MHz wall clock), where (HW_ID) and how many rounds / steps it did.
 __device__ uint32_t g_trace[2][8192 * 4];
 // forward: shader clocks a wave spent waiting for the staged records (+ LDS store) / in cull + compaction / in the
@@ -109,7 +109,7 @@ __device__ __forceinline__ void quad_excl_total(float x, float k1, float k2, flo
 // those, 64 per round (round 3: it used to be one 64-bit word per (tile, 64 list positions, block); a backward round
 // then staged 64 records for the ~12 that were marked, and its rounds — wait for the records 2000-2400 shader clocks,
 // mask + list 1000-1200, against 1600 per step — were 28 % of a wave's life at C3 and 40 % at the mapper's real
-// sizes, tools/wave_trace.py).
+// sizes, profiles/r03l_wave_trace.txt).
 // Layout in 8-byte words: [0] tag naming the producer's block shape; [1, 1 + T*8) the blocks' entry counts (u32,
 // T*16 of them); [1 + T*8, 1 + T*16) the launch order of the backward's blocks, most expensive first (u32, written by
 // block_order_kernel behind the staged forward; sls_mapping_step keeps its own, made by the consumer's launch); then

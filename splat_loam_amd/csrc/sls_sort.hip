@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t block_mask_of(const BlockMaskArgs &a, uint32
 // anything else takes the emission + radix pass below.
 // ---------------------------------------------------------------------------
 #ifdef SLS_TRACE
-// Experiment build only (tools/build_variant.sh trace ... -DSLS_TRACE, tools/bin_trace.py): every wave of bin_direct_kernel
+// Experiment build only (tools/build_variant.sh trace ... -DSLS_TRACE; read back with sls_debug_read_bin_trace, profiles/r04f_bin_trace.txt): every wave of bin_direct_kernel
 // and every workgroup of the counting merge records the 100 MHz wall clock at its phases.
 __device__ uint32_t g_bin_trace[32768 * 8];      // per wave: start, loads done, counted, cursors ready, end, rounds, S, (pad)
 __device__ uint32_t g_merge_trace[1024 * 4];     // per workgroup: start, network done, counted + stored, end
@@ -653,7 +653,7 @@ int radix_sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uin
 // ---------------------------------------------------------------------------
 // Temporal re-sort of the depth order.  Between two mapping iterations on the
 // same keyframe a surfel moves by at most ~100 positions in the depth order
-// (tools/order_coherence.py), so instead of three radix passes the previous
+// (measured in round 2: HISTORY.md), so instead of three radix passes the previous
 // permutation is repaired:
 //   A. windows of kResortWindow positions of the OLD order are sorted by
 //      (new key, surfel index) with a bitonic network in LDS;
@@ -1631,7 +1631,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     }
     {
         ScopedTimer tm(T_BIN_DIRECT, st);
-        // (SLS_BIN_SPLIT=2|4: that many workgroups per chunk, for A/B runs.  Measured, tools/bin_trace.py: a wave never has
+        // (SLS_BIN_SPLIT=2|4: that many workgroups per chunk, for A/B runs.  Measured, profiles/r04f_bin_trace.txt: a wave never has
         //  more than 8 rounds at BASELINE config 3 — the launch is its chain of phases, not its heaviest chunk — and
         //  the sub-chunks' extra loads and counts cost more than the split gives: 24.8 / 24.0 / 26.6 us with 1 / 2 / 4)
         static const int split_env = getenv("SLS_BIN_SPLIT") ? atoi(getenv("SLS_BIN_SPLIT")) : 1;

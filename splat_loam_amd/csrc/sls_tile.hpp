@@ -68,7 +68,7 @@ __device__ __forceinline__ bool cull_pass(const float4 q4, float bcx, float bcy,
 // whole block by  G(d0) - |gradG.Dx| - |gradG.Dy| - eps |gradG|_1.  If that is positive no pixel of
 // the block lies in the 3D footprint: a separating-line test whose axis is the footprint's own
 // boundary normal at the block centre — nearly exact for footprints larger than the block, which
-// are the near surfels that dominate the consumed part of every list (tools/sim_lane_use.py:
+// are the near surfels that dominate the consumed part of every list (a CPU simulation of the lanes' use in round 3, HISTORY.md:
 // 31 % fewer evaluated (block, surfel) pairs than the support box alone, 2.5 % above the exact
 // count, nothing missed).  The 2D (low-pass) branch reaches sqrt(kc^2/2) pixels from the centre:
 // tested as the distance from the centre to the block's pixel box.

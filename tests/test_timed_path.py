@@ -254,7 +254,7 @@ def _assert_engine_matches_chain(name, st, g, am, model, raw, own, same, own64=N
         else:
             # At full size (2400-entry lists, 500 k surfels) two float32 evaluations of the same formulas — these
             # kernels and the checker's float32 build — differ by what float32 rounding and summation order cost; the
-            # float64 build says how much that is (tools/c3_noise.py: the float32 checker itself is 0.3..1.7e-5 from
+            # float64 build says how much that is (profiles/r04d_c3_noise.txt: the float32 checker itself is 0.3..1.7e-5 from
             # it).  The engine passes if it meets the bar against the float32 checker, or is as close to the float64
             # checker as the float32 checker is (x1.5) — and the test says which tensors NEEDED that second clause and
             # fails if one did that the caller had not named (`clause_for`: rotations at C3; everything on the tall image,
