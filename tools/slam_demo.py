@@ -120,20 +120,6 @@ def run(H=64, W=1024, n_frames=6, n_iter=60, verbose=True, dev="cuda:0"):
     return dict(losses=losses, errs=errs, fits=fits, depth_err=depth_err, N=eng.N)
 
 
-def _new_surfels(points_world, normals_world, existing_xyz, smax, dev):
-    """Parameters of densified surfels (slam/mapper.py:100-135): scale from distCUDA2 over new + existing
-    centres, normal-aligned rotation, opacity 0.9."""
-    n = normals_world / np.linalg.norm(normals_world, axis=1, keepdims=True)
-    helper = np.where(np.abs(n[:, 2:3]) < 0.9, np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
-    t0 = np.cross(n, helper); t0 /= np.linalg.norm(t0, axis=1, keepdims=True)
-    rots = synth._quat_from_R(np.stack([t0, np.cross(n, t0), n], 2))
-    xyz = torch.tensor(points_world, dtype=torch.float32, device=dev)
-    full = xyz if existing_xyz is None else torch.cat([xyz, existing_xyz.detach()])
-    d2 = torch.clamp(distCUDA2(full), 1e-7, smax ** 2)[:xyz.shape[0]]
-    return SurfelModel.from_activated(xyz, torch.sqrt(d2)[:, None].repeat(1, 2), torch.tensor(rots, dtype=torch.float32),
-                                      torch.full((xyz.shape[0], 1), 0.9), device=str(dev))
-
-
 @_with_pix_offset
 def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=True, dev="cuda:0", out_dir=None,
                  first_stride=None, el_deg=None, densify_percentage=0.15, densify_threshold_opacity=0.5,
@@ -149,7 +135,8 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=Tr
     probability proportional to the log-depth gradient; the first keyframe draws from every valid pixel;
     `first_stride` replaces the draw of the FIRST keyframe by a regular column stride — a denser model than the
     reference's rule builds, kept as a stress option), then engine.remap, `n_iter` iterations over keyframes
-    sampled as Mapper.optimize does (sample_geometric over the keyframe list), pruning (Mapper.prune), engine.remap.
+    sampled as Mapper.optimize does (sample_geometric over the keyframe list), pruning (Mapper.prune) — all three through
+    fused_mapper.update_model, the code behind the SLS_FUSED_MAPPER=1 binding.
     step: (dx, dy, yaw_deg) of the generating trajectory per frame."""
     dev = torch.device(dev)
     rng = np.random.default_rng(0)
@@ -166,56 +153,43 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=Tr
         points = cloud[lut.reshape(-1).clamp_min(0).long()] * valid.reshape(-1, 1)
         return depth, normals, valid, points
 
-    def add_keyframe(model, eng, est_pose, depth, normals, valid, points, first):
+    from types import SimpleNamespace
+    from splat_loam_amd import fused_mapper
+    mcfg = SimpleNamespace(mapping=SimpleNamespace(
+        num_iterations=n_iter - 1, densify_threshold_egeom=densify_threshold_egeom,
+        densify_threshold_opacity=densify_threshold_opacity, densify_percentage=densify_percentage,
+        prob_view_last_keyframe=prob_view_last_keyframe, pruning_min_opacity=pruning_min_opacity, pruning_min_size=0.0,
+        opt_lambda_alpha=cfg.opt_lambda_alpha, opt_lambda_normal=cfg.opt_lambda_normal, opt_scaling_max=cfg.opt_scaling_max,
+        opt_scaling_max_penalty=cfg.opt_scaling_max_penalty), opt=SimpleNamespace(depth_ratio=cfg.depth_ratio))
+    totals = {}
+
+    def add_keyframe(model, est_pose, depth, normals, valid, first):
+        """Mapper.update_model (slam/mapper.py:33-47) for this keyframe: fused_mapper.update_model — densify, n_iter
+        iterations over the keyframes drawn as Mapper.optimize draws them, prune (pinned by golden G7)."""
         cam = Camera(K, depth[None], normals.permute(2, 0, 1), valid[None], est_pose, data_device=str(dev))
-        gen = torch.Generator(device=dev).manual_seed(len(kfs))
+        frm = SimpleNamespace(camera=cam, model_T_frame=torch.tensor(est_pose, dtype=torch.float32, device=dev))
+        kfs.append(frm)
+        drawn = None
         if first and first_stride:
-            mask = valid.clone().bool()
+            drawn = valid.clone().bool()
             if first_stride > 1:
-                keep_cols = torch.zeros(mask.shape[1], dtype=torch.bool, device=dev); keep_cols[::first_stride] = True
-                mask &= keep_cols[None, :]
-        else:
-            pkg = None
-            if not first:
-                with torch.no_grad():
-                    pkg = render(cam, model, cfg.depth_ratio)
-            cand = slam_rules.densify_candidates(cam.image_valid, None if first else pkg["rend_alpha"],
-                                                 None if first else pkg["surf_depth"], cam.image_depth,
-                                                 densify_threshold_opacity, densify_threshold_egeom, initialize_model=first)
-            mask = slam_rules.densify_sample(cand, cam.image_depth, cam.image_valid, densify_percentage, generator=gen)
-            if mask is None:
-                mask = torch.zeros_like(cand)
-        sel = mask.reshape(-1).cpu().numpy().astype(bool)
-        n_new = int(sel.sum())
-        if n_new >= 2:
-            R, t = est_pose[:3, :3], est_pose[:3, 3]
-            pw = points.cpu().numpy()[sel].astype(np.float64) @ R.T + t
-            nw = normals.reshape(-1, 3).cpu().numpy()[sel].astype(np.float64) @ R.T
-            new = _new_surfels(pw, nw, None if first else model._xyz, cfg.opt_scaling_max, dev)
-            if first:
-                model = new
-                eng = MappingEngine(model, cfg)
-            else:
-                for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
-                    setattr(model, name, torch.nn.Parameter(torch.cat([getattr(model, name).detach(), getattr(new, name).detach()]).contiguous()))
-                eng.remap(None, appended=n_new)
-        kfs.append(cam)
-        p = slam_rules.keyframe_probabilities(len(kfs), prob_view_last_keyframe)     # slam/mapper.py:142-149
-        for it in range(n_iter):
-            eng.step(kfs[rng.choice(len(kfs), p=p)], sync="lagged")
-        eng.flush()
-        keep = ~slam_rules.prune_mask(model.get_opacity.detach(), model.get_scaling.detach(), pruning_min_opacity, 0.0)
-        if not bool(keep.all()):
-            for name in ("_xyz", "_scaling", "_rotation", "_opacity"):
-                setattr(model, name, torch.nn.Parameter(getattr(model, name).detach()[keep].contiguous()))
-            eng.remap(keep)
-        return model, eng, cam, n_new, int((~keep).sum())
+                keep_cols = torch.zeros(drawn.shape[1], dtype=torch.bool, device=dev); keep_cols[::first_stride] = True
+                drawn &= keep_cols[None, :]
+        res = fused_mapper.update_model(model, kfs, frm, mcfg, initialize_model=first, drawn=drawn, rng=rng,
+                                        generator=torch.Generator(device=dev).manual_seed(len(kfs) - 1))
+        eng = fused_mapper._ENGINES.get(model)
+        for k_, v_ in (eng[1].stats.items() if eng else ()):
+            totals[k_] = totals.get(k_, 0) + v_
+        return cam, res["added"], int(res["removed"].sum())
 
     kfs, est = [], [gt[0].copy()]
     t0 = time.perf_counter()
-    model, eng, kf_cam, n_new, n_pruned = add_keyframe(None, None, est[0], *frame(0), first=True)
+    empty = lambda w: torch.zeros((0, w), dtype=torch.float32)
+    model = SurfelModel(empty(3), empty(2), empty(4), empty(1), device=str(dev))
+    model.training_setup(fused=True)
+    kf_cam, n_new, n_pruned = add_keyframe(model, est[0], *frame(0)[:3], first=True)
     kf_pose = est[0]
-    log = [(0, n_new, n_pruned, eng.N)]
+    log = [(0, n_new, n_pruned, int(model._xyz.shape[0]))]
     prm = GSAlignerParams(image_height=H, image_width=W)
     al = GSAligner(**prm.__dict__)
 
@@ -242,10 +216,10 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=Tr
             keyframe_threshold_distance)
         if new_kf:
             tracked = 0
-            model, eng, kf_cam, n_new, n_pruned = add_keyframe(model, eng, pose, depth, normals, valid, points, first=False)
+            kf_cam, n_new, n_pruned = add_keyframe(model, pose, depth, normals, valid, first=False)
             kf_pose, kf_T_frame = pose, torch.eye(4, device=dev)
             set_reference(kf_cam)
-            log.append((k, n_new, n_pruned, eng.N))
+            log.append((k, n_new, n_pruned, int(model._xyz.shape[0])))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if out_dir is not None:
         # what SLAM.save_results leaves behind (slam/slam.py:130-170): odom.txt, graph.yaml, models/%04d.ply
@@ -263,8 +237,8 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=Tr
             print(f"keyframe at frame {k}: +{n_new} surfels, -{n_pruned} pruned, model {n}")
         print("pose error per frame [cm]:", " ".join(f"{e[0] * 100:.1f}" for e in errs))
         print(f"{n_frames} frames, {len(kfs)} keyframes in {dt * 1e3:.0f} ms; final error {errs[-1][0] * 100:.2f} cm / {math.degrees(errs[-1][1]):.3f} deg "
-              f"after {np.linalg.norm(gt[-1][:3, 3]):.2f} m; engine stats {eng.stats}")
-    return dict(errs=errs, log=log, N=eng.N, est=est, gt=gt, seconds=dt, stats=dict(eng.stats))
+              f"after {np.linalg.norm(gt[-1][:3, 3]):.2f} m; engine stats {totals}")
+    return dict(errs=errs, log=log, N=int(model._xyz.shape[0]), est=est, gt=gt, seconds=dt, stats=dict(totals))
 
 
 if __name__ == "__main__":
