@@ -32,12 +32,12 @@ from bench_support import log
 
 
 def _timed(dev, fn, n_w, n_t):
-    """ms per call: the best of three timed runs of n_t calls (host-bound loops: one allocator or scheduler hiccup in a
-    run of a hundred calls would otherwise be the figure)"""
+    """ms per call: the best of five timed runs of n_t calls (host-bound loops: one allocator or scheduler hiccup in a
+    run of a hundred calls would otherwise be the figure; between boxes the host-bound rows still differ by a factor)"""
     for _ in range(n_w):
         fn()
     best = float("inf")
-    for _ in range(3):
+    for _ in range(5):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n_t):

@@ -5,10 +5,10 @@ export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
-# per-launch durations of the bench's kernels (which launches of bin_direct are the slow ones: tools/bin_tail.py)
-rm -rf /tmp/prof && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-timing > /tmp/prof.log 2>&1)
-find /tmp/prof -name "*kernel_trace.csv" -exec cp {} gpurun_out/${TAG}_kernel_trace.csv \;
-find /tmp/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_bench_kernel_stats.csv \;
-python tools/bin_tail.py gpurun_out/${TAG}_kernel_trace.csv 2>/dev/null | head -12
-timeout 300 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin); print(d['value'], d['config']['ms_per_iteration'], {k:v['avg_us'] for k,v in d['kernels'].items()})"
+bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1; tail -4 gpurun_out/${TAG}_profile_round.log
+timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -3 gpurun_out/${TAG}_pytest.log
+timeout 120 python tools/g7_probe.py > gpurun_out/${TAG}_g7_probe.txt 2>&1
+# per-launch durations (which launches of bin_direct are the slow ones: tools/bin_tail.py)
+rm -rf /tmp/prof && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-timing > /tmp/prof.log 2>&1)
+find /tmp/prof -name "*kernel_trace.csv" -exec cp {} /tmp/${TAG}_kernel_trace.csv \;
+python tools/bin_tail.py /tmp/${TAG}_kernel_trace.csv > gpurun_out/${TAG}_bin_tail.txt 2>/dev/null; head -11 gpurun_out/${TAG}_bin_tail.txt
