@@ -199,6 +199,7 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
         res["Msplats_per_s_torch_glue"] = round(n2 / (res["iteration_torch_glue_ms"] * 1e-3) / 1e6, 1)
         return res
 
+    rasterizer_alone(False, False)       # (discarded: whatever the process does once — module loads, allocator growth — lands here)
     out = {"all_planes": {**rasterizer_alone(False, False), **iterations(False)},
            "lean_allmap": {**rasterizer_alone(True, False), **iterations(True)},
            "staged_all_planes": rasterizer_alone(False, True)}

@@ -213,9 +213,9 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R,
  * What `GaussianRasterizer` runs by default (gaussian_renderer/__init__.py:26,40-47; slam/mapper.py:201): the kernels
  * of sls_mapping_step behind the staged interface's contract.  The instance buffers are sized for `R_capacity` (the
  * caller's guess: last call's R with head room); the status block (R, bit 0 of `overflow`: capacity too small, bit 1:
- * the repaired depth order was not exact) reaches `status_mirror` (pinned HOST memory, optional) from a launch of its
- * own between the binning and the tile forward, words 0..6 before word 7: the caller arms words 0 and 7 with a value
- * the device never writes (0xFFFFFFFF) and polls them while the tile forward runs; a non-zero `overflow` means the
+ * the repaired depth order was not exact) reaches `status_mirror` (pinned HOST memory, optional) from the first
+ * workgroup of the binning kernel, a few microseconds into it, words 0..6 before word 7: the caller arms words 0 and 7 with a value
+ * the device never writes (0xFFFFFFFF) and polls them while the binning and the tile forward run; a non-zero `overflow` means the
  * outputs are void — repeat with more room resp. with reuse_rounds = 0.
  * depth_order (N uint32, caller-kept PER CAMERA, may be null with reuse_rounds = 0): receives the depth order;
  * reuse_rounds 1..4 repairs the order found there (from this camera's previous call) instead of sorting from scratch

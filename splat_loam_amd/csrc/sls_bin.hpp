@@ -38,7 +38,8 @@ size_t direct_coarse_words(const DevCam &cam, int N);
 int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &db, bool counted, const uint32_t *order,
                       const int32_t *erec_box, const int32_t *rect, const uint32_t *sbox, void *scratch, uint32_t *vals_out,
                       uint32_t *ranges, uint32_t *total_out, uint32_t *overflow, int resort_windows,
-                      const uint64_t *resort_edges, const uint2 **bmask_out, int bmask_mode, hipStream_t st);
+                      const uint64_t *resort_edges, const uint2 **bmask_out, int bmask_mode, hipStream_t st,
+                      uint32_t *status_mirror = nullptr);     // (pinned host memory: the status block, early — sls_forward_ws)
 int launch_depth_order_scan(int N, const float *depth, const uint32_t *tiles, uint32_t *order, uint32_t *offsets,
                             uint32_t *total_out, void *scratch, size_t scratch_bytes, int keys_prefilled,
                             hipStream_t st, int reuse_order = 0, uint32_t *fail_flag = nullptr,

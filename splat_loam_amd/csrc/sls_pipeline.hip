@@ -313,13 +313,7 @@ int sls_backward_det(const SlsCamera *cam, int N, uint64_t R, const float *means
 }
 
 // ---- the drop-in forward without the host read of R --------------------------------------------------------------
-// A tiny launch between the binning and the tile forward: the status block (R, void bits) into pinned host memory, so
-// that the host knows whether the capacity sufficed while the tile forward is still running.
-__global__ void status_mirror_kernel(const uint32_t *status, uint32_t *mirror)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) mirror_status_block(status, mirror);
-}
-
+// (the status block — R, void bits — reaches the caller's pinned host mirror from the first workgroup of bin_direct)
 size_t sls_forward_ws_bytes(int N, int H, int W, uint64_t R_capacity)
 {
     if (N < 0 || H <= 0 || W <= 0) return 0;
@@ -379,12 +373,8 @@ int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const floa
     const uint2 *bmask = nullptr;
     rc = launch_bin_direct(dc, N, cap, db, handoff.counted != 0, order, w.erec, nullptr, nullptr, w.sort_scratch, w.vals,
                            w.ranges, &status_dev->R, &status_dev->overflow, handoff.resort_windows, handoff.resort_edges,
-                           &bmask, list_pairs, st);
+                           &bmask, list_pairs, st, (uint32_t *)status_mirror);      // (the status block leaves from its first workgroup)
     if (rc) return rc;
-    if (status_mirror) {
-        hipLaunchKernelGGL(status_mirror_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)status_dev, (uint32_t *)status_mirror);
-        SLS_LAUNCH_CHECK("status_mirror_kernel");
-    }
     const uint32_t *list = bmask ? (const uint32_t *)bmask : w.vals;
     *sorted_list = list;
     *sorted_stride = bmask ? 2 : 1;

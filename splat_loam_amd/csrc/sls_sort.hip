@@ -860,7 +860,8 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
                                                                   uint32_t *__restrict__ total_out,
                                                                   uint32_t *__restrict__ overflow, int resort_windows,
                                                                   const uint64_t *__restrict__ resort_edges,
-                                                                  uint32_t *__restrict__ fail_flag)
+                                                                  uint32_t *__restrict__ fail_flag,
+                                                                  uint32_t *__restrict__ status_mirror)
 {
     constexpr int BINS = 1 << BITS, TPB = kDirectChunk / SPLIT, WAVES = TPB / 64;
     constexpr int PER = BINS > TPB ? BINS / TPB : 1;          // tiles per thread in the per-tile steps
@@ -996,6 +997,22 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
         }
     }
     __syncthreads();
+    // The drop-in forward (sls_forward_ws): workgroup 0 has just published R and — its threads alone — the two void bits
+    // (capacity too small, repaired order inexact): the status block goes to the caller's pinned host mirror HERE, a
+    // few microseconds into the launch, and the host knows whether the forward stands while the binning and the tile
+    // forward are still running.  (total_out = word 0 of the block; the launch's other workgroups never write it.)
+    if (status_mirror && blockIdx.x == 0 && tid == 0) {
+        __threadfence();
+        // (words written a moment ago by other threads of this workgroup: read where atomics live, not through this CU's L1)
+        const uint32_t w0 = __hip_atomic_load(total_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w1 = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_nontemporal_store(w0, status_mirror + 0);
+        __builtin_nontemporal_store(w1, status_mirror + 1);
+#pragma unroll
+        for (int k = 2; k < 7; ++k) __builtin_nontemporal_store(0u, status_mirror + k);
+        __threadfence_system();
+        __builtin_nontemporal_store(0u, status_mirror + 7);      // (the host polls words 0 and 7: sls_common.hpp, mirror_status_block)
+    }
     SLS_BT(3);
     SLS_BTV(5, (S + 63u) / 64u);
     SLS_BTV(6, S);
@@ -1605,7 +1622,8 @@ DirectBin make_direct_bin(const DevCam &cam, int N, void *sort_scratch, uint2 *s
 int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &db, bool counted, const uint32_t *order,
                       const int32_t *erec_box, const int32_t *rect, const uint32_t *sbox, void *scratch, uint32_t *vals_out,
                       uint32_t *ranges, uint32_t *total_out, uint32_t *overflow, int resort_windows,
-                      const uint64_t *resort_edges, const uint2 **bmask_out, int bmask_mode, hipStream_t st)
+                      const uint64_t *resort_edges, const uint2 **bmask_out, int bmask_mode, hipStream_t st,
+                      uint32_t *status_mirror)
 {
     const int T = cam.GX * cam.GY;
     if (bmask_out) *bmask_out = nullptr;
@@ -1638,7 +1656,7 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
         const int split = (split_env == 2 || split_env == 4) ? split_env : 1;
 #define SLS_DIRECT3(B_, P_, S_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_, S_>), dim3(db.nchunks * S_), dim3(kDirectChunk / S_), 0, st, N, cam.GX, db, \
                                order, (const uint2 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
-                               total_out, overflow, resort_windows, resort_edges, overflow)
+                               total_out, overflow, resort_windows, resort_edges, overflow, status_mirror)
 #define SLS_DIRECT(B_, P_) do { if (split == 1) SLS_DIRECT3(B_, P_, 1); else if (split == 2) SLS_DIRECT3(B_, P_, 2); else SLS_DIRECT3(B_, P_, 4); } while (0)
         if (db.bins == 256) { if (bm.out) SLS_DIRECT(8, true); else SLS_DIRECT(8, false); }
         else { if (bm.out) SLS_DIRECT(9, true); else SLS_DIRECT(9, false); }
