@@ -8,6 +8,7 @@ mkdir -p gpurun_out
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_profile_round.log 2>&1; tail -4 gpurun_out/${TAG}_profile_round.log
 timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -3 gpurun_out/${TAG}_pytest.log
 timeout 120 python tools/g7_probe.py > gpurun_out/${TAG}_g7_probe.txt 2>&1
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 # per-launch durations (which launches of bin_direct are the slow ones: tools/bin_tail.py)
 rm -rf /tmp/prof && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-timing > /tmp/prof.log 2>&1)
 find /tmp/prof -name "*kernel_trace.csv" -exec cp {} /tmp/${TAG}_kernel_trace.csv \;
