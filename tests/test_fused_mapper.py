@@ -136,6 +136,42 @@ def test_g7_optimize_on_the_checker_cpu():
             assert e_max <= (0.0 if k == 0 else 5e-2) and e_999 <= 2e-2 and e_med <= 1e-6, (k, name, e_max, e_999, e_med)
 
 
+def test_adam_state_travels_through_the_optimizer():
+    """fused_optimize's two hand-overs, without a GPU: optimizer.state -> the engine's flat buckets [xyz 3N | opacity N |
+    scaling 2N | rotation 4N] and step count, and back into per-parameter tensors torch's Adam continues from; a
+    parameter without state (after the reference's prune) starts from zeros at step 0; groups at different steps are
+    refused."""
+    N = 5
+    m = SurfelModel(torch.randn(N, 3), torch.randn(N, 2), torch.randn(N, 4), torch.randn(N, 1), device="cpu")
+    m.training_setup(fused=False)
+    params = tuple(getattr(m, fused_mapper._ATTR[g]) for g in fused_mapper.GROUPS)
+    eng = SimpleNamespace(N=N, t=-1, exp_avg=torch.full((10 * N,), 7.0), exp_avg_sq=torch.full((10 * N,), 7.0))
+    fused_mapper._adam_state_in(eng, m.optimizer, params)
+    assert eng.t == 0 and not eng.exp_avg.any() and not eng.exp_avg_sq.any()
+    for p in params:
+        p.grad = torch.randn_like(p)
+    m.optimizer.step(); m.optimizer.step()
+    fused_mapper._adam_state_in(eng, m.optimizer, params)
+    assert eng.t == 2
+    off = 0
+    for name, p in zip(fused_mapper.GROUPS, params):
+        n = p.numel()
+        assert torch.equal(eng.exp_avg[off:off + n].view(p.shape), m.optimizer.state[p]["exp_avg"])
+        assert torch.equal(eng.exp_avg_sq[off:off + n].view(p.shape), m.optimizer.state[p]["exp_avg_sq"])
+        off += n
+    assert off == 10 * N
+    eng.t, eng.exp_avg, eng.exp_avg_sq = 9, torch.arange(10 * N, dtype=torch.float32), torch.arange(10 * N, dtype=torch.float32) * 2
+    fused_mapper._adam_state_out(eng, m.optimizer, params)
+    assert torch.equal(m.optimizer.state[m._opacity]["exp_avg"].reshape(-1), torch.arange(3 * N, 4 * N, dtype=torch.float32))
+    assert torch.equal(m.optimizer.state[m._rotation]["exp_avg_sq"].reshape(-1), torch.arange(6 * N, 10 * N, dtype=torch.float32) * 2)
+    assert all(float(m.optimizer.state[p]["step"]) == 9 for p in params)
+    m.optimizer.step()
+    assert float(m.optimizer.state[m._xyz]["step"]) == 10
+    m.optimizer.state[m._xyz]["step"] = torch.tensor(3.0)
+    with pytest.raises(RuntimeError, match="step counts differ"):
+        fused_mapper._adam_state_in(eng, m.optimizer, params)
+
+
 HOOK_SCRIPT = """
 import os, sys, types
 sys.path.insert(0, {root!r}); sys.path.insert(0, {pkg!r})
@@ -335,3 +371,48 @@ def test_fused_optimize_carries_the_adam_state(device):
         assert float(model.optimizer.state[model._rotation]["step"]) == 10
         finals.append((_rows(model), model.optimizer.state[model._scaling]["exp_avg_sq"].cpu().numpy()))
     assert np.array_equal(finals[0][0], finals[1][0]) and np.array_equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.gpu
+def test_bound_optimize_runs_the_engine(device):
+    """`install()` on a class shaped like the reference's Mapper (`self.model.get_gmodel`, `self.model.keyframes`,
+    `self.cfg`): its `optimize()` then IS fused_optimize — parameters move, the optimizer's state is the engine's, the
+    loop the class came with is never entered — and `uninstall()` gives the class its own method back."""
+    from splat_loam_amd import synth
+    dev = str(device)
+    N, H, W = 2000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=9, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    frames = [SimpleNamespace(camera=Camera(sc["K"], depth, None, valid, p, data_device=dev)) for p in synth.keyframe_poses(3)]
+    gmodel = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=dev)
+    gmodel.training_setup(fused=False)
+
+    class Mapper:
+        entered = 0
+
+        def __init__(self):
+            self.model = SimpleNamespace(get_gmodel=gmodel, keyframes=frames)
+            self.cfg = SimpleNamespace(mapping=SimpleNamespace(num_iterations=7, prob_view_last_keyframe=None, opt_lambda_alpha=0.1,
+                                                               opt_lambda_normal=0.1, opt_scaling_max=0.5, opt_scaling_max_penalty=0.2),
+                                       opt=SimpleNamespace(depth_ratio=0.0))
+
+        def optimize(self):
+            Mapper.entered += 1
+
+    try:
+        assert fused_mapper.install(Mapper)
+        before = gmodel._xyz.detach().clone()
+        np.random.seed(1)
+        assert Mapper().optimize() is None
+        assert Mapper.entered == 0 and not torch.equal(before, gmodel._xyz.detach())
+        st = gmodel.optimizer.state[gmodel._opacity]
+        assert float(st["step"]) == 8 and st["exp_avg_sq"].shape == gmodel._opacity.shape and float(st["exp_avg_sq"].abs().max()) > 0
+        # the state is what torch's own Adam continues from
+        gmodel._xyz.grad = torch.zeros_like(gmodel._xyz)
+        gmodel.optimizer.step()
+        assert float(gmodel.optimizer.state[gmodel._xyz]["step"]) == 9
+    finally:
+        fused_mapper.uninstall()
+    Mapper().optimize()
+    assert Mapper.entered == 1
+
