@@ -225,6 +225,8 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
     out["hooked_mapper"] = {"ms_per_iteration": round(hooked, 4), "engine_ms_per_iteration": round(engine_ms, 4),
                             "ratio": round(hooked / engine_ms, 3), "Msplats_per_s": round(n2 / (hooked * 1e-3) / 1e6, 1)}
     rasterizer._WS_CACHE.clear()
+    del mdl, mdl2, eng
+    torch.cuda.empty_cache()     # (the next size starts from a clean allocator: no 440 MB blocks to carve 4 MB tensors from)
     return out
 
 
