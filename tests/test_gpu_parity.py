@@ -371,8 +371,9 @@ def test_hip_against_the_float64_autograd_formulation(device, oracle64, oracle32
     """VERDICT r04 item 2 (and weak #1): the HIP path against oracle/torch_ref.py directly — a dense float64 torch
     formulation that shares NO arithmetic with the kernels: the textbook ray-plane form x = t d, u = Tu.(x - p)/su instead
     of the kernels' cancellation-free one, torch's own sin / cos / atan2 / norm, gradients from autograd instead of
-    hand-written derivatives (it takes only the non-differentiable integer decisions — tile rectangles, depth order —
-    from the checker's float64 preprocess, which the first assertions compare with the HIP integers).  96 surfels on a
+    hand-written derivatives.  The non-differentiable givens (tile rectangles, depth order, the centre pixel's value) are
+    taken from the HIP forward's own buffers and the ray tables from NumPy, so nothing compiled from include/sls_*.h
+    enters the reference value; the checker only says which pixels are fragile.  96 surfels on a
     32x128 image that wraps; `seed12-seam`: the sensor turned so that the surfels cluster at the azimuth seam.
     Bars (max-norm per plane / tensor, non-fragile pixels, rotations in the tangent space of the unit quaternion; fixed
     numbers, no alternatives): radii / rectangles equal; allmap 2e-5 in both scenes; gradients 2e-5 in the generic scene
@@ -406,7 +407,18 @@ def test_hip_against_the_float64_autograd_formulation(device, oracle64, oracle32
     GX = W // 16
     assert cam.wrap == 1 and (not yaw_deg or ((pre["rect"][vis, 0] + pre["rect"][vis, 1]) > GX).sum() >= 5), "the seam case must have rectangles that wrap"
     leaves = [torch.tensor(a, requires_grad=True) for a in a64]
-    am64 = torch_ref.dense_forward(cam, ost["tables"], pre, *leaves)
+    # What the float64 formulation takes as given comes from the HIP forward ITSELF, not from the checker's C code: the
+    # integer decisions (radii, rectangles, depth keys: just compared) and the surfels' centre pixels out of the kernels'
+    # records; the pixel rays from NumPy (double, rounded once to float as sls_ray_tables defines them).  The checker
+    # contributes the Camera container and the fragile-pixel mask — which pixels are compared, not what they hold.
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (sc["K"][0, 0], sc["K"][1, 1], sc["K"][0, 2], sc["K"][1, 2]))
+    azc, elr = (np.arange(W, dtype=np.float64) - cx) / fx, (np.arange(H, dtype=np.float64) - cy) / fy
+    tables = (np.stack([np.cos(azc), np.sin(azc)], 1).astype(np.float32).astype(np.float64),
+              np.stack([np.cos(elr), np.sin(elr)], 1).astype(np.float32).astype(np.float64))
+    assert np.abs(tables[0] - ost["tables"][0]).max() <= 1e-7 and np.abs(tables[1] - ost["tables"][1]).max() <= 1e-7
+    pre_hip = {"rec": st.rec.cpu().numpy().astype(np.float64), "radii": st.radii.cpu().numpy(), "rect": st.rect.cpu().numpy(),
+               "depth": st.depth.cpu().numpy()}
+    am64 = torch_ref.dense_forward(cam, tables, pre_hip, *leaves)
     ok = ~ost["fwd"]["fragile"]
     am = st.allmap.cpu().numpy().astype(np.float64)
     ref = am64.detach().numpy()
