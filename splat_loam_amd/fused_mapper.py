@@ -20,7 +20,6 @@ import importlib.abc
 import importlib.util
 import os
 import sys
-import weakref
 
 import numpy as np
 import torch
@@ -105,7 +104,13 @@ def prune_model(gmodel, min_opacity: float = 0.0, min_size: float = 0.0) -> torc
 # --------------------------------------------------------------------------------------------------------------
 # the hot stage
 # --------------------------------------------------------------------------------------------------------------
-_ENGINES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_ENGINE_ATTR = "_sls_fused_engine"      # (signature, MappingEngine) kept ON the model: it lives and dies with it
+
+
+def engine_of(gmodel):
+    """The MappingEngine fused_optimize last ran `gmodel` on (None: none yet) — its `.stats` count repeated iterations."""
+    hit = getattr(gmodel, _ENGINE_ATTR, None)
+    return hit[1] if hit is not None else None
 
 
 def _group_of(optimizer, name):
@@ -132,7 +137,7 @@ def _engine_for(gmodel, cfg_map, depth_ratio):
                        opt_scaling_max=float(cfg_map.opt_scaling_max),
                        opt_scaling_max_penalty=float(cfg_map.opt_scaling_max_penalty), depth_ratio=float(depth_ratio))
     sig = (tuple(id(p) for p in params), int(params[0].shape[0]), lrs, betas, eps, tuple(sorted(mc.__dict__.items())))
-    hit = _ENGINES.get(gmodel)
+    hit = getattr(gmodel, _ENGINE_ATTR, None)
     if hit is not None and hit[0] == sig:
         return hit[1]
     for p in params:        # (the engine updates these tensors in place: it needs them as it finds them)
@@ -141,8 +146,8 @@ def _engine_for(gmodel, cfg_map, depth_ratio):
         if p.dtype != torch.float32 or not p.is_contiguous():
             raise RuntimeError("fused_optimize needs contiguous float32 parameters")
     eng = MappingEngine(gmodel, mc, lrs=lrs, betas=betas, eps=eps)
-    _ENGINES[gmodel] = (sig, eng)
-    return eng
+    setattr(gmodel, _ENGINE_ATTR, (sig, eng))      # (model -> engine -> model: a cycle the collector frees with the model;
+    return eng                                     #  a module-level table keyed by the model would keep both alive for ever)
 
 
 def _adam_state_in(eng, optimizer, params) -> None:

@@ -359,9 +359,7 @@ def test_fused_optimize_carries_the_adam_state(device):
         cfg = SimpleNamespace(mapping=SimpleNamespace(num_iterations=(4 if split else 9), prob_view_last_keyframe=0.4,
                                                       opt_lambda_alpha=0.4, opt_lambda_normal=0.5, opt_scaling_max=0.1,
                                                       opt_scaling_max_penalty=1.0), opt=SimpleNamespace(depth_ratio=0.0))
-        fused_mapper._ENGINES.pop(model, None)
-        for eng in ([fused_mapper._engine_for(model, cfg.mapping, 0.0)]):
-            eng.deterministic = True                   # bit-reproducible accumulation: the two runs must agree exactly
+        fused_mapper._engine_for(model, cfg.mapping, 0.0).deterministic = True      # bit-reproducible accumulation: the two runs must agree exactly
         np.random.seed(5)
         fused_mapper.fused_optimize(model, frames, cfg)
         if split:

@@ -33,7 +33,6 @@ for k in range(3):
         np.random.seed(100 + k)
         if tag.startswith("engine"):
             cfg = t._cfg(g)
-            fused_mapper._ENGINES.pop(model, None)
             eng = fused_mapper._engine_for(model, cfg.mapping, 0.0)
             eng.deterministic = tag.endswith("deterministic")
             fused_mapper.fused_optimize(model, frames[:k + 1], cfg)

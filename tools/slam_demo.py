@@ -177,8 +177,8 @@ def run_sequence(H=64, W=1024, n_frames=13, kf_every=None, n_iter=60, verbose=Tr
                 drawn &= keep_cols[None, :]
         res = fused_mapper.update_model(model, kfs, frm, mcfg, initialize_model=first, drawn=drawn, rng=rng,
                                         generator=torch.Generator(device=dev).manual_seed(len(kfs) - 1))
-        eng = fused_mapper._ENGINES.get(model)
-        for k_, v_ in (eng[1].stats.items() if eng else ()):
+        eng = fused_mapper.engine_of(model)
+        for k_, v_ in (eng.stats.items() if eng else ()):
             totals[k_] = totals.get(k_, 0) + v_
         return cam, res["added"], int(res["removed"].sum())
 
