@@ -172,7 +172,8 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
             def fwd_only():
                 with torch.no_grad():
                     rast(means3D=leaves[0], means2D=leaves[0], opacities=leaves[1], scales=leaves[2], rotations=leaves[3])
-            res = {"fwd_ms": round(_timed(dev, fwd_only, warm, iters), 4), "fwd_bwd_ms": round(_timed(dev, fb, warm, iters), 4)}
+            res = {"rasterizer_fwd_ms": round(_timed(dev, fwd_only, warm, iters), 4),
+                   "rasterizer_fwd_bwd_ms": round(_timed(dev, fb, warm, iters), 4)}
             lib.sls_timing_enable(1)
             for _ in range(10):
                 fb()
