@@ -172,8 +172,10 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
             def fwd_only():
                 with torch.no_grad():
                     rast(means3D=leaves[0], means2D=leaves[0], opacities=leaves[1], scales=leaves[2], rotations=leaves[3])
-            res = {"rasterizer_fwd_ms": round(_timed(dev, fwd_only, warm, iters), 4),
-                   "rasterizer_fwd_bwd_ms": round(_timed(dev, fb, warm, iters), 4)}
+            # (forward + backward FIRST, behind a long warm-up: a mapper calls backward() every iteration, and torch's
+            #  autograd device thread answers slowly — +0.05…0.1 ms per call — for a while after a stretch without one)
+            t_fb = _timed(dev, fb, 4 * warm, iters)
+            res = {"rasterizer_fwd_ms": round(_timed(dev, fwd_only, warm, iters), 4), "rasterizer_fwd_bwd_ms": round(t_fb, 4)}
             lib.sls_timing_enable(1)
             for _ in range(10):
                 fb()
@@ -231,8 +233,35 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
     return out
 
 
+def _pin_threads(cores):
+    """Every thread of this process onto `cores` (None: back to what each had).  The drop-in rows are a ping-pong between
+    the Python thread and torch's autograd device thread; on a 256-core host the two land on cores that wake each other
+    in 10 us or in 100, at random per process — the rows were bimodal (0.18 / 0.28 ms at C3).  Four neighbouring cores
+    keep the measurement about the path, not about the scheduler."""
+    saved = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            saved[int(tid)] = os.sched_getaffinity(int(tid))
+            os.sched_setaffinity(int(tid), cores if not isinstance(cores, dict) else cores.get(int(tid), saved[int(tid)]))
+        except OSError:
+            pass
+    return saved
+
+
 def dropin(c):
-    return {f"{c.N}_{c.H}x{c.W}": _dropin_at(c, c.N, c.H, c.W, 30, 10), "50000_64x1024": _dropin_at(c, 50_000, 64, 1024, 50, 20)}
+    saved = None
+    try:
+        mine = sorted(os.sched_getaffinity(0))
+        saved = _pin_threads(set(mine[:4]))
+    except (AttributeError, OSError):
+        pass
+    try:
+        out = {f"{c.N}_{c.H}x{c.W}": _dropin_at(c, c.N, c.H, c.W, 30, 10), "50000_64x1024": _dropin_at(c, 50_000, 64, 1024, 50, 20)}
+    finally:
+        if saved:
+            _pin_threads(saved)
+    out["threads_pinned_to_cores"] = sorted(set(mine[:4])) if saved else None
+    return out
 
 
 def dp_world1(c):
