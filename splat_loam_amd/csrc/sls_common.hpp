@@ -53,8 +53,10 @@ void timer_begin(int slot, hipStream_t st);
 void timer_end(int slot, hipStream_t st);
 struct ScopedTimer {
     int slot; hipStream_t st;
+    bool open = true;
     ScopedTimer(int s, hipStream_t t) : slot(s), st(t) { timer_begin(slot, st); }
-    ~ScopedTimer() { timer_end(slot, st); }
+    void end_now() { if (open) { timer_end(slot, st); open = false; } }
+    ~ScopedTimer() { end_now(); }
 };
 
 #define SLS_HIP_CHECK(expr)                                                         \

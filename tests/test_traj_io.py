@@ -92,3 +92,31 @@ def test_rpe_point_distance_definition():
     assert m < 1e-12
     m, s, _ = rpe_point_distance([pose(k, 1.03) for k in range(60)], gt)
     assert abs(m - 0.03) < 2e-3 and s < 2e-3
+
+
+def test_g8_graph_fields_equal_the_reference_dataclasses(tmp_path):
+    """G8 (tools/make_golden.py:g8): `ResultGraph.from_slam` (scene/postprocessing.py:44-83) run on stand-in local
+    models; graph.yaml written here from the same poses / projection matrix must carry the same fields and numbers.
+    (The reference's TUM / KITTI writers, utils/trajectory_utils.py:185-242, could NOT be run for a fixture: that module
+    imports pytransform3d, which is not installed — odom.txt is covered by the round trips above only.)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_formats.npz"))
+    poses, proj, wTm = g["graph_in_poses"], g["graph_in_proj"], g["graph_in_wTm"]
+    models = [{"id": 0, "world_T_model": np.eye(4, dtype=np.float32), "filename": "results/run0/0000.ply", "frame_ids": [0, 1, 2]},
+              {"id": 1, "world_T_model": wTm, "filename": "results/run0/0001.ply", "frame_ids": [3, 4]}]
+    frames = [{"id": i, "timestamp": 1.7e9 + 0.1 * i, "model_T_frame": poses[i], "projmatrix": proj, "model_id": 0 if i < 3 else 1}
+              for i in range(5)]
+    f = tmp_path / "graph.yaml"
+    traj_io.write_graph(f, models, frames)
+    doc = traj_io.read_graph(f)
+    assert list(doc.keys()) == ["models", "frames"]
+    assert all(list(m.keys()) == list(g["graph_model_fields"]) for m in doc["models"])
+    assert all(list(fr.keys()) == list(g["graph_frame_fields"]) for fr in doc["frames"])
+    assert [m["id"] for m in doc["models"]] == list(g["graph_model_id"])
+    assert [m["filename"] for m in doc["models"]] == list(g["graph_model_filename"])
+    assert [",".join(str(i) for i in m["frame_ids"]) for m in doc["models"]] == list(g["graph_model_frame_ids"])
+    assert np.array_equal(np.array([m["world_T_model"] for m in doc["models"]]), g["graph_model_world_T_model"])
+    assert [fr["id"] for fr in doc["frames"]] == list(g["graph_frame_id"])
+    assert [fr["model_id"] for fr in doc["frames"]] == list(g["graph_frame_model_id"])
+    assert np.array_equal(np.array([fr["timestamp"] for fr in doc["frames"]]), g["graph_frame_timestamp"])
+    assert np.array_equal(np.array([fr["model_T_frame"] for fr in doc["frames"]]), g["graph_frame_model_T_frame"])
+    assert np.array_equal(np.array([fr["projmatrix"] for fr in doc["frames"]]), g["graph_frame_projmatrix"])

@@ -19,6 +19,8 @@ G7  Mapper.update_model stage by stage (slam/mapper.py:33-47: densify -> optimiz
     ray-cast room, 21 iterations each, on the CPU checker, with `distCUDA2` = a brute-force 3-NN: inputs, the
     rendered alpha the densification looks at, the drawn pixels, the drawn keyframes, the surfel set after every
     stage.  Replayed by tests/test_fused_mapper.py (CPU: the cold stages; GPU: the whole thing on MappingEngine).
+G8  on-disk formats: the table GaussianModel.save_ply hands to plyfile (recording stand-in), what GaussianModel.load_ply
+    reads from a file written by ply_io.save_ply, ResultGraph.from_slam's dataclass fields (scene/postprocessing.py)
 """
 import os
 import sys
@@ -354,11 +356,144 @@ def g7():
     np.savez_compressed(os.path.join(OUT, "g7_update_model.npz"), **out)
 
 
+def g8():
+    """On-disk formats, pinned by what the reference's own writers build:
+    (a) GaussianModel.save_ply (scene/gaussian_model.py:123-168) run with a RECORDING stand-in for plyfile
+        (`PlyElement.describe` keeps the structured array it is handed, `PlyData.write` the file name): property
+        names, dtypes and values of the table the reference gives to plyfile;
+    (b) GaussianModel.load_ply (:170-221) run on a file written by THIS repo's ply_io.save_ply, through a stand-in
+        `PlyData.read` (a 20-line header parser of its own, below; `device="cuda"` redirected to the CPU): what the
+        reference reads back from our bytes;
+    (c) ResultGraph.from_slam (scene/postprocessing.py:44-83) on stand-in local models: the dataclass fields.
+    NOT covered: the TUM / KITTI trajectory writers (utils/trajectory_utils.py:185-242) — that module imports
+    pytransform3d at load time, which is not installed here; traj_io's odom.txt is checked against its own reader only."""
+    import dataclasses
+    import hashlib
+    import tempfile
+    from pathlib import Path
+    from types import SimpleNamespace
+    import scene.gaussian_model as gmod
+    from splat_loam_amd import ply_io
+    rec = {}
+
+    class PlyElement:
+        @staticmethod
+        def describe(arr, name):
+            rec["elements"], rec["name"] = np.array(arr, copy=True), name
+            return ("element", name)
+
+    class _Prop:
+        def __init__(self, name):
+            self.name = name
+
+    class _Element:
+        def __init__(self, table):
+            self.table = table
+            self.properties = [_Prop(n) for n in table.dtype.names]
+
+        def __getitem__(self, name):
+            return self.table[name]
+
+    class PlyData:
+        def __init__(self, elements=None):
+            self.elements = elements
+
+        def write(self, filename):
+            rec["filename"] = str(filename)
+
+        @staticmethod
+        def read(path):
+            blob = open(path, "rb").read()
+            end = blob.index(b"end_header\n") + 11
+            head = blob[:end].decode("ascii").split("\n")
+            assert head[0] == "ply" and head[1] == "format binary_little_endian 1.0"
+            n = int(head[2].split()[2])
+            props = [ln.split() for ln in head if ln.startswith("property")]
+            assert all(pr[1] == "float" for pr in props)
+            table = np.frombuffer(blob, dtype=[(pr[2], "<f4") for pr in props], count=n, offset=end)
+            return PlyData([_Element(table)])
+
+    gmod.PlyElement, gmod.PlyData = PlyElement, PlyData
+    rng = np.random.default_rng(8)
+    n = 37
+    raw = {"xyz": rng.normal(size=(n, 3)), "opacity": rng.normal(size=(n, 1)), "scaling": rng.normal(size=(n, 2)),
+           "rotation": rng.normal(size=(n, 4))}
+    raw = {k: v.astype(np.float32) for k, v in raw.items()}
+    gm = gmod.GaussianModel("cpu")
+    gm._xyz = torch.nn.Parameter(torch.tensor(raw["xyz"]))
+    gm._opacity = torch.nn.Parameter(torch.tensor(raw["opacity"]))
+    gm._scaling = torch.nn.Parameter(torch.tensor(raw["scaling"]))
+    gm._rotation = torch.nn.Parameter(torch.tensor(raw["rotation"]))
+    tmp = Path(tempfile.mkdtemp())
+    gm.save_ply(tmp / "models" / "0000.ply")
+    el = rec["elements"]
+    out = {"in_" + k: v for k, v in raw.items()}
+    out["ply_element_name"] = np.array(rec["name"])
+    out["ply_names"] = np.array(list(el.dtype.names))
+    out["ply_dtypes"] = np.array([el.dtype[nm].str for nm in el.dtype.names])
+    out["ply_table"] = np.stack([el[nm] for nm in el.dtype.names], axis=1)          # (n, 13), the table's own dtype (f4)
+    assert rec["filename"].endswith("0000.ply")
+    # (b) the reference's reader on OUR writer's bytes
+    ours = tmp / "ours.ply"
+    ply_io.save_ply(ours, raw["xyz"], raw["opacity"], raw["scaling"], raw["rotation"])
+    out["ours_sha256"] = np.array(hashlib.sha256(open(ours, "rb").read()).hexdigest())
+
+    class _TorchOnCpu:                      # load_ply builds its tensors with device="cuda" (gaussian_model.py:205-220)
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def tensor(data, dtype=None, device=None):
+            return torch.tensor(data, dtype=dtype)
+    gmod.torch = _TorchOnCpu()
+    gm2 = gmod.GaussianModel("cpu")
+    gm2.load_ply(str(ours))
+    gmod.torch = torch
+    for k, attr in (("xyz", "_xyz"), ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation")):
+        out["ref_loaded_" + k] = getattr(gm2, attr).detach().numpy()
+        assert np.array_equal(out["ref_loaded_" + k], raw[k]), k
+    # (c) ResultGraph.from_slam
+    for name in ("open3d",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import scene.postprocessing as pp
+    from splat_loam_amd import synth
+    poses = synth.keyframe_poses(5)
+    K = synth.spherical_K(64, 1024)
+    proj = np.eye(4, dtype=np.float32)
+    proj[:3, :3] = K.T
+
+    def frame(i):
+        return SimpleNamespace(timestamp=1.7e9 + 0.1 * i, model_T_frame=torch.tensor(poses[i], dtype=torch.float32),
+                               camera=SimpleNamespace(projection_matrix=torch.tensor(proj)))
+    wTm = np.eye(4, dtype=np.float32)
+    wTm[:3, 3] = (3.0, -1.0, 0.25)
+    models = [SimpleNamespace(world_T_model=torch.eye(4), keyframes=[frame(0), frame(1), frame(2)]),
+              SimpleNamespace(world_T_model=torch.tensor(wTm), keyframes=[frame(3), frame(4)])]
+    graph = pp.ResultGraph.from_slam(None, models, Path("results/run0"))
+    d = dataclasses.asdict(graph)
+    assert [f.name for f in dataclasses.fields(pp.ResultModel)] == ["id", "world_T_model", "filename", "frame_ids"]
+    assert [f.name for f in dataclasses.fields(pp.ResultFrame)] == ["id", "timestamp", "model_T_frame", "projmatrix", "model_id"]
+    out["graph_model_fields"] = np.array([f.name for f in dataclasses.fields(pp.ResultModel)])
+    out["graph_frame_fields"] = np.array([f.name for f in dataclasses.fields(pp.ResultFrame)])
+    out["graph_in_poses"] = np.stack(poses).astype(np.float32)
+    out["graph_in_proj"], out["graph_in_wTm"] = proj, wTm
+    out["graph_model_id"] = np.array([m["id"] for m in d["models"]])
+    out["graph_model_world_T_model"] = np.array([m["world_T_model"] for m in d["models"]], dtype=np.float64)
+    out["graph_model_filename"] = np.array([str(m["filename"]) for m in d["models"]])
+    out["graph_model_frame_ids"] = np.array([",".join(str(i) for i in m["frame_ids"]) for m in d["models"]])
+    out["graph_frame_id"] = np.array([f["id"] for f in d["frames"]])
+    out["graph_frame_timestamp"] = np.array([f["timestamp"] for f in d["frames"]], dtype=np.float64)
+    out["graph_frame_model_T_frame"] = np.array([f["model_T_frame"] for f in d["frames"]], dtype=np.float64)
+    out["graph_frame_projmatrix"] = np.array([f["projmatrix"] for f in d["frames"]], dtype=np.float64)
+    out["graph_frame_model_id"] = np.array([f["model_id"] for f in d["frames"]])
+    np.savez_compressed(os.path.join(OUT, "g8_formats.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()
         print("wrote", name)
