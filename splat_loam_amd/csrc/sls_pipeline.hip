@@ -472,17 +472,7 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
                      (uint64_t)10 * (uint64_t)N < (1ull << 32)),
                 "reduce-scatter gradient layout: apply_adam = 0, even N, chunk a multiple of 4 covering 10 N");
     const int H = cam->H, W = cam->W;
-#ifdef SLS_ABL_GREC
-    // (experiment build only: the gradient records in an allocation of their own instead of the workspace)
-    MapWs w = carve(N, H, W, R_capacity, workspace, cfg->deterministic != 0);
-    {
-        static float *abl_g = nullptr;
-        if (!abl_g) { if (hipMalloc(&abl_g, (size_t)1 << 28) != hipSuccess) return SLS_E_HIP; (void)hipMemset(abl_g, 0, (size_t)1 << 28); }
-        w.grec = abl_g;
-    }
-#else
     const MapWs w = carve(N, H, W, R_capacity, workspace, cfg->deterministic != 0);
-#endif
     if (workspace_bytes < w.total) {
         set_error("mapping workspace too small: %zu < %zu", workspace_bytes, w.total);
         return SLS_E_SCRATCH;

@@ -21,7 +21,6 @@
 // Survivors of the cull are compacted into a wave-private LDS list (ballot +
 // mbcnt), a step takes the next four.
 #include <cstring>
-#include <type_traits>
 #include "sls_tile.hpp"
 #include "sls_consumer_dev.hpp"
 
@@ -763,6 +762,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 //            fixed-point value reaches 2^50 — the prediction was off by more than 2^22 — sets bit 3 of the iteration's
 //            overflow word: the iteration is void and the caller repeats it with the two launches above.
 // Same kernel otherwise: the result does not depend on the order of the blocks or of the atomics.
+// SLS_ABL_EXTRA (experiment builds only, tools/build_variant.sh ... -DSLS_ABL_EXTRA=k): behind the engine's tile backward a
+// SECOND launch of the same kernel, timed in a slot of its own ("knn" in bench.py's kernel table), with one ingredient
+// changed — k = 1: no atomics (what they cost), k = 2: unchanged, its gradient records into a scratch copy (the control:
+// the production launch's time under the same bracketing).  The iteration's results are not touched.
 #ifdef SLS_ABL_EXTRA
 #define SLS_ABL_PARAM , int abl
 #define SLS_ABL_ARG(v_) , v_
@@ -770,17 +773,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 #define SLS_ABL_PARAM
 #define SLS_ABL_ARG(v_)
 #endif
-// SPLIT (DENSE, DET = 0; the launcher decides, launch_render_bwd_block): a block is a workgroup of TWO waves.  Where the
-// block's compact list holds kSplitMin entries or more, wave 0 walks only its back part [c, cc) and wave 1 the front
-// part [0, c) — after a CHEAP walk over [c, cc) that carries nothing but the transmittance chain and the suffix sum S
-// (the step without its gradient fields, their reduction and the atomic: 0.5 of a step), so that wave 1 enters entry
-// c - 1 with exactly the (T, S) the one-wave walk has there: per-entry gradients are the same bits.  With c = 0.32 cc
-// both waves take about 0.68 of the block's chain.  For when a launch is ONE generation of waves (the mapper's real
-// sizes: 256 tiles x 16 blocks = the GPU's 4096 wave slots) and so lasts as long as its longest block's chain.
-constexpr uint32_t kSplitMin = 96;     // (>= 95: the cut then never falls into the list's short tail round)
-__host__ __device__ inline uint32_t split_point(uint32_t cc) { return ((uint32_t)(0.32f * (float)cc)) & ~3u; }
-template <int BW, int BH, bool LEAN, int FUSED, int DET, bool DENSE, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
+template <int BW, int BH, bool LEAN, int FUSED, int DET, bool DENSE>
+__global__ __launch_bounds__(64) void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
@@ -788,25 +782,19 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
     uint8_t *__restrict__ touched, uint32_t *__restrict__ dbg_cycles, ConsumerArgs ca, int consumer_blocks,
     uint32_t *__restrict__ det_max, unsigned long long *__restrict__ det_acc, const uint32_t *__restrict__ block_order,
     int vstride, const uint8_t *__restrict__ det_prev, const uint32_t *__restrict__ det_gex, uint32_t *__restrict__ det_flag,
-    uint32_t order_tag, uint32_t split_min SLS_ABL_PARAM)
+    uint32_t order_tag SLS_ABL_PARAM)
 {
     static_assert(DET != 3 || DENSE, "the one-pass deterministic accumulation walks the forward's compact lists");
     static_assert(!FUSED || LEAN, "the fused consumer gradient has no median / distortion channel");
-    static_assert(!SPLIT || (DENSE && DET == 0), "two waves per block: on the forward's compact lists, float atomics");
     SLS_TRACE_BEGIN();
-    constexpr int kWaves = SPLIT ? 2 : 1;
-    const int wv = SPLIT ? (int)(threadIdx.x >> 6) : 0;      // SPLIT: wave 0 = the list's back part, wave 1 = its front part
-    if (FUSED == 1 && blockIdx.x == 0 && wv == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
+    if (FUSED == 1 && blockIdx.x == 0) consumer_reduce_partials_wave(ca, consumer_blocks, (int)threadIdx.x);
     static_assert(BW * BH == 16 && kTileW % BW == 0 && kTileH % BH == 0, "16-pixel blocks tiling a tile");
     constexpr int kPerTile = kTilePix / 16, kBX = kTileW / BW;
     // (record 64: all zeros, never active — pads the compacted list to a multiple of four, as in the forward)
-    // (wave-private staging: one set per wave of the workgroup)
-    __shared__ float4 s_rec_w[kWaves][65 * kRec4];
-    __shared__ uint32_t s_list_w[kWaves][64 + 4];   // culling path: the round's survivors; DENSE: its entries' list positions
-    __shared__ uint32_t s_gidx_w[kWaves][65];
+    __shared__ float4 s_rec[65 * kRec4];
+    __shared__ uint32_t s_list[64 + 4];          // culling path: the round's survivors; DENSE: its entries' list positions
+    __shared__ uint32_t s_gidx[65];
     __shared__ uint4 s_ex[DET == 3 ? 65 : 1];    // DET = 3: the predicted-scale bytes (16 fields) of the round's entries
-    float4 *const s_rec = s_rec_w[wv];
-    uint32_t *const s_list = s_list_w[wv], *const s_gidx = s_gidx_w[wv];
     // DENSE: blk_mask is the compact-list hand-over of a forward with the same block shape (the launcher checks what
     // it can, the tag settles it: another producer's buffer is not walked)
     const int T = cam.GX * cam.GY;
@@ -830,7 +818,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
         return;
     }
     const uint64_t t_start = dbg_cycles ? clock64() : 0;
-    const int lane = threadIdx.x & 63, slot = lane & 3, p = lane >> 2;
+    const int lane = threadIdx.x, slot = lane & 3, p = lane >> 2;
     int tile, sub;
     if (block_order && otag == order_tag) {
         // the blocks of this XCD, most expensive first (bwd_block_order_kernel): b -> (XCD b % 8, rank b / 8)
@@ -845,13 +833,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
     const int ty = tile / cam.GX, tx = tile - ty * cam.GX;
     SLS_MARK(1, 0, tile);
     const uint2 range = ranges[tile];
-    // SPLIT: the block's entry count decides whether wave 1 has work; if not it leaves BEFORE the first barrier (the
-    // hardware takes a finished wave out of the workgroup's barrier count) and frees its slot
-    uint32_t split_cc = 0u;
-    if (SPLIT) {
-        split_cc = reinterpret_cast<const uint32_t *>(blk_mask + 1)[tile * kPerTile + sub];
-        if (wv == 1 && split_cc < split_min) return;
-    }
     const int x0 = tx * kTileW + (sub % kBX) * BW, y0 = ty * kTileH + (sub / kBX) * BH;
     const int px = x0 + (p % BW), py = y0 + (p / BW);
     const bool inside = (px < cam.W) && (py < cam.H);
@@ -886,8 +867,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
         else if (lane < 16 + 2 * BW) { qr = y0 + BH; qc = x0 + lane - 16 - BW; }
         else if (lane < 16 + 2 * BW + BH) { qr = y0 + lane - 16 - 2 * BW; qc = x0 - 1; }
         else { qr = y0 + lane - 16 - 2 * BW - BH; qc = x0 + BW; }
-        // (SPLIT: the stage is wave 0's work; wave 1 only meets the two barriers and reads the pieces)
-        const bool has = wv == 0 && lane < kRing && qr >= 0 && qr < cam.H && qc >= 0 && qc < cam.W;
+        const bool has = lane < kRing && qr >= 0 && qr < cam.H && qc >= 0 && qc < cam.W;
         uint32_t bvalid = 0u;      // (the byte as loaded: a comparison here would wait for it before stage 1's loads leave)
         float bal = 0.0f, bN0 = 0.0f, bN1 = 0.0f, bN2 = 0.0f, bgt = 0.0f;
         if (has) {
@@ -913,12 +893,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
             else { dr = 3; dc = lane - 52; }
             const int r = y0 + dr, c = x0 + dc;
             float4 pt = make_float4(0, 0, 0, 0);
-            if (wv == 0 && lane < 60 && r >= 0 && r < cam.H && c >= 0 && c < cam.W) {
+            if (lane < 60 && r >= 0 && r < cam.H && c >= 0 && c < cam.W) {
                 float sd;
                 const float3 pp = surf_point(ca, r, c, sd);
                 pt = make_float4(pp.x, pp.y, pp.z, sd);
             }
-            if (wv == 0 && lane < 60) s_pt[(dr + 2) * 12 + dc + 2] = pt;
+            if (lane < 60) s_pt[(dr + 2) * 12 + dc + 2] = pt;
         }
         // (keeps the byte a register until here: the compiler otherwise compares it where it is loaded — and waits for
         //  it, a full round trip, before stage 1's loads are issued)
@@ -934,13 +914,13 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                             make_float3(pd.x, pd.y, pd.z), make_float3(pr.x, pr.y, pr.z), make_float3(pl.x, pl.y, pl.z),
                             bu, bv, bn, lg, ln, la);
         }
-        if (wv == 0 && lane < kRing) { s_cb[lane] = bu; s_cb[kRing + lane] = bv; s_cb[2 * kRing + lane] = bn; }
+        if (lane < kRing) { s_cb[lane] = bu; s_cb[kRing + lane] = bv; s_cb[2 * kRing + lane] = bn; }
         if (lane >= 16) { lg = 0.0f; ln = 0.0f; la = 0.0f; }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
             lg += __shfl_down(lg, off, 64); ln += __shfl_down(ln, off, 64); la += __shfl_down(la, off, 64);
         }
-        if (wv == 0 && lane == 0) {      // (three arrays, one per term: preprocess_bwd sums them with 16-byte loads)
+        if (lane == 0) {      // (three arrays, one per term: preprocess_bwd sums them with 16-byte loads)
             const size_t nb = (size_t)T * kPerTile, blk = (size_t)(tile * kPerTile + sub);
             ca.partials[blk] = lg; ca.partials[nb + blk] = ln; ca.partials[2 * nb + blk] = la;
         }
@@ -987,9 +967,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
     float Tr = Tf, S = 0.0f;   // replicated over the quad
     // One step: the list entries in slots j (LDS record slot of my quad lane; 64 = the empty padding record) with
     // contributor numbers `contributor`, back to front: slot 0 of a quad holds the LAST entry of the four.
-    // (cheap_tag = std::true_type: SPLIT's cheap walk — the transmittance chain and S only)
-    auto blend_step = [&](const int j, const uint32_t contributor, auto cheap_tag) {
-        constexpr bool CHEAP = decltype(cheap_tag)::value;
+    auto blend_step = [&](const int j, const uint32_t contributor) {
         const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
         const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
         Eval e;
@@ -1026,7 +1004,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
         quad_excl_total(w * gk, k1, k2, k3, Se, St);
         const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
         S += St;
-        if constexpr (CHEAP) return;
         float dL_ddepth = w * dD;
         if (!LEAN) {
             dL_ddepth += w * ddist;
@@ -1057,13 +1034,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
         // (the padding entry is never active: its sums are exact zeros)
         if (DET == 0) {
 #ifdef SLS_ABL_EXTRA
-            // (experiment build only, tools/build_variant.sh: a SECOND launch of the kernel behind the production one,
-            //  timed in a slot of its own, with one ingredient taken out — abl = 1: no atomics)
             if (abl == 1) asm volatile("" :: "v"(tot), "v"(gidx));
-            else if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
-#else
-            if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
+            else
 #endif
+            if (tot != 0.0f) atomicAdd(&grec[(size_t)gidx * kGrec + field], tot);
         } else if (DET == 1) {
             if (tot != 0.0f) atomicMax(&det_max[(size_t)gidx * kGrec + field], __float_as_uint(fabsf(tot)));
         } else if (DET == 2) {
@@ -1089,12 +1063,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                                    + ((size_t)range.x * kPerTile + (size_t)sub * (size_t)n);
         if (cc > 0u) {
             const int nr = (int)((cc + 63u) / 64u);
-            // SPLIT: the cut c (a multiple of four, never inside the short tail round: kSplitMin); round rb holds it — its
-            // slots [0, m) are the entries >= c.  Wave 0 stops there; wave 1 walks [c, cc) cheaply, then [0, c) in full.
-            const bool split = SPLIT && cc >= split_min;
-            const int csplit = split ? (int)split_point(cc) : 0;
-            const int rb = csplit >> 6, msplit = 64 * (rb + 1) - csplit;
-            const int r_lo = (split && wv == 0) ? rb : 0;
             if (lane < kRec4) s_rec[64 * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             SLS_STAGE_DECL
             // The round's entries are STAGED in descending list order (LDS slot j = the round's entry cnt - 1 - j): a step
@@ -1106,7 +1074,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
             SLS_CSTAGE_LOAD_IDX(nr - 1)
             uint2 mine_next = clist[SLS_CENTRY(nr - 1, lane)];      // (list position, surfel) of the entry in slot `lane`
             SLS_WSTAGE_LOAD_REC()
-            if (nr - 1 > r_lo) { SLS_CSTAGE_LOAD_IDX(nr - 2) }
+            if (nr > 1) { SLS_CSTAGE_LOAD_IDX(nr - 2) }
             // DET = 3: the entries' predicted-scale bytes travel one round ahead of their use, like the records: the entry
             // of slot `lane` two rounds ahead (mine_next2) names the surfel whose 16 bytes are requested a round ahead
             uint2 mine_next2 = make_uint2(0u, 0u);
@@ -1117,7 +1085,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                 if (lane == 0) s_ex[64] = make_uint4(0u, 0u, 0u, 0u);
             }
             SLS_PHASE_DECL();
-            for (int r = nr - 1; r >= r_lo; --r) {
+            for (int r = nr - 1; r >= 0; --r) {
                 SLS_PHASE_RESET();
                 SLS_WSTAGE_STORE()
                 if (r == nr - 1) SLS_MARK(1, 3, sp4.x);
@@ -1126,7 +1094,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                 s_gidx[lane] = mine.y;
                 s_list[lane] = mine.x + 1u;              // (the contributor numbers of the round's entries)
                 if (DET == 3) s_ex[lane] = ex_next;
-                if (r > r_lo) {
+                if (r > 0) {
                     SLS_WSTAGE_LOAD_REC()
                     if (DET == 3) {
                         mine_next = mine_next2;
@@ -1135,7 +1103,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                     } else {
                         mine_next = clist[SLS_CENTRY(r - 1, lane)];
                     }
-                    if (r > r_lo + 1) { SLS_CSTAGE_LOAD_IDX(r - 2) }
+                    if (r > 1) { SLS_CSTAGE_LOAD_IDX(r - 2) }
                 }
                 const int cnt = (int)min(64u, cc - (uint32_t)(r * 64));
                 if (lane < 3 * kRec4 && cnt * kRec4 + lane < 64 * kRec4) s_rec[cnt * kRec4 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1145,14 +1113,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
                 __builtin_amdgcn_wave_barrier();
                 SLS_PHASE(0);
                 SLS_PHASE(1);
-                if constexpr (SPLIT) {
-                    const int kcheap = (!split || wv == 0) ? 0 : (r > rb ? cnt : (r == rb ? msplit : 0));
-                    const int kend = (split && wv == 0 && r == rb) ? msplit : cnt;
-                    for (int k = 0; k < kcheap; k += 4) blend_step(k + slot, s_list[k + slot], std::true_type{});
-                    for (int k = kcheap; k < kend; k += 4) blend_step(k + slot, s_list[k + slot], std::false_type{});
-                } else {
-                    for (int k = 0; k < cnt; k += 4) blend_step(k + slot, s_list[k + slot], std::false_type{});
-                }
+                for (int k = 0; k < cnt; k += 4) blend_step(k + slot, s_list[k + slot]);
                 SLS_PHASE(2);
             }
 #undef SLS_CENTRY
@@ -1200,14 +1161,14 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void render_bwd_block_kernel(
             __builtin_amdgcn_wave_barrier();
             for (int k = 0; k < npass; k += 4) {
                 const int j = (int)s_list[k + slot];
-                blend_step(j, (uint32_t)(r * 64 + j + 1), std::false_type{});
+                blend_step(j, (uint32_t)(r * 64 + j + 1));
             }
         }
 #undef SLS_SIDX1
 #undef SLS_SSTAGE_LOAD_IDX
     }
 
-    if (dbg_cycles && lane == 0 && wv == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
+    if (dbg_cycles && lane == 0) dbg_cycles[tile * kPerTile + sub] = (uint32_t)(clock64() - t_start);
     SLS_TRACE_END(1);
 }
 
@@ -1301,21 +1262,9 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
     hipLaunchKernelGGL((render_bwd_block_kernel<BW_, BH_, LEAN_, FUSED_, DET_, DENSE_>), grid, block, 0, st, cam, (const uint2 *)ranges, \
                        vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
                        (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag, order_tag, split_min SLS_ABL_ARG(abl_mode))
+                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag, order_tag SLS_ABL_ARG(abl_mode))
 #define SLS_BWD_BLOCK(BW_, BH_, LEAN_, FUSED_, DET_)                                                                 \
     do { if (dense) SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, true); else SLS_BWD_LAUNCH(BW_, BH_, LEAN_, FUSED_, DET_, false); } while (0)
-    // two waves per block (SPLIT, above) where the launch is at most ONE generation of waves: it then lasts as long as
-    // its longest block's chain, and the second waves find free slots
-#define SLS_BWD_SPLIT(LEAN_, FUSED_)                                                                                 \
-    hipLaunchKernelGGL((render_bwd_block_kernel<8, 2, LEAN_, FUSED_, 0, true, true>), grid, dim3(128), 0, st, cam, (const uint2 *)ranges, \
-                       vals, (const float4 *)rec, (const float2 *)col_cs, (const float2 *)row_cs,                    \
-                       (const float4 *)pix_state, (const uint2 *)pix_contrib, dL_dallmap, grec, block_masks,         \
-                       touched, g_dbg_bwd_cycles, ca, cblocks, det_max, det_acc, block_order, vals_stride, det_prev, det_gex, det_flag, order_tag, split_min SLS_ABL_ARG(abl_mode))
-    static const int split_env = getenv("SLS_BWD_SPLIT") ? atoi(getenv("SLS_BWD_SPLIT")) : -1;
-    static const uint32_t split_min_env = getenv("SLS_BWD_SPLIT_MIN") ? (uint32_t)atoi(getenv("SLS_BWD_SPLIT_MIN")) : kSplitMin;
-    const uint32_t split_min = split_min_env < kSplitMin ? kSplitMin : split_min_env;
-    const bool split = dense && shape == 1 && !det_prev && !det_max &&
-                       (split_env >= 0 ? split_env != 0 : T * (kTilePix / 16) <= 4096);
     if (det_prev) {
         // deterministic accumulation in ONE launch: predicted scales (8x2 kernel on the forward's compact lists only)
         SLS_REQUIRE(det_acc && det_gex && det_flag && shape == 1 && dense, "the one-pass deterministic accumulation needs the 8x2 kernel on the forward's compact lists");
@@ -1333,30 +1282,12 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
         else { SLS_BWD_BLOCK(8, 2, false, 0, 1); SLS_BWD_BLOCK(8, 2, false, 0, 2); }
     } else if (fused_consumer) {
         SLS_REQUIRE(lean && shape == 1, "the fused consumer gradient exists for the lean 8x2 kernel only");
-#if defined(SLS_ABL_EXTRA) && SLS_ABL_EXTRA == 3
-        // (abl = 3: the scratch-copy launch IN FRONT of the production one — is it the position behind the forward that costs?)
-        if (consumer_b_inline && dense) {
-            tm.end_now();
-            static float *abl_grec3 = nullptr;
-            if (!abl_grec3) { if (hipMalloc(&abl_grec3, (size_t)1 << 28) != hipSuccess) return SLS_E_HIP; (void)hipMemsetAsync(abl_grec3, 0, (size_t)1 << 28, st); }
-            float *const keep = grec;
-            { ScopedTimer tm2(T_KNN, st); grec = abl_grec3; abl_mode = 2; SLS_BWD_LAUNCH(8, 2, true, 2, 0, true); }
-            grec = keep; abl_mode = 0;
-            ScopedTimer tm3(T_RENDER_BWD, st);
-            SLS_BWD_LAUNCH(8, 2, true, 2, 0, true);
-            SLS_LAUNCH_CHECK("render_bwd_block_kernel");
-            return SLS_OK;
-        }
-#endif
-        if (split) { if (consumer_b_inline) SLS_BWD_SPLIT(true, 2); else SLS_BWD_SPLIT(true, 1); }
-        else if (consumer_b_inline) SLS_BWD_BLOCK(8, 2, true, 2, 0); else SLS_BWD_BLOCK(8, 2, true, 1, 0);
+        if (consumer_b_inline) SLS_BWD_BLOCK(8, 2, true, 2, 0); else SLS_BWD_BLOCK(8, 2, true, 1, 0);
 #ifdef SLS_ABL_EXTRA
         if (consumer_b_inline && dense) {
             tm.end_now();
             ScopedTimer tm2(T_KNN, st);
             abl_mode = SLS_ABL_EXTRA;
-            // (abl = 2: the unchanged kernel once more — its gradient records into a scratch copy: what a second
-            //  launch gains from the caches the first one left warm)
             static float *abl_grec = nullptr;
             if (abl_mode == 2) {
                 if (!abl_grec) { if (hipMalloc(&abl_grec, (size_t)1 << 28) != hipSuccess) return SLS_E_HIP; (void)hipMemsetAsync(abl_grec, 0, (size_t)1 << 28, st); }
@@ -1365,10 +1296,8 @@ int launch_render_bwd_block(const DevCam &cam, const uint32_t *ranges, const uin
             SLS_BWD_LAUNCH(8, 2, true, 2, 0, true);
         }
 #endif
-    } else if (split) { if (lean) SLS_BWD_SPLIT(true, 0); else SLS_BWD_SPLIT(false, 0); }
-    else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, 0, 0); else SLS_BWD_BLOCK(4, 4, true, 0, 0); }
+    } else if (lean) { if (shape == 1) SLS_BWD_BLOCK(8, 2, true, 0, 0); else SLS_BWD_BLOCK(4, 4, true, 0, 0); }
     else { if (shape == 1) SLS_BWD_BLOCK(8, 2, false, 0, 0); else SLS_BWD_BLOCK(4, 4, false, 0, 0); }
-#undef SLS_BWD_SPLIT
 #undef SLS_BWD_LAUNCH
 #undef SLS_BWD_BLOCK
     SLS_LAUNCH_CHECK("render_bwd_block_kernel");

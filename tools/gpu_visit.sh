@@ -3,4 +3,4 @@ TAG=${1:-r06x}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-SHAPES="170000,64,1024" VARIANTS="SLS_BWD_SPLIT=0 SLS_BWD_SPLIT=1+SLS_BWD_SPLIT_MIN=160 SLS_BWD_SPLIT=1+SLS_BWD_SPLIT_MIN=190 SLS_BWD_SPLIT=1+SLS_BWD_SPLIT_MIN=220 SLS_BWD_SPLIT=1+SLS_BWD_SPLIT_MIN=260" KERNELS=render REPS=2 bash tools/ab_env.sh 2>&1 | tee gpurun_out/${TAG}_ab_split.txt
+for s in "500000 64 2048" "170000 64 1024" "50000 64 1024"; do timeout 120 python tools/fwd_stats.py $s; done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_fwd_stats.txt

@@ -34,7 +34,7 @@ def main():
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + [SRC, "-o", out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     for name, prefix, marker in (("forward step", "_ZN3sls23render_fwd_dense_kernelILi8ELi2ELb0ELb1EE", "v_exp_f32"),
-                                 ("backward step", "_ZN3sls23render_bwd_block_kernelILi8ELi2ELb1ELi2ELi0ELb1ELb0EE", "global_atomic_add_f32")):
+                                 ("backward step", "_ZN3sls23render_bwd_block_kernelILi8ELi2ELb1ELi2ELi0ELb1EE", "global_atomic_add_f32")):
         a = [i for i, l in enumerate(lines) if l.startswith(prefix)][0]
         b = [i for i in range(a, len(lines)) if "s_endpgm" in lines[i]][0]
         seg = lines[a:b]
