@@ -16,6 +16,9 @@ unless stated otherwise.
                        `hooked_mapper`: fused_mapper.fused_optimize — what SLS_FUSED_MAPPER=1 binds Mapper.optimize to
   dp_world1            the keyframe-parallel iteration through RCCL in a ONE-rank group (collectives move a rank's data
                        onto itself): what the exchange adds on one GPU, per scheme; no scaling figure
+  update_model         the reference's unit of work, Mapper.update_model (densify -> 201 iterations -> prune) per keyframe
+                       on a C4-sized local model through fused_mapper.update_model: wall time split into its stages
+                       against 201 x the steady-state iteration
 """
 from __future__ import annotations
 
@@ -289,9 +292,66 @@ def dp_world1(c):
     return out
 
 
+def update_model(c, n0=150_000, h2=128, w2=1024, n_kf=8, new_keyframes=4, num_iterations=200):
+    """The reference's unit of work: `Mapper.update_model` (slam/mapper.py:33-47) = densify -> num_iterations + 1 iterations
+    -> prune, per keyframe, through fused_mapper.update_model on a C4-sized local model (NCD 128x1024,
+    <= 150 k surfels per local model, configs/ncd: densify 15 % of the candidates).  Wall time per keyframe, split into
+    its stages (device synchronised between them), against (num_iterations + 1) x the steady-state iteration."""
+    from splat_loam_amd import fused_mapper, synth
+    from splat_loam_amd.engine import MappingEngine
+    from splat_loam_amd.renderer import depth_to_points
+    from splat_loam_amd.scene import Camera, SurfelModel
+    dev = str(c.dev)
+    sc2 = synth.make_scene(n0, h2, w2, seed=0)
+    d2, v2 = synth.make_targets(h2, w2, sc2)
+    poses = synth.keyframe_poses(n_kf + new_keyframes)
+
+    def frame(k):
+        cam = Camera(sc2["K"], d2, None, v2, poses[k], data_device=dev)
+        pts = depth_to_points(cam, cam.image_depth)                   # sensor frame: the measured normal faces the sensor
+        cam.image_normal = (-pts / pts.norm(dim=0, keepdim=True).clamp_min(1e-9)).contiguous()
+        return SimpleNamespace(camera=cam, model_T_frame=torch.tensor(poses[k], dtype=torch.float32, device=dev))
+    mapping = SimpleNamespace(num_iterations=num_iterations, densify_threshold_egeom=-1.0, densify_threshold_opacity=0.5,
+                              densify_percentage=0.15, prob_view_last_keyframe=0.4, pruning_min_opacity=0.0,
+                              pruning_min_size=0.0, opt_lambda_alpha=c.cfg.opt_lambda_alpha,
+                              opt_lambda_normal=c.cfg.opt_lambda_normal, opt_scaling_max=c.cfg.opt_scaling_max,
+                              opt_scaling_max_penalty=c.cfg.opt_scaling_max_penalty)
+    cfg = SimpleNamespace(mapping=mapping, opt=SimpleNamespace(depth_ratio=0.0))
+    model = SurfelModel.from_activated(sc2["means"], sc2["scales"], sc2["rots"], sc2["opac"], device=dev)
+    model.training_setup(fused=True)
+    frames = [frame(k) for k in range(n_kf + new_keyframes)]
+    keyframes = frames[:n_kf]
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    np.random.seed(0)
+    # warm-up: two whole updates (allocator, kernels' first launches — the first update of a process pays ~0.25 s of them), not reported
+    for _ in range(2):
+        fused_mapper.update_model(model, keyframes, keyframes[-1], cfg, generator=gen)
+    rows = []
+    for k in range(n_kf, n_kf + new_keyframes):
+        keyframes = keyframes[1:] + [frames[k]]
+        torch.cuda.synchronize(c.dev)
+        t0 = time.perf_counter()
+        res = fused_mapper.update_model(model, keyframes, frames[k], cfg, generator=gen, timings=True)
+        torch.cuda.synchronize(c.dev)
+        wall = (time.perf_counter() - t0) * 1e3
+        tm = res["timings_ms"]
+        rows.append({"N": int(model._xyz.shape[0]), "added": int(res["added"]), "wall_ms": round(wall, 3),
+                     **{kk: round(vv, 3) for kk, vv in tm.items()}})
+    # the steady-state iteration on the same model and window (engine alone, keyframes drawn as the mapper draws them)
+    eng = MappingEngine(model, fused_mapper.engine_of(model).cfg)
+    pick = np.random.default_rng(3).choice(n_kf, size=600, p=c.kf_p) if n_kf == c.n_kf else None
+    d, _ = c.run(model, eng, [f.camera for f in keyframes], 200, 400, pick=pick)
+    it_ms = d / 400 * 1e3
+    mean_wall = float(np.mean([r["wall_ms"] for r in rows]))
+    return {"workload": f"{n0} surfels + 15 % of the candidates per keyframe, {h2}x{w2}, window of {n_kf}, num_iterations {num_iterations}",
+            "per_keyframe": rows, "steady_state_ms_per_iteration": round(it_ms, 4),
+            "iterations_alone_ms": round((num_iterations + 1) * it_ms, 3), "mean_wall_ms": round(mean_wall, 3),
+            "wall_over_iterations": round(mean_wall / ((num_iterations + 1) * it_ms), 4)}
+
+
 ALL = {"single_keyframe": single_keyframe, "full_sort": full_sort, "iterations_400_800": iterations_400_800,
        "deterministic": deterministic, "real_sizes": real_sizes, "sparse_union": sparse_union, "dropin": dropin,
-       "dp_world1": dp_world1}
+       "dp_world1": dp_world1, "update_model": update_model}
 
 
 def collect_extras(c, names=None):

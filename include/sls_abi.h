@@ -261,6 +261,33 @@ int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_dept
                          float lambda_normal, float lambda_alpha, int n_valid, float *loss_sums,
                          float *dL_dallmap, void *scratch, size_t scratch_bytes, void *stream);
 
+/* render()'s post-processing alone — what the reference's NO-GRAD callers of gaussian_renderer.render read
+ * (gaussian_renderer/__init__.py:48-93 + utils/graphic_utils.py:26-88; callers: slam/mapper.py:52-54,
+ * slam/tracker.py:173-175, slam/slam.py:81-82, scene/postprocessing.py:162): one launch instead of ~30 torch kernels.
+ *   view_rot9: HOST pointer, world_view_transform[:3,:3] row-major (as a matrix: view frame -> world);
+ *   out: rend_normal (3*H*W, world frame), surf_depth (H*W), surf_normal (3*H*W, world frame, x alpha, zero border);
+ *   rend_alpha / rend_dist are planes 1 / 6 of allmap themselves. */
+int sls_render_maps(int H, int W, const float *allmap, const float *view_rot9, const float *col_cs_half,
+                    const float *row_cs_half, float depth_ratio, float *rend_normal, float *surf_depth,
+                    float *surf_normal, void *stream);
+
+/* Mapper.densify's candidates and sampling weights (slam/mapper.py:51-102 with densify_threshold_egeom <= 0;
+ * utils/graphic_utils.py:91-106): weights_out[H*W] = |central differences of log(depth)| at the valid pixels rendered
+ * with alpha <= threshold_opacity (rend_alpha = NULL: at every valid pixel — a model's first keyframe), 0 elsewhere;
+ * stats_out (4 words, device): [#candidates, float bits of the gradient's maximum over the image, float sum of the
+ * weights, 0].  valid: uint8, 1 = valid. */
+int sls_densify_weights(int H, int W, const float *image_depth, const uint8_t *valid, const float *rend_alpha,
+                        float threshold_opacity, float *weights_out, uint32_t *stats_out, void *stream);
+
+/* Mapper.densify's new rows (slam/mapper.py:104-137) for n drawn pixels (row-major indices, int64 as torch's nonzero
+ * leaves them): centres = the measured points in the model frame, rotations = unit quaternions (w,x,y,z; w >= 0) whose
+ * third axis is the measured normal (utils/general_utils.py:85-187).  All pointers DEVICE; cam_to_model16 =
+ * inv(world_view_transform^T), model_T_frame16 = the keyframe's pose in the model, both row-major 4x4.  Scales (3-NN,
+ * sls_knn_dist2) and opacity (0.9) are the caller's. */
+int sls_densify_rows(int n, int H, int W, const int64_t *pixels, const float *image_depth, const float *image_normal,
+                     const float *col_cs_half, const float *row_cs_half, const float *cam_to_model16,
+                     const float *model_T_frame16, float *xyz_out, float *quat_out, void *stream);
+
 /* ---- one whole mapping iteration, enqueued without any host sync -----------
  * slam/mapper.py:150-204 for one keyframe: activations (scene/gaussian_model.py:
  * 39-44) -> rasterizer forward -> sls_consumer_fwd_bwd -> rasterizer backward ->
@@ -495,6 +522,11 @@ int sls_adam_step_sparse(int N, float *xyz, float *opacity_raw, float *scaling_r
 size_t sls_knn_scratch_bytes(int M);
 int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes,
                   void *stream);
+/* The same for the FIRST M_first points only (out: M_first floats), neighbours searched among all M: what Mapper.densify
+ * keeps of `distCUDA2(cat(new, existing))` (slam/mapper.py:109-117 reads `[:n_new]`).  Same values as sls_knn_dist2's
+ * first M_first; the search runs only for the waves of the sorted curve that hold a query. */
+int sls_knn_dist2_first(int M, int M_first, const float *xyz, float *out, void *scratch, size_t scratch_bytes,
+                        void *stream);
 
 /* visible[i] = 1 if surfel centre i survives the near cut (radii would be >0
  * unless it is off-image). */

@@ -80,6 +80,9 @@ _PROTOS = {
     "sls_camera_from_matrices": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.POINTER(SlsCamera)]),
     "sls_ray_tables": (C.c_int, [C.POINTER(SlsCamera), _VP, _VP]),
     "sls_ray_tables_at": (C.c_int, [C.POINTER(SlsCamera), C.c_float, C.c_float, _VP, _VP]),
+    "sls_render_maps": (C.c_int, [C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),
+    "sls_densify_rows": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_VP] * 10),
+    "sls_densify_weights": (C.c_int, [C.c_int, C.c_int, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),
     "sls_consumer_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sls_consumer_fwd_bwd": (C.c_int, [C.c_int, C.c_int] + [_VP] * 5 + [C.c_float] * 3 + [C.c_int, _VP, _VP, _VP,
                                                                                          C.c_size_t, _VP]),
@@ -121,6 +124,7 @@ _PROTOS = {
                                         _VP, C.c_size_t, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "sls_knn_dist2_first": (C.c_int, [C.c_int, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),
     "sls_aligner_workspace_bytes": (C.c_size_t, []),
     "sls_aligner_normals": (C.c_int, [C.POINTER(SlsCamera), _VP, _VP, C.c_float, _VP, _VP]),

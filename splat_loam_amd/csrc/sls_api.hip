@@ -86,8 +86,14 @@ int launch_consumer(int H, int W, const float *allmap, const float *gt_depth, co
                     hipStream_t st, bool sums_zeroed = false, struct ConsumerArgs *args_out_skip_c = nullptr,
                     int order_tiles = 0, const uint32_t *block_cost = nullptr, uint32_t *block_order = nullptr,
                     bool no_launch = false);
+int launch_render_maps(int H, int W, const float *allmap, const float *rot9, const float *col_h, const float *row_h,
+                       float depth_ratio, float *rend_normal, float *surf_depth, float *surf_normal, hipStream_t st);
+int launch_densify_weights(int H, int W, const float *depth, const uint8_t *valid, const float *alpha, float thr, float *w_out,
+                           uint32_t *stats, hipStream_t st);
+int launch_densify_rows(int n, int H, int W, const int64_t *pix, const float *depth, const float *normal, const float *col_h,
+                        const float *row_h, const float *c2w, const float *mTf, float *xyz, float *quat, hipStream_t st);
 size_t knn_scratch_bytes(int M);
-int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st);
+int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st, int Mq = -1);
 
 // ---------------------------------------------------------------------------
 // P6 fused Adam: every parameter tensor of the model in ONE launch.
@@ -332,6 +338,37 @@ int sls_consumer_fwd_bwd(int H, int W, const float *allmap, const float *gt_dept
                            (hipStream_t)stream);
 }
 
+int sls_render_maps(int H, int W, const float *allmap, const float *view_rot9, const float *col_cs_half,
+                    const float *row_cs_half, float depth_ratio, float *rend_normal, float *surf_depth,
+                    float *surf_normal, void *stream)
+{
+    SLS_REQUIRE(H > 0 && W > 0, "bad size");
+    SLS_REQUIRE(allmap && view_rot9 && col_cs_half && row_cs_half && rend_normal && surf_depth && surf_normal, "null pointer");
+    return launch_render_maps(H, W, allmap, view_rot9, col_cs_half, row_cs_half, depth_ratio, rend_normal, surf_depth,
+                              surf_normal, (hipStream_t)stream);
+}
+
+int sls_densify_weights(int H, int W, const float *image_depth, const uint8_t *valid, const float *rend_alpha,
+                        float threshold_opacity, float *weights_out, uint32_t *stats_out, void *stream)
+{
+    SLS_REQUIRE(H > 0 && W > 0, "bad size");
+    SLS_REQUIRE(image_depth && valid && weights_out && stats_out, "null pointer");
+    return launch_densify_weights(H, W, image_depth, valid, rend_alpha, threshold_opacity, weights_out, stats_out,
+                                  (hipStream_t)stream);
+}
+
+int sls_densify_rows(int n, int H, int W, const int64_t *pixels, const float *image_depth, const float *image_normal,
+                     const float *col_cs_half, const float *row_cs_half, const float *cam_to_model16,
+                     const float *model_T_frame16, float *xyz_out, float *quat_out, void *stream)
+{
+    SLS_REQUIRE(n >= 0 && H > 0 && W > 0, "bad size");
+    if (n == 0) return SLS_OK;
+    SLS_REQUIRE(pixels && image_depth && image_normal && col_cs_half && row_cs_half && cam_to_model16 && model_T_frame16 &&
+                    xyz_out && quat_out, "null pointer");
+    return launch_densify_rows(n, H, W, pixels, image_depth, image_normal, col_cs_half, row_cs_half, cam_to_model16,
+                               model_T_frame16, xyz_out, quat_out, (hipStream_t)stream);
+}
+
 size_t sls_knn_scratch_bytes(int M) { return knn_scratch_bytes(M); }
 
 int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, void *stream)
@@ -340,6 +377,14 @@ int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scr
     if (M == 0) return SLS_OK;
     SLS_REQUIRE(xyz && out && scratch, "null pointer");
     return launch_knn(M, xyz, out, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int sls_knn_dist2_first(int M, int M_first, const float *xyz, float *out, void *scratch, size_t scratch_bytes, void *stream)
+{
+    SLS_REQUIRE(M >= 0 && M_first >= 0 && M_first <= M, "bad sizes");
+    if (M == 0 || M_first == 0) return SLS_OK;
+    SLS_REQUIRE(xyz && out && scratch, "null pointer");
+    return launch_knn(M, xyz, out, scratch, scratch_bytes, (hipStream_t)stream, M_first);
 }
 
 int sls_mark_visible(const SlsCamera *cam, int N, const float *means3D, uint8_t *visible, void *stream)

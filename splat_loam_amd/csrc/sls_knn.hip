@@ -222,7 +222,7 @@ __device__ __forceinline__ float wave_max(float v)
 
 __global__ __launch_bounds__(64) void knn_query_kernel(int M, int nboxes, const float4 *__restrict__ pts,
                                                        const float4 *__restrict__ boxes,
-                                                       const float4 *__restrict__ subboxes, float *__restrict__ out)
+                                                       const float4 *__restrict__ subboxes, float *__restrict__ out, uint32_t Mq)
 {
     constexpr int kSubs = kKnnBox / kKnnSub;            // 8 sub-boxes per box
     __shared__ float4 s_run[kKnnSub];                   // wave-private: the workgroup IS one wave
@@ -230,8 +230,12 @@ __global__ __launch_bounds__(64) void knn_query_kernel(int M, int nboxes, const 
     __shared__ uint32_t s_sub[64 * kSubs];
     const int lane = threadIdx.x;
     const int q = blockIdx.x * 64 + lane;
-    const bool live = q < M;
-    const float4 me = pts[live ? q : M - 1];
+    const float4 me = pts[q < M ? q : M - 1];
+    // Mq < M (sls_knn_dist2_first): only the points whose ORIGINAL index is below Mq are queries — Mapper.densify asks
+    // for the new surfels' distances among new + existing centres (slam/mapper.py:109-117) and drops the rest.  A wave
+    // of 64 neighbours on the curve without one leaves; the others search exactly as they would
+    const bool live = q < M && __float_as_uint(me.w) < Mq;
+    if (!__ballot(live)) return;
     const int own_box = (blockIdx.x * 64) / kKnnBox, own_sub0 = (blockIdx.x * 64) / kKnnSub;   // my runs: own_sub0, +1
     const int nsub = (M + kKnnSub - 1) / kKnnSub;
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
@@ -392,7 +396,7 @@ static KnnScratch knn_layout(int M, void *base)
 
 size_t knn_scratch_bytes(int M) { return M > 0 ? knn_layout(M, nullptr).total : 0; }
 
-int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st)
+int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratch_bytes, hipStream_t st, int Mq)
 {
     const KnnScratch s = knn_layout(M, scratch);
     if (scratch_bytes < s.total) {
@@ -421,7 +425,8 @@ int launch_knn(int M, const float *xyz, float *out, void *scratch, size_t scratc
                        which ? s.vals_tmp : s.vals, s.pts, s.boxes, s.subboxes);
     SLS_LAUNCH_CHECK("knn_gather_boxes_kernel");
     static_assert(kKnnBox == 256 && kKnnSub == 32, "the query kernel's lane mappings are written for 8 runs of 32");
-    hipLaunchKernelGGL(knn_query_kernel, dim3((M + 63) / 64), dim3(64), 0, st, M, nboxes, s.pts, s.boxes, s.subboxes, out);
+    hipLaunchKernelGGL(knn_query_kernel, dim3((M + 63) / 64), dim3(64), 0, st, M, nboxes, s.pts, s.boxes, s.subboxes, out,
+                       (uint32_t)(Mq < 0 || Mq > M ? M : Mq));
     SLS_LAUNCH_CHECK("knn_query_kernel");
     return SLS_OK;
 }

@@ -413,6 +413,10 @@ int sls_backward_ws(const SlsCamera *cam, int N, const float *means3D, const flo
     const int T = dc.GX * dc.GY;
     const bool order_bwd = block_order != nullptr && block_masks_shape == 3 && debug_state().bwd_variant == 3 &&
                            T % 32 == 0 && kTileW == 16 && kTileH == 16;
+    // (a tile-kernel variant switched between forward and backward — sls_debug_variant — is no lost gradient: the launcher
+    //  walks the forward's compact lists only when block_masks_shape names the backward's own shape, otherwise the
+    //  backward culls the tiles' lists itself; the kernel's tag check is a last guard against a FOREIGN buffer, which the
+    //  workspace lease rules out on this path)
     int rc = launch_render_bwd(dc, w.ranges, sorted_list, w.rec, col_cs, row_cs, w.pix_state, w.pix_contrib, dL_dallmap,
                                w.grec, st, block_masks_shape ? w.block_masks : nullptr,
                                (cam->flags & SLS_CAM_LEAN_ALLMAP) != 0, w.touched, nullptr, nullptr, nullptr,

@@ -1001,6 +1001,11 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     // (capacity too small, repaired order inexact): the status block goes to the caller's pinned host mirror HERE, a
     // few microseconds into the launch, and the host knows whether the forward stands while the binning and the tile
     // forward are still running.  (total_out = word 0 of the block; the launch's other workgroups never write it.)
+    // INVARIANT this snapshot rests on (words 2..6 go out as zeros): on the drop-in path every void bit is raised IN FRONT
+    // of this point — bit 0 three lines up by this workgroup, bit 1 by the counting merge, a launch earlier — and nothing
+    // behind it (the other workgroups of this launch, the tile forward) writes the status block.  A check added later
+    // must either sit in front of it or be read from the device's block (rasterize_forward_ws re-reads that block under
+    // settings.debug and raises on a difference).
     if (status_mirror && blockIdx.x == 0 && tid == 0) {
         __threadfence();
         // (words written a moment ago by other threads of this workgroup: read where atomics live, not through this CU's L1)

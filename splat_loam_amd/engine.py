@@ -186,12 +186,14 @@ class MappingEngine:
     def _ensure_workspace(self, H, W, capacity):
         lib = _abi.lib()
         if (self.workspace is None or capacity > self.capacity or (H, W) != self._ws_hw
-                or self._ws_det != bool(self.deterministic)):
+                or self._ws_det != bool(self.deterministic) or self.N > getattr(self, "_ws_n", 0)):
             self._ws_det = bool(self.deterministic)
             self.capacity, self._ws_hw = int(max(capacity, self.capacity)), (H, W)   # (keyframes of another size: re-carve)
             wcfg = _abi.SlsMappingConfig()
             wcfg.deterministic = 1 if self.deterministic else 0     # (the fixed-point accumulators only when asked for)
-            nbytes = int(lib.sls_mapping_workspace_bytes_cfg(self.N, H, W, self.capacity, C.byref(wcfg)))
+            # (sized for a quarter more surfels than there are: resize() keeps it while the model grows into that room)
+            self._ws_n = self.N + (self.N // 4 if getattr(self, "_bucket_store", None) is not None else 0)
+            nbytes = int(lib.sls_mapping_workspace_bytes_cfg(self._ws_n, H, W, self.capacity, C.byref(wcfg)))
             self.workspace = None     # release before re-allocating
             self.workspace = torch.empty((nbytes + 256,), dtype=torch.uint8, device=self.dev)
             self._ws_ready = False
@@ -808,6 +810,40 @@ class MappingEngine:
         self._orders.clear()                         # surfel indices changed: every kept depth order is void
         self._det_prev.clear()                       # ... and so is every predicted scale
         self._det_two_pass_next = True
+        self._params()
+
+    @torch.no_grad()
+    def resize(self, n_new: int) -> None:
+        """The surfel set changed size and the caller brings the optimiser state itself (fused_mapper.fused_optimize reads
+        it from optimizer.state before every run, as the reference's densify / prune helpers leave it): everything that
+        does not depend on N stays — the pinned status mirrors, the events, the keyframes' launch orders of the tile
+        backward — and what does is re-used while it is large enough (buckets, workspace and depth-order buffers are
+        allocated with a quarter of head room: a local model grows by < 1 % per keyframe).  Depth orders are void
+        (surfel indices moved); moments and step count are whatever the caller writes next.  Single-GPU path only."""
+        if self._lag_pending is not None or self._lag_ready:
+            self.flush()
+        if self._dp is not None or self._sx is not None:
+            raise RuntimeError("resize() is for the single-GPU engine; keyframe-parallel state is laid out by N: use remap()")
+        n_new = int(n_new)
+        if int(self.model._xyz.shape[0]) != n_new:
+            raise RuntimeError(f"the model holds {int(self.model._xyz.shape[0])} surfels, not {n_new}")
+        n10 = 10 * n_new
+        store = getattr(self, "_bucket_store", None)
+        if store is None or store[0].numel() < n10 + 2:
+            room = n10 + n10 // 4 + 2
+            store = [torch.zeros((room,), dtype=torch.float32, device=self.dev) for _ in range(3)]
+            self._bucket_store = store
+        self.grads, self.exp_avg, self.exp_avg_sq = store[0][:n10 + 2], store[1][:n10], store[2][:n10]
+        self.grads.zero_()
+        self.N, self.t = n_new, 0
+        self._set_order_ages()
+        for ent in self._orders.values():
+            ent[1] = None                                   # the order itself: from scratch at the keyframe's next visit
+            if ent[0].numel() < n_new:
+                ent[0] = torch.empty((n_new + n_new // 4,), dtype=torch.int32, device=self.dev)
+        self._det_prev.clear()
+        self._det_two_pass_next = True
+        self._ws_ready = False                              # (the records' region moved with N: zeroed at the next step)
         self._params()
 
     def allmap(self, H, W) -> torch.Tensor:

@@ -72,7 +72,7 @@ def set_pix_offset(ox: float, oy: float) -> None:
 # while the entry is alive.
 # ---------------------------------------------------------------------------
 class _CamEntry:
-    __slots__ = ("cam", "col_cs", "row_cs", "view_ref", "proj_ref")
+    __slots__ = ("cam", "col_cs", "row_cs", "view_ref", "proj_ref", "rot9", "half", "c2w")
 
 
 _CAM_CACHE: "OrderedDict[tuple, _CamEntry]" = OrderedDict()
@@ -126,10 +126,24 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
     e.cam.flags = 1 if lean else 0            # SLS_CAM_LEAN_ALLMAP
     e.col_cs, e.row_cs = _ray_tables(e.cam, device)
     e.view_ref, e.proj_ref = v, p
+    e.rot9 = (C.c_float * 9)(*[float(x) for x in vh[:3, :3].reshape(-1)])   # view frame -> world, as a matrix (render_maps)
+    e.half = None                                                              # the (c - .5, r - .5) ray tables, made when asked for
+    e.c2w = None                                                               # inv(view^T) on the device (fused_mapper's densify), likewise
     _CAM_CACHE[key] = e
     while len(_CAM_CACHE) > _CAM_CACHE_MAX:
         _CAM_CACHE.popitem(last=False)
     return e
+
+
+def half_pixel_tables(e: _CamEntry, device: torch.device):
+    """The ray tables of the consumer's back-projection convention, pixel (c, r) at (c - 0.5, r - 0.5)
+    (utils/graphic_utils.py:46-49), cached with the camera entry."""
+    if e.half is None:
+        col = torch.empty((e.cam.W, 2), dtype=torch.float32)
+        row = torch.empty((e.cam.H, 2), dtype=torch.float32)
+        _abi.check(_abi.lib().sls_ray_tables_at(C.byref(e.cam), -0.5, -0.5, col.data_ptr(), row.data_ptr()), "sls_ray_tables_at")
+        e.half = (col.to(device), row.to(device))
+    return e.half
 
 
 def _stream(device: torch.device) -> int:
@@ -357,7 +371,7 @@ class _WsEntry:
     """Per (device, N, H, W, flags): one workspace, the status block + its pinned mirror, the capacity guess; per
     camera (the matrix-cache key): the depth order of its last call."""
     __slots__ = ("ws", "ws_ptr", "ws_bytes", "cap", "ready", "busy", "status", "mirror", "mirror_np", "orders", "calls",
-                 "rounds", "rounds_until", "stats")
+                 "rounds", "rounds_until", "stats", "stream", "cap_hint")
 
 
 _WS_CACHE: "OrderedDict[tuple, _WsEntry]" = OrderedDict()
@@ -385,14 +399,30 @@ def _ws_entry(dev, N, H, W, lean) -> _WsEntry:
     e.mirror_np = e.mirror.numpy()
     e.orders, e.calls, e.rounds, e.rounds_until = OrderedDict(), 0, 1, 0
     e.stats = {"too_small": 0, "repair_failed": 0, "from_scratch": 0, "repaired": 0}
+    e.stream, e.cap_hint = None, 0
     # (the surfel set changed — Mapper.densify / prune between keyframes: the old size's workspace will not be asked
-    #  for again; one still held by a forward awaiting its backward stays until that has run)
-    for old in [k for k, v in _WS_CACHE.items() if k[0] == key[0] and k[2:] == key[2:] and k[1] != N and not v.busy]:
-        del _WS_CACHE[old]
+    #  for again; one still held by a forward awaiting its backward stays until that has run.  What the old size
+    #  learned about the scene — instances per surfel — sizes the new one: a first forward that overflows runs twice)
+    for old in [k for k, v in _WS_CACHE.items() if k[0] == key[0] and k[2:] == key[2:] and k[1] != N]:
+        seen = _WS_CACHE[old].stats.get("R")
+        if seen:
+            e.cap_hint = max(e.cap_hint, int(1.3 * seen * N / max(old[1], 1)) + 1024)
+        if not _WS_CACHE[old].busy:
+            del _WS_CACHE[old]
     _WS_CACHE[key] = e
     while len(_WS_CACHE) > _WS_CACHE_MAX:
         _WS_CACHE.popitem(last=False)
     return e
+
+
+_WARNED = set()
+
+
+def _warn_once(key, text) -> None:
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(text, RuntimeWarning, stacklevel=3)
 
 
 def _ws_alloc(e: _WsEntry, dev, N, H, W, cap) -> None:
@@ -426,11 +456,22 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
     if T > 512 or cam.tile_cull_min >= 2:
         return None
     e = _ws_entry(dev, N, H, W, bool(cam.flags & 1))
-    if e.busy:
-        return None
     st = _stream(dev)
+    if e.busy:
+        # a forward of this size still waits for its backward (a loss kept alive, or two renders before one backward):
+        # the staged path serves this call — correct, slower; say so once, it is easy to hold a graph by accident
+        _warn_once("busy", "GaussianRasterizer: the workspace of this (N, H, W) is held by an earlier forward whose "
+                           "backward has not run; this call takes the staged path (slower).  Drop or backward() the "
+                           "earlier result to get the one-call path back.")
+        return None
+    if e.stream is not None and e.stream != st:
+        # the workspace's buffers are ordered by ONE stream; a call on another one has no dependency on what still runs there
+        _warn_once("stream", "GaussianRasterizer: called on another stream than the one its workspace belongs to; this "
+                             "call takes the staged path.")
+        return None
+    e.stream = st
     if e.ws is None:
-        _ws_alloc(e, dev, N, H, W, max(4 * N, 1 << 16))
+        _ws_alloc(e, dev, N, H, W, max(4 * N, 1 << 16, e.cap_hint))
     # the camera's previous depth order (the matrix cache's key says "same camera"): repaired while young enough, with
     # MappingEngine's ages (a repair that does not reach the exact order voids the forward, which is then repeated
     # from scratch — the caller never sees an inexact list)
@@ -492,6 +533,13 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
     ent[1] = e.calls
     if settings.debug:
         torch.cuda.synchronize(dev)
+        # the early mirror is a snapshot taken by bin_direct's first workgroup (words 0 and 1): nothing behind that point
+        # may raise a void bit (sls_sort.hip states the invariant where the bits are set) — checked here against the
+        # device's own status block once everything has run
+        final = e.status.cpu().numpy()
+        if (int(final[0]) & 0xFFFFFFFF) != R or int(final[1]) != 0:
+            raise RuntimeError(f"sls_forward_ws: the status block changed after its early mirror (R {R} -> "
+                               f"{int(final[0]) & 0xFFFFFFFF}, flags 0 -> {int(final[1])})")
     s = WsState()
     s.cam, s.entry, s.N, s.R, s.cap, s.radii, s.allmap = ce, e, N, R, e.cap, radii, allmap
     s.list_ptr, s.stride, s.shape = int(lst.value), int(stride.value), int(shape.value)
@@ -592,7 +640,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if st is None:
             st = rasterize_forward(raster_settings, m, o, s_, r)
         ctx.state = st
-        ctx.save_for_backward(m, s_, r)
+        ctx.settings = raster_settings
+        ctx.save_for_backward(m, s_, r, o)
         ctx.mark_non_differentiable(st.radii)
         # allmap is returned as a fresh tensor the caller may overwrite in place
         # (gaussian_renderer/__init__.py:61-62,70-71); the backward never reads it.
@@ -600,14 +649,15 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _grad_radii, grad_allmap):
-        m, s_, r = ctx.saved_tensors
+        m, s_, r, o = ctx.saved_tensors
         st = ctx.state
         if grad_allmap is None:
             grad_allmap = torch.zeros_like(st.allmap)
+        if isinstance(st, WsState) and (ctx.lease is None or ctx.lease.state is None):
+            # a second walk of the graph (retain_graph=True): the workspace went back with the first one.  The forward is
+            # repeated through the staged calls, whose buffers this node then owns — later walks reuse them
+            st = ctx.state = rasterize_forward(ctx.settings, m, o, s_, r)
         if isinstance(st, WsState):
-            if ctx.lease is None or ctx.lease.state is None:
-                raise RuntimeError("the rasterizer's backward ran twice on one forward (retain_graph): its buffers are "
-                                   "gone; set SLS_STAGED_FORWARD=1 for a graph that is walked more than once")
             try:
                 dmeans, dscales, drots, dopac = rasterize_backward_ws(st, m, s_, r, grad_allmap)
             finally:
@@ -619,17 +669,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         return dmeans, None, dopac, dscales, drots, None, None
 
 
-# set by fused_mapper.maybe_install() while its run-time binding of Mapper.optimize waits for the class to exist
-# (SLS_FUSED_MAPPER=1; slam/mapper.py imports this module before its class statement runs); None otherwise
-_PENDING_HOOK = None
+# run-time bindings that wait for their target to exist: fused_mapper (SLS_FUSED_MAPPER=1: slam/mapper.py imports this
+# module before its class statement runs) and fused_render (SLS_FUSED_RENDER=1: gaussian_renderer likewise); empty otherwise
+_PENDING_HOOKS: dict = {}
 
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
-        if _PENDING_HOOK is not None:
-            _PENDING_HOOK()
+        for hook in list(_PENDING_HOOKS.values()):
+            hook()
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         _need_cuda(positions, "positions")

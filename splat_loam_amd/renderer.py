@@ -11,9 +11,12 @@ reference by tests/golden/g1_camera.npz and g2_render.npz.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from . import _abi
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, _stream, get_camera, half_pixel_tables
 
 
 def pixel_rays(camera) -> torch.Tensor:
@@ -71,7 +74,34 @@ def render(camera, model, depth_ratio: float = 0.0, rasterizer_cls=GaussianRaste
     means2D = torch.zeros_like(means3D, dtype=torch.float32)
     radii, allmap = rasterizer(means3D=means3D, means2D=means2D, opacities=model.get_opacity,
                                scales=model.get_scaling, rotations=model.get_rotation, cov3D_precomp=None)
+    if allmap.is_cuda and not allmap.requires_grad and rasterizer_cls is GaussianRasterizer:
+        # nobody differentiates this call (Mapper.densify, the tracker's target, the logger, meshing): the maps in ONE launch
+        return render_maps(camera, settings, allmap, depth_ratio, radii=radii, means2D=means2D)
     return postprocess(camera, allmap, depth_ratio, radii=radii, means2D=means2D)
+
+
+def render_maps(camera, settings, allmap: torch.Tensor, depth_ratio: float = 0.0, radii=None, means2D=None) -> dict:
+    """postprocess() as one HIP launch (sls_render_maps): same dict, same values to rounding (the surface normal is
+    taken from sensor-frame differences and rotated once — the reference's world-frame differences carry the pose's
+    translation through a cancellation), no autograd graph.  Pinned against postprocess(), which golden G2 pins against
+    the reference (tests/test_fused_render.py::test_render_maps_match_postprocess)."""
+    if not allmap.is_cuda:
+        raise RuntimeError("render_maps needs a ROCm device tensor; there is no CPU fallback")
+    dev = allmap.device
+    am = allmap.detach()
+    if am.dtype != torch.float32 or not am.is_contiguous():
+        am = am.float().contiguous()
+    _, H, W = am.shape
+    ce = get_camera(settings, dev)
+    col_h, row_h = half_pixel_tables(ce, dev)
+    out = torch.empty((7, H, W), dtype=torch.float32, device=dev)      # rend_normal 3 | surf_depth 1 | surf_normal 3
+    _abi.check(_abi.lib().sls_render_maps(H, W, am.data_ptr(), C.addressof(ce.rot9), col_h.data_ptr(), row_h.data_ptr(),
+                                          float(depth_ratio), out[0:3].data_ptr(), out[3:4].data_ptr(), out[4:7].data_ptr(),
+                                          _stream(dev)), "sls_render_maps")
+    res = {"rend_alpha": am[1:2], "rend_normal": out[0:3], "rend_dist": am[6:7], "surf_depth": out[3:4], "surf_normal": out[4:7]}
+    if radii is not None:
+        res.update({"viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii})
+    return res
 
 
 def postprocess(camera, allmap: torch.Tensor, depth_ratio: float = 0.0, radii=None, means2D=None) -> dict:

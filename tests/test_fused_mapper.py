@@ -414,3 +414,131 @@ def test_bound_optimize_runs_the_engine(device):
     Mapper().optimize()
     assert Mapper.entered == 1
 
+
+
+def test_unsupported_adam_options_are_refused():
+    """weight_decay / amsgrad / maximize are not what the fused Adam computes: refused, not dropped."""
+    m = SurfelModel(np.zeros((4, 3), np.float32), np.zeros((4, 2), np.float32), np.tile(np.float32([1, 0, 0, 0]), (4, 1)),
+                    np.zeros((4, 1), np.float32), device="cpu")
+    m.training_setup(fused=False)
+    mapping = SimpleNamespace(opt_lambda_alpha=0.1, opt_lambda_normal=0.1, opt_scaling_max=0.5, opt_scaling_max_penalty=0.2)
+    for key, val in (("weight_decay", 1e-2), ("amsgrad", True), ("maximize", True)):
+        m.optimizer.param_groups[2][key] = val
+        with pytest.raises(RuntimeError, match="weight_decay, amsgrad and maximize"):
+            fused_mapper._engine_for(m, mapping, 0.0)
+        m.optimizer.param_groups[2][key] = 0.0 if key == "weight_decay" else False
+
+
+@pytest.mark.gpu
+def test_state_goes_back_to_torchs_fused_adam(device):
+    """The reference could build `torch.optim.Adam(..., fused=True)`: torch then keeps `step` on the parameter's device.
+    After fused_optimize the state must be where torch's own kernels expect it: a following optimizer.step() of torch's
+    runs and counts on (the count used to come back as a host tensor whatever the optimizer)."""
+    from splat_loam_amd import synth
+    dev = str(device)
+    N, H, W = 1500, 32, 256
+    sc = synth.make_scene(N, H, W, seed=4, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    frames = [SimpleNamespace(camera=Camera(sc["K"], depth, None, valid, p, data_device=dev)) for p in synth.keyframe_poses(2)]
+    cfg = SimpleNamespace(mapping=SimpleNamespace(num_iterations=3, prob_view_last_keyframe=0.4, opt_lambda_alpha=0.1,
+                                                  opt_lambda_normal=0.1, opt_scaling_max=0.5, opt_scaling_max_penalty=0.2),
+                          opt=SimpleNamespace(depth_ratio=0.0))
+    for first_torch_step in (False, True):
+        model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=dev)
+        groups = [{"params": [getattr(model, a)], "lr": lr, "name": n} for n, a, lr in
+                  (("xyz", "_xyz", 5e-4), ("opacity", "_opacity", 5e-2), ("scaling", "_scaling", 5e-3), ("rotation", "_rotation", 1e-3))]
+        model.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=True)
+        if first_torch_step:      # (torch creates its own device-side counts first)
+            for g in groups:
+                g["params"][0].grad = torch.zeros_like(g["params"][0])
+            model.optimizer.step()
+        np.random.seed(2)
+        fused_mapper.fused_optimize(model, frames, cfg)
+        want = 4 + (1 if first_torch_step else 0)
+        for g in groups:
+            st = model.optimizer.state[g["params"][0]]
+            assert torch.is_tensor(st["step"]) and st["step"].is_cuda and float(st["step"]) == want
+            g["params"][0].grad = torch.zeros_like(g["params"][0])
+        model.optimizer.step()
+        assert float(model.optimizer.state[model._xyz]["step"]) == want + 1
+
+
+@pytest.mark.gpu
+def test_densify_rows_kernel_matches_torch(device):
+    """sls_densify_rows (one launch) against the torch form golden G3 / G7 pin — depth_to_points at the drawn pixels, the
+    measured normals rotated into the model frame, normal_aligned_quaternions — on a posed keyframe with random normals
+    (some exactly on the x axis: the other helper axis) and a sparse draw: centres 1e-5 m at ranges up to 30 m (an ulp or
+    two of float32), quaternions 5e-6 incl. the sign convention."""
+    from splat_loam_amd import synth
+    from splat_loam_amd.renderer import depth_to_points
+    dev = str(device)
+    H, W = 64, 1024
+    sc = synth.make_scene(1000, H, W, seed=1, range_lo=2.0, range_hi=30.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    rng = np.random.default_rng(3)
+    normal = rng.normal(size=(3, H, W)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=0, keepdims=True)
+    normal[:, 5, 7] = (1.0, 0.0, 0.0)
+    normal[:, 9, 100] = (-1.0, 2e-4, -3e-4)
+    normal[:, 9, 100] /= np.linalg.norm(normal[:, 9, 100])
+    pose = synth.keyframe_poses(6)[5]
+    a = 0.3
+    pose = pose @ np.array([[np.cos(a), 0, np.sin(a), 0.2], [0, 1, 0, -0.1], [-np.sin(a), 0, np.cos(a), 0.05], [0, 0, 0, 1]])
+    cam = Camera(sc["K"], depth, normal, valid, pose, data_device=dev)
+    frame = SimpleNamespace(camera=cam, model_T_frame=torch.tensor(pose, dtype=torch.float32, device=dev))
+    drawn = torch.tensor(rng.random((H, W)) < 0.05, device=dev)
+    drawn[5, 7] = True
+    drawn[9, 100] = True
+    xyz, quat = fused_mapper._densify_rows_hip(frame, drawn)
+    with torch.no_grad():
+        want_xyz = depth_to_points(cam, cam.image_depth)[..., drawn].T.contiguous()
+        normals = frame.model_T_frame[:3, :3] @ cam.image_normal[..., drawn]
+        want_q = fused_mapper.normal_aligned_quaternions(normals.T.contiguous())
+    assert xyz.shape == want_xyz.shape and quat.shape == want_q.shape and xyz.shape[0] == int(drawn.sum())
+    assert float((xyz - want_xyz).abs().max()) <= 1e-5
+    assert float((quat - want_q).abs().max()) <= 5e-6
+    assert float((quat.norm(dim=1) - 1).abs().max()) <= 1e-6 and bool((quat[:, 0] >= 0).all())
+
+
+@pytest.mark.gpu
+def test_densify_weights_kernel_matches_slam_rules(device):
+    """sls_densify_weights against slam_rules.densify_candidates + compute_depth_gradient (the torch forms golden G6 pins):
+    per-pixel weights, the candidates' count, the gradient's maximum, the weights' sum — with invalid pixels, a zero and
+    a negative range (non-finite logs) in the image — and the draw built on it: the right number of pixels, all of them
+    candidates with a positive weight, none twice."""
+    import ctypes as C
+    from splat_loam_amd import _abi, synth
+    from splat_loam_amd.fused import camera_aux
+    dev = str(device)
+    H, W = 64, 512
+    sc = synth.make_scene(1000, H, W, seed=2, range_lo=2.0, range_hi=30.0)
+    depth, valid = synth.make_targets(H, W, sc)
+    rng = np.random.default_rng(5)
+    depth = depth.copy(); valid = valid.copy()
+    depth[0, 10, 20] = 0.0
+    depth[0, 30, 300] = -1.0
+    valid[0][rng.random((H, W)) < 0.1] = 0
+    cam = Camera(sc["K"], depth, None, valid, np.eye(4), data_device=dev)
+    alpha = torch.tensor(rng.random((1, H, W)).astype(np.float32), device=dev)
+    for first in (False, True):
+        cand = slam_rules.densify_candidates(cam.image_valid, alpha, None, cam.image_depth, 0.5, -1.0, first)
+        grad = slam_rules.compute_depth_gradient(cam.image_depth, cam.image_valid)[0]
+        want_w = torch.where(cand, grad, torch.zeros_like(grad))
+        aux = camera_aux(cam)
+        w = torch.empty((H * W,), dtype=torch.float32, device=dev)
+        stats = torch.empty((4,), dtype=torch.int32, device=dev)
+        _abi.check(_abi.lib().sls_densify_weights(H, W, aux.gt.data_ptr(), aux.valid.data_ptr(),
+                                                  None if first else alpha.reshape(-1).contiguous().data_ptr(), 0.5, w.data_ptr(),
+                                                  stats.data_ptr(), torch.cuda.current_stream(device).cuda_stream), "sls_densify_weights")
+        host = stats.cpu().numpy()
+        assert int(host[0]) == int(cand.sum())
+        assert float((w.view(H, W) - want_w).abs().max()) <= 2e-6 * float(grad.max())
+        assert bool((w.view(H, W)[cand] > 0).all()) and bool((w.view(H, W)[~cand] == 0).all())
+        gmax, total = (float(v) for v in host[1:3].view(np.float32))
+        assert abs(gmax - float(grad.max())) <= 2e-6 * gmax and abs(total - float(want_w.sum())) <= 1e-4 * total
+        gen = torch.Generator(device=dev); gen.manual_seed(3)
+        drawn, n_cand = fused_mapper._densify_draw_hip(cam, None if first else alpha, 0.5, 0.15, gen)
+        assert n_cand == int(cand.sum()) and int(drawn.sum()) == int(0.15 * n_cand)
+        assert bool(cand[drawn].all())
+        n_pos = int((want_w > 0).sum())
+        assert int((want_w[drawn] == 0).sum()) <= max(0, int(drawn.sum()) - n_pos)      # (zero-gradient candidates only once the others are used up)

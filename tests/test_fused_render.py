@@ -1,0 +1,148 @@
+"""`SLS_FUSED_RENDER=1` (splat_loam_amd/fused_render.py): the run-time binding that gives the reference's
+`gaussian_renderer.render` a one-launch post-processing where autograd is off.  CPU: the mechanics on a stand-in module
+shaped like gaussian_renderer/__init__.py (a caller that imported the function BEFORE the binding must get the new
+behaviour).  GPU: the fast path's maps against the reference-shaped torch path on the same model."""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from splat_loam_amd import fused_render
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stand_in_module():
+    src = (
+        "def render(camera, model, depth_ratio=0.0):\n"
+        "    CALLS.append((camera, depth_ratio))\n"
+        "    return {'who': 'reference'}\n")
+    mod = types.ModuleType("gaussian_renderer")
+    mod.CALLS = []
+    exec(compile(src, "gaussian_renderer/__init__.py", "exec"), mod.__dict__)
+    return mod
+
+
+def test_binding_reaches_a_function_that_was_imported_before_it(monkeypatch):
+    mod = _stand_in_module()
+    monkeypatch.setitem(sys.modules, "gaussian_renderer", mod)
+    held = mod.render                       # what `from gaussian_renderer import render` leaves in slam/mapper.py
+    fake_model = SimpleNamespace(get_xyz=SimpleNamespace(is_cuda=True))
+    seen = []
+    monkeypatch.setattr(fused_render, "_fast", lambda c, m, d: seen.append((c, d)) or {"who": "fast"})
+    try:
+        assert fused_render.install()
+        assert held is mod.render and held.__defaults__ == (0.0,)
+        with torch.no_grad():
+            assert held("cam0", fake_model)["who"] == "fast" and seen == [("cam0", 0.0)]
+            assert held("cam1", fake_model, 1.0)["who"] == "fast" and seen[-1] == ("cam1", 1.0)
+        # a differentiated call is the reference's own code, untouched
+        assert held("cam2", fake_model, 0.5)["who"] == "reference" and mod.CALLS == [("cam2", 0.5)]
+        # a CPU model too (nothing here can run it)
+        with torch.no_grad():
+            assert held("cam3", SimpleNamespace(get_xyz=SimpleNamespace(is_cuda=False)))["who"] == "reference"
+    finally:
+        fused_render.uninstall()
+    with torch.no_grad():
+        assert held("cam4", fake_model)["who"] == "reference" and mod.CALLS[-1] == ("cam4", 0.0)
+
+
+def test_binding_waits_for_the_function(monkeypatch):
+    """`gaussian_renderer` imports the rasterizer before its `def render` runs: maybe_install() finds no function yet and
+    leaves a hook that the first GaussianRasterizer(...) fires."""
+    from splat_loam_amd import rasterizer
+    monkeypatch.setenv("SLS_FUSED_RENDER", "1")
+    monkeypatch.delitem(sys.modules, "gaussian_renderer", raising=False)
+    try:
+        fused_render.maybe_install()
+        assert "render" in rasterizer._PENDING_HOOKS and fused_render._PATCHED is None
+        mod = _stand_in_module()
+        monkeypatch.setitem(sys.modules, "gaussian_renderer", mod)
+        for hook in list(rasterizer._PENDING_HOOKS.values()):       # (what GaussianRasterizer.__init__ does)
+            hook()
+        assert fused_render._PATCHED is mod.render and "render" not in rasterizer._PENDING_HOOKS
+    finally:
+        fused_render.uninstall()
+
+
+def test_refuses_a_render_of_another_shape(monkeypatch):
+    mod = types.ModuleType("gaussian_renderer")
+    exec("def render(camera, model):\n    return None\n", mod.__dict__)
+    monkeypatch.setitem(sys.modules, "gaussian_renderer", mod)
+    with pytest.raises(RuntimeError, match="SLS_FUSED_RENDER"):
+        fused_render.install()
+    assert fused_render._PATCHED is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth_ratio", [0.0, 0.3, 1.0])
+def test_render_maps_match_postprocess(device, depth_ratio):
+    """sls_render_maps against renderer.postprocess (torch; pinned to the reference's render() by golden G2) on a
+    rendered image, identity pose and a pose with translation and yaw: rend_alpha / rend_dist are the planes themselves,
+    surf_depth and rend_normal agree to rounding, surf_normal to 2e-4 (unit vectors; the torch path differences WORLD
+    points — 1e-5 relative through the translation's cancellation)."""
+    from splat_loam_amd import renderer, synth
+    from splat_loam_amd.scene import Camera, SurfelModel
+    dev = str(device)
+    N, H, W = 20000, 64, 512
+    sc = synth.make_scene(N, H, W, seed=6, range_lo=2.0, range_hi=30.0, scale_hi=0.3)
+    depth, valid = synth.make_targets(H, W, sc)
+    model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=dev)
+    for pose in (np.eye(4), synth.keyframe_poses(4)[3]):
+        cam = Camera(sc["K"], depth, None, valid, pose, data_device=dev)
+        with torch.no_grad():
+            fast = renderer.render(cam, model, depth_ratio)
+            settings = renderer.GaussianRasterizationSettings(H, W, 1.0, cam.world_view_transform, cam.projection_matrix)
+            _, allmap = renderer.GaussianRasterizer(raster_settings=settings)(
+                means3D=model.get_xyz, means2D=model.get_xyz, opacities=model.get_opacity, scales=model.get_scaling,
+                rotations=model.get_rotation)
+            ref = renderer.postprocess(cam, allmap.clone(), depth_ratio)
+        assert torch.equal(fast["rend_alpha"], allmap[1:2]) and torch.equal(fast["rend_dist"], allmap[6:7])
+        assert set(fast) >= {"rend_alpha", "rend_normal", "rend_dist", "surf_depth", "surf_normal", "radii", "visibility_filter"}
+        d = (fast["surf_depth"] - ref["surf_depth"]).abs().max() / ref["surf_depth"].abs().max()
+        assert float(d) <= 2e-6, float(d)
+        assert float((fast["rend_normal"] - ref["rend_normal"]).abs().max()) <= 2e-6
+        e = (fast["surf_normal"] - ref["surf_normal"]).abs()
+        assert float(e.max()) <= 2e-4, float(e.max())
+        assert float(fast["surf_normal"][:, 0].abs().max()) == 0.0 and float(fast["surf_normal"][:, :, -1].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_bound_render_serves_no_grad_callers(device, monkeypatch):
+    """The binding end to end on a module shaped like the reference's (its render = this repo's torch path, which G2
+    pins to the reference's): under no_grad the held function returns the fast maps, with autograd on it is the module's
+    own code and its result carries a graph."""
+    from splat_loam_amd import renderer, synth
+    from splat_loam_amd.scene import Camera, SurfelModel
+    dev = str(device)
+    N, H, W = 5000, 32, 256
+    sc = synth.make_scene(N, H, W, seed=2, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    depth, valid = synth.make_targets(H, W, sc)
+    model = SurfelModel.from_activated(sc["means"], sc["scales"], sc["rots"], sc["opac"], device=dev)
+    cam = Camera(sc["K"], depth, None, valid, synth.keyframe_poses(2)[1], data_device=dev)
+    mod = types.ModuleType("gaussian_renderer")
+    mod.renderer = renderer
+    exec("def render(camera, model, depth_ratio=0.0):\n"
+         "    s = renderer.GaussianRasterizationSettings(int(camera.image_height), int(camera.image_width), 1.0,\n"
+         "                                               camera.world_view_transform, camera.projection_matrix)\n"
+         "    radii, allmap = renderer.GaussianRasterizer(raster_settings=s)(means3D=model.get_xyz, means2D=model.get_xyz,\n"
+         "        opacities=model.get_opacity, scales=model.get_scaling, rotations=model.get_rotation)\n"
+         "    return renderer.postprocess(camera, allmap, depth_ratio, radii=radii)\n", mod.__dict__)
+    monkeypatch.setitem(sys.modules, "gaussian_renderer", mod)
+    held = mod.render
+    fused_render.CALLS.update(fast=0, reference=0)
+    try:
+        assert fused_render.install()
+        with torch.no_grad():
+            a = held(cam, model)
+        b = held(cam, model)
+        assert fused_render.CALLS == {"fast": 1, "reference": 1}
+        assert b["surf_depth"].requires_grad and not a["surf_depth"].requires_grad
+        assert float((a["surf_depth"] - b["surf_depth"].detach()).abs().max()) <= 2e-6 * float(b["surf_depth"].abs().max())
+        assert float((a["surf_normal"] - b["surf_normal"].detach()).abs().max()) <= 2e-4
+    finally:
+        fused_render.uninstall()

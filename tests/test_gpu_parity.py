@@ -479,6 +479,60 @@ def test_workspace_path_edge_sizes(device, monkeypatch, N, H, W, shrink):
         assert ent.stats["R"] == 0 and not bool((out["0"][0] > 0).any()) and float(out["0"][1].abs().max()) == 0.0
 
 
+def test_workspace_path_second_backward_and_held_graph(device, monkeypatch):
+    """(a) a graph walked twice (retain_graph=True) — the second walk finds the workspace gone and repeats the
+    forward through the staged calls instead of raising: same gradients both times; (b) a result that is kept alive
+    without a backward holds the workspace: the next forward of that size takes the staged path AND says so once;
+    (c) a new surfel count inherits the instances-per-surfel the old size saw (no overflow-and-repeat on its first call)."""
+    import warnings
+    from splat_loam_amd import rasterizer, synth
+    from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.setenv("SLS_STAGED_FORWARD", "0")
+    N, H, W = 6000, 64, 512
+    sc = synth.make_scene(N, H, W, seed=12, range_lo=2.0, range_hi=15.0, scale_hi=0.25)
+    view, proj = synth.camera_matrices(sc["K"])
+    settings = GaussianRasterizationSettings(H, W, 1.0, torch.tensor(view, device=device), torch.tensor(proj, device=device), False, False)
+    dL = torch.tensor(np.random.default_rng(0).normal(size=(7, H, W)).astype(np.float32), device=device)
+    rasterizer._WS_CACHE.clear()
+    rasterizer._WARNED.clear()
+
+    def render(n=N):
+        t = {k: torch.tensor(sc[k][:n], device=device).requires_grad_(True) for k in ("means", "scales", "rots", "opac")}
+        _, am = GaussianRasterizer(raster_settings=settings)(means3D=t["means"], means2D=t["means"], opacities=t["opac"],
+                                                             scales=t["scales"], rotations=t["rots"])
+        return t, am
+    # (a)
+    t, am = render()
+    loss = (am * dL).sum()
+    loss.backward(retain_graph=True)
+    first = {k: v.grad.clone() for k, v in t.items()}
+    for v in t.values():
+        v.grad = None
+    loss.backward()
+    for k, v in t.items():
+        scale = float(first[k].abs().max())
+        assert float((v.grad - first[k]).abs().max()) <= 5e-6 * scale, k
+    ent = next(iter(rasterizer._WS_CACHE.values()))
+    assert not ent.busy
+    # (b)
+    t1, held = render()
+    assert ent.busy
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        t2, am2 = render()
+        render()
+    assert sum("staged path" in str(x.message) for x in w) == 1, [str(x.message) for x in w]
+    assert torch.equal(am2.detach(), held.detach())
+    (held * dL).sum().backward()
+    assert not ent.busy
+    # (c)
+    seen = ent.stats["R"]
+    n2 = N - 500
+    render(n2)[1].sum().backward()
+    ent2 = next(v for k, v in rasterizer._WS_CACHE.items() if k[1] == n2)
+    assert ent2.cap_hint >= seen * n2 // N and ent2.stats["too_small"] == 0 and ent2.cap >= ent2.stats["R"]
+
+
 def test_binning_with_rectangles_that_cover_the_image(device, oracle32, monkeypatch):
     """VERDICT r04 item 4.  Surfels within a metre of the sensor have tile rectangles of hundreds of tiles (up to all 512
     at 64x2048) and sit together at the front of the depth order: one wave of bin_direct_kernel then has hundreds of
@@ -552,6 +606,13 @@ def test_knn_bitexact(device, oracle32):
     pts = pts[rng.permutation(len(pts))]
     got = distCUDA2(torch.tensor(pts, device=device)).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), oracle32.knn_dist2(pts).view(np.uint32))
+    # queries = the first `first` points only (what Mapper.densify keeps): the same bits as the full call's head
+    full = torch.tensor(got, device=device)
+    t = torch.tensor(pts, device=device)
+    for first in (1, 63, 64, 700, len(pts) - 1, len(pts)):
+        part = distCUDA2(t, first=first)
+        assert part.shape == (first,) and torch.equal(part.view(torch.int32), full[:first].view(torch.int32)), first
+    assert distCUDA2(t, first=0).shape == (0,)
 
 
 def test_fused_adam_matches_torch(device):
