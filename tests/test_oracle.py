@@ -294,3 +294,31 @@ def test_integer_outputs_reproduced_with_independent_math(oracle32):
         rect = torch.stack([bb["txlo"], bb["ncols"], bb["tylo"], bb["nrows"]], 1).numpy().astype(np.int32)
         assert np.array_equal(rect[vis], pre["rect"][vis])
         assert vals.numel() == b["R"] and np.array_equal(ranges.numpy().astype(np.uint32), b["ranges"])
+
+
+def test_tiled_float64_formulation_equals_the_dense_one():
+    """oracle/torch_ref.py: dense_forward_tiled (the tiles as a batch, every surfel only on the tiles of its rectangle) is
+    the SAME function as dense_forward — image and gradients to float64 rounding — on a wrapping 32x128 image and on a
+    ragged 40x72 one (tiles that overhang the image).  The tiled form is what lets the GPU suite hold the HIP path to the
+    float64 formulation at 2 000 surfels (tests/test_gpu_parity.py)."""
+    import torch
+    from oracle import torch_ref
+    from oracle.oracle import Oracle
+    from splat_loam_amd import synth
+    o = Oracle(np.float64)
+    for N, H, W in ((60, 32, 128), (40, 40, 72)):
+        sc = synth.make_scene(N, H, W, seed=3, range_lo=2.0, range_hi=8.0, scale_lo=0.05, scale_hi=0.4)
+        view, proj = synth.camera_matrices(sc["K"])
+        cam = o.camera(H, W, view.astype(np.float64), proj)
+        a64 = [np.asarray(sc[k], np.float64) for k in ("means", "scales", "rots", "opac")]
+        ost = o.forward(cam, *a64)
+        la = [torch.tensor(a, requires_grad=True) for a in a64]
+        lb = [torch.tensor(a, requires_grad=True) for a in a64]
+        A = torch_ref.dense_forward(cam, ost["tables"], ost["pre"], *la)
+        B = torch_ref.dense_forward_tiled(cam, ost["tables"], ost["pre"], *lb)
+        assert float((A - B).detach().abs().max()) <= 1e-13
+        dL = torch.tensor(np.random.default_rng(0).normal(size=(7, H, W)))
+        (A * dL).sum().backward()
+        (B * dL).sum().backward()
+        for x, y in zip(la, lb):
+            assert float((x.grad - y.grad).abs().max()) <= 1e-12 * float(x.grad.abs().max())
