@@ -142,7 +142,7 @@ def sparse_union(c):
     return out
 
 
-def _dropin_at(c, n2, h2, w2, iters, warm):
+def _dropin_at(c, n2, h2, w2, iters, warm, rows_only=False):
     from splat_loam_amd import fused_mapper, rasterizer
     from splat_loam_amd.mapping import optimize_step, optimize_step_fused
     from splat_loam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -206,6 +206,10 @@ def _dropin_at(c, n2, h2, w2, iters, warm):
         return res
 
     rasterizer_alone(False, False)       # (discarded: whatever the process does once — module loads, allocator growth — lands here)
+    if rows_only:
+        out = {"all_planes": rasterizer_alone(False, False), "lean_allmap": rasterizer_alone(True, False)}
+        rasterizer._WS_CACHE.clear()
+        return out
     out = {"all_planes": {**rasterizer_alone(False, False), **iterations(False)},
            "lean_allmap": {**rasterizer_alone(True, False), **iterations(True)},
            "staged_all_planes": rasterizer_alone(False, True)}
@@ -252,6 +256,11 @@ def _pin_threads(cores):
 
 
 def dropin(c):
+    """The reported rows are UNPINNED — what a user's process gets (round 6: backward() on the calling thread by default
+    with one GPU, rasterizer._autograd_policy); `pinned_to_four_cores` repeats the rasterizer-alone rows with every thread
+    of the process on four neighbouring cores, round 5's way of taking them."""
+    out = {f"{c.N}_{c.H}x{c.W}": _dropin_at(c, c.N, c.H, c.W, 30, 10), "50000_64x1024": _dropin_at(c, 50_000, 64, 1024, 50, 20)}
+    out["autograd_multithreading"] = bool(torch.autograd.is_multithreading_enabled())
     saved = None
     try:
         mine = sorted(os.sched_getaffinity(0))
@@ -259,11 +268,12 @@ def dropin(c):
     except (AttributeError, OSError):
         pass
     try:
-        out = {f"{c.N}_{c.H}x{c.W}": _dropin_at(c, c.N, c.H, c.W, 30, 10), "50000_64x1024": _dropin_at(c, 50_000, 64, 1024, 50, 20)}
+        if saved:
+            pinned = _dropin_at(c, c.N, c.H, c.W, 30, 10, rows_only=True)
+            out["pinned_to_four_cores"] = {"cores": sorted(set(mine[:4])), f"{c.N}_{c.H}x{c.W}": pinned}
     finally:
         if saved:
             _pin_threads(saved)
-    out["threads_pinned_to_cores"] = sorted(set(mine[:4])) if saved else None
     return out
 
 

@@ -235,6 +235,10 @@ int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const floa
                    int32_t *radii, float *allmap, void *workspace, size_t workspace_bytes, struct SlsMappingStatus *status_dev,
                    struct SlsMappingStatus *status_mirror, const uint32_t **sorted_list, int *sorted_stride,
                    int *block_masks_shape, void *stream);
+/* Blocks until words 0 and 7 of the pinned status mirror sls_forward_ws was given differ from `sentinel` (the caller
+ * arms both with a value the device never writes): a bounded spin on the calling thread — no interpreter lock is held by
+ * a ctypes caller meanwhile — then a drain of the stream as a last resort. */
+int sls_wait_status_mirror(const void *mirror_host, uint32_t sentinel, void *stream);
 /* The backward of that forward: tile backward (it marks the surfels it reaches) + the projection's backward, which
  * reads — and clears — only the marked surfels' gradient records: no 64 N-byte memset per call.  block_order (optional;
  * sls_block_order_bytes(H, W) bytes, zero-initialised, caller-kept PER CAMERA): the tile backward walks its pixel blocks

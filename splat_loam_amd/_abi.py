@@ -124,6 +124,7 @@ _PROTOS = {
                                         _VP, C.c_size_t, _VP]),
     "sls_knn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "sls_knn_dist2": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "sls_wait_status_mirror": (C.c_int, [_VP, C.c_uint32, _VP]),
     "sls_knn_dist2_first": (C.c_int, [C.c_int, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP]),
     "sls_mark_visible": (C.c_int, [C.POINTER(SlsCamera), C.c_int, _VP, _VP, _VP]),
     "sls_aligner_workspace_bytes": (C.c_size_t, []),

@@ -379,6 +379,24 @@ int sls_knn_dist2(int M, const float *xyz, float *out, void *scratch, size_t scr
     return launch_knn(M, xyz, out, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+int sls_wait_status_mirror(const void *mirror_host, uint32_t sentinel, void *stream)
+{
+    // The drop-in forward's status (R, void bits) arrives in the caller's pinned host block a few microseconds into the
+    // binning; the caller must know it before it hands the image on.  Spun HERE (the binding releases the interpreter's
+    // lock around a foreign call) with the CPU's pause hint; if the words have not arrived after ~2 ms of spinning the
+    // stream is drained — a lost mirror write must not hang the caller.
+    SLS_REQUIRE(mirror_host, "null pointer");
+    const volatile uint32_t *w = (const volatile uint32_t *)mirror_host;
+    for (int spin = 0; spin < 400000; ++spin) {
+        if (w[7] != sentinel && w[0] != sentinel) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SLS_OK; }
+        __builtin_ia32_pause();
+    }
+    SLS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (w[7] != sentinel && w[0] != sentinel) return SLS_OK;
+    set_error("the forward's status never reached its host mirror");
+    return SLS_E_HIP;
+}
+
 int sls_knn_dist2_first(int M, int M_first, const float *xyz, float *out, void *scratch, size_t scratch_bytes, void *stream)
 {
     SLS_REQUIRE(M >= 0 && M_first >= 0 && M_first <= M, "bad sizes");

@@ -510,13 +510,8 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
             return None
         _abi.check(rc, "sls_forward_ws")
         e.ready = True
-        spins = 0
-        while row[7] == _SENTINEL or row[0] == _SENTINEL:       # (the tile forward is running meanwhile)
-            spins += 1
-            if spins > 2_000_000:
-                torch.cuda.current_stream(dev).synchronize()
-                if row[7] == _SENTINEL or row[0] == _SENTINEL:
-                    raise RuntimeError("the forward's status never reached its host mirror")
+        # (the wait runs in the library: no interpreter lock held while the binning and the tile forward run)
+        _abi.check(lib.sls_wait_status_mirror(e.mirror.data_ptr(), 0xFFFFFFFF, st), "sls_wait_status_mirror")
         R, flags = int(row[0]) & 0xFFFFFFFF, int(row[1])
         if flags == 0:
             break
@@ -617,6 +612,25 @@ def frame_from_precomp(cov3D_precomp: torch.Tensor):
     return torch.stack([su, sv], dim=1).contiguous(), q.contiguous()
 
 
+_AUTOGRAD_POLICY_DONE = False
+
+
+def _autograd_policy() -> None:
+    """torch runs the backward of device tensors on a worker thread of its own: every mapping iteration then hands over
+    twice between that thread and the caller's, and on a many-core host the two wake each other in 10 us or in 100, at
+    random per process (profiles/r05j_autograd_thread.txt: the drop-in rows were bimodal, 0.18 / 0.28 ms at C3).  With ONE
+    visible GPU the worker buys nothing — there is nothing to run beside it — so the first differentiated forward makes
+    backward() run on the calling thread (`torch.autograd.set_multithreading_enabled(False)`, process-wide).
+    SLS_AUTOGRAD_SINGLE_THREAD=0 leaves torch as it is, =1 does it whatever the number of GPUs."""
+    global _AUTOGRAD_POLICY_DONE
+    if _AUTOGRAD_POLICY_DONE:
+        return
+    _AUTOGRAD_POLICY_DONE = True
+    want = os.environ.get("SLS_AUTOGRAD_SINGLE_THREAD", "")
+    if want == "1" or (want == "" and torch.cuda.device_count() == 1):
+        torch.autograd.set_multithreading_enabled(False)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, opacities, scales, rotations, cov3D_precomp, raster_settings):
@@ -628,6 +642,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if m.shape != (m.shape[0], 3) or s_.shape != (m.shape[0], 2) or r.shape != (m.shape[0], 4) or o.numel() != m.shape[0]:
             raise ValueError("expected means3D (N,3), scales (N,2), rotations (N,4), opacities (N,1)")
         needs_grad = any(ctx.needs_input_grad[:5])
+        if needs_grad:
+            _autograd_policy()
         ctx.debug = bool(raster_settings.debug)
         ctx.lease = None
         st = None
