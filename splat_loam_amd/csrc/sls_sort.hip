@@ -849,6 +849,11 @@ __device__ __forceinline__ uint32_t wave_max_scan(uint32_t v)
 // chunk against 1.5 k at the far end — and a launch lasts as long as its heaviest workgroup.  Workgroup `sub` of a chunk
 // first counts the rectangles of the sub-chunks in front of it (LDS counts only: a tenth of what emitting them costs)
 // to know where its own instances start.
+// A workgroup one of whose waves holds kHeavyWave instances or more (near surfels: rectangles of a hundred tiles and more,
+// all at the front of the depth order — 14 k instances in ONE wave at the bench window's last keyframes, 222 rounds where
+// the launch's median wave has two: profiles/r05a_bin_tail.txt) leaves the wave-by-wave rounds: see "heavy" below.
+constexpr uint32_t kHeavyWave = 1536;
+constexpr int kHeavyParts = 4, kHeavyChunks = 16;
 template <int BITS, bool PAIRS, int SPLIT>
 __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N, int GX, DirectBin db,
                                                                   const uint32_t *__restrict__ order,
@@ -871,10 +876,21 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     __shared__ uint4 s_lane[WAVES][64];          // per wave and lane: {rectangle, block box, surfel, first instance of the lane}
     __shared__ uint32_t s_mark[WAVES][64];       // per wave: which lane's instances start at each slot of the current round
     __shared__ uint32_t s_part[WAVES];
+    __shared__ uint32_t s_ws[WAVES];             // the waves' instance counts (which workgroup is "heavy")
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int chunk = (int)blockIdx.x / SPLIT, sub = (int)blockIdx.x % SPLIT;
+    // Workgroups in front of the grid's chunks (SPLIT = 1): HELPERS of the first kHeavyChunks chunks — where the near
+    // surfels sit — kHeavyParts - 1 each.  A helper looks at its chunk; if that is not heavy (almost always) it leaves at
+    // once, else it takes one quarter of the chunk's tiles (pass `part` below) while the chunk's own workgroup takes
+    // quarter 0: a heavy chunk's 70 k scattered 8-byte stores are what ONE compute unit's address pipeline takes 35 us for
+    // (measured with the stores compiled out), its instances' arithmetic as much again — four compute units share both.
+    const int nhelp = SPLIT == 1 ? min(kHeavyChunks, db.nchunks) * (kHeavyParts - 1) : 0;
+    const bool helper = (int)blockIdx.x < nhelp;
+    const int chunk = helper ? (int)blockIdx.x / (kHeavyParts - 1) : ((int)blockIdx.x - nhelp) / SPLIT;
+    const int sub = helper ? 0 : ((int)blockIdx.x - nhelp) % SPLIT;
+    const int part = helper ? 1 + (int)blockIdx.x % (kHeavyParts - 1) : 0;
+    const bool lead = !helper && chunk == 0 && sub == 0;      // the launch's first chunk: ranges, R, the void bits, the status mirror
     SLS_BT(0);
-    if (resort_windows > 0 && blockIdx.x == 0) {
+    if (resort_windows > 0 && lead) {
         for (int b = tid; b + 1 < resort_windows; b += TPB)
             if (resort_edges[2 * b + 1] >= resort_edges[2 * (b + 1)]) atomicOr(fail_flag, kResortFailed);
     }
@@ -952,10 +968,17 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     const uint32_t S = (uint32_t)__shfl((int)incl, 63, 64);
     const uint32_t first = incl - t;
     s_lane[w][lane] = make_uint4(er.x, er.y, g, first);
+    if (lane == 63) s_ws[w] = S;
     __syncthreads();
     SLS_BT(1);
+    bool heavy = false;                          // (workgroup-uniform)
+    if (SPLIT == 1) {
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) heavy = heavy || s_ws[k] >= kHeavyWave;
+    }
+    if (helper && !heavy) return;                // (workgroup-uniform: nothing to help with)
     // per-wave counts (the order inside a wave does not matter for counting: every lane walks its own rectangle)
-    count_rect_tiles_wave(er.x, GX, s_cur + w * BINS);
+    if (!heavy) count_rect_tiles_wave(er.x, GX, s_cur + w * BINS);
 #pragma unroll
     for (int m = 0; m < SPLIT - 1; ++m) count_rect_tiles_wave(front[m], GX, s_pre);
     SLS_BT(2);
@@ -979,7 +1002,7 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
             const int d = tid * PER + q;
             if (d >= BINS) break;
             const uint32_t dbase = wp + dinc - dsum + loc[q];
-            if (blockIdx.x == 0) {
+            if (lead) {
                 // the digit bases ARE the tile ranges (A5), clipped to the buffers' capacity
                 if (d < nranges) ranges_out[d] = tot[q] ? make_uint2(min(dbase, cap), min(dbase + tot[q], cap)) : make_uint2(0u, 0u);
                 if (d == BINS - 1) {
@@ -988,6 +1011,7 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
                     if (R > cap && overflow) atomicOr(overflow, 1u);     // too small: flagged, every slot below cap still filled
                 }
             }
+            if (heavy) { s_pre[d] = dbase + ccol[q]; continue; }      // (the tile's first slot for this chunk; no per-wave cursors)
             uint32_t c[WAVES];
 #pragma unroll
             for (int k = 0; k < WAVES; ++k) c[k] = s_cur[k * BINS + d];
@@ -1006,7 +1030,7 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     // behind it (the other workgroups of this launch, the tile forward) writes the status block.  A check added later
     // must either sit in front of it or be read from the device's block (rasterize_forward_ws re-reads that block under
     // settings.debug and raises on a difference).
-    if (status_mirror && blockIdx.x == 0 && tid == 0) {
+    if (status_mirror && lead && tid == 0) {
         __threadfence();
         // (words written a moment ago by other threads of this workgroup: read where atomics live, not through this CU's L1)
         const uint32_t w0 = __hip_atomic_load(total_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1025,6 +1049,103 @@ __global__ __launch_bounds__(kDirectChunk / SPLIT) void bin_direct_kernel(int N,
     // the last lane whose first instance is <= q — every lane marks the slot its instances start at, a max-scan over the
     // round's 64 slots (carried on from the previous round) names the owner: one LDS round trip and six DPP steps.
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (SPLIT == 1 && heavy) {
+        // ---- heavy workgroup: every INSTANCE of the chunk goes to a thread, whatever surfel it belongs to.
+        // An instance's place is   first slot of its tile for this chunk + set bits of the tile's membership mask below
+        // its depth position,   the mask M[wave][tile] = one bit per lane of the wave whose rectangle holds the tile.  1024
+        // positions x 512 tiles are 64 KB of masks; taken a QUARTER of the tiles at a time (16 KB + 8 KB of per-wave
+        // prefixes) they fit into the cursor table the rounds would have used.  Four passes; in each the pass's instances
+        // are dealt out in equal contiguous shares, one per thread (the owner of a share's first instance by binary
+        // search in the prefix of the positions' counts, then rectangles are walked and owners advanced), twice:
+        //   once to set the masks' bits (LDS atomics: neighbouring instances are neighbouring tiles, different words),
+        //   once — behind the per-tile prefix over the waves' bit counts — to place and store them.
+        // No step depends on a cursor another step wrote, and no thread has more than S / 1024 + 1 instances per walk.
+        // (Masks by ballot instead — every wave asks "does my rectangle hold tile t" for the pass's 128 tiles — cost 8 k
+        //  instructions per wave whatever the instance count: 99 us at keyframe 5 where the rounds took 37.)
+        constexpr int QT = BINS / 4;                                   // tiles per pass
+        uint64_t *const Mq = reinterpret_cast<uint64_t *>(s_cur);     // [WAVES][QT]
+        uint32_t *const pre = s_cur + 2 * WAVES * QT;                 // [WAVES][QT]: set bits of the tile in the waves in front
+        uint32_t *const cpre = &s_mark[0][0];                         // [TPB]: inclusive prefix of the positions' counts in the pass
+        uint32_t *const wsum = s_part;                                // [WAVES]
+        static_assert(3 * WAVES * QT <= WAVES * BINS, "the heavy passes' masks and prefixes live in the cursor table");
+        const int onc = (int)((er.x >> 9) & 1023u), oty = (int)((er.x >> 19) & 63u), onr = (int)(er.x >> 25);
+        static_assert(kHeavyParts == 4, "a helper per quarter of the tiles");
+        const bool shared = chunk < kHeavyChunks;     // (this chunk has helpers: its own workgroup takes quarter 0 only)
+        for (int qp = shared ? part : 0; qp < (shared ? part + 1 : 4); ++qp) {
+            const int t_lo = qp * QT, t_hi = min(t_lo + QT, nranges);    // tiles of the pass; tile rows that can hold one:
+            if (t_lo >= t_hi) break;
+            const int ra = t_lo / GX, rb = (t_hi - 1) / GX;
+            const int y0 = max(ra, oty), y1 = min(rb, oty + onr - 1);  // rows of MY rectangle among them
+            const uint32_t cq = (onc > 0 && y1 >= y0) ? (uint32_t)(onc * (y1 - y0 + 1)) : 0u;
+            for (int i = tid; i < 2 * WAVES * QT; i += TPB) s_cur[i] = 0u;
+            uint32_t inc2 = cq;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(inc2, off, 64);
+                if (lane >= off) inc2 += u;
+            }
+            if (lane == 63) wsum[w] = inc2;
+            __syncthreads();
+            uint32_t wp2 = 0, Sq = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) { const uint32_t v = wsum[k]; wp2 += k < w ? v : 0u; Sq += v; }
+            cpre[tid] = wp2 + inc2;
+            __syncthreads();
+            const uint32_t share = (Sq + (uint32_t)TPB - 1u) / (uint32_t)TPB;
+            const uint32_t i_begin = (uint32_t)tid * share, i_end = min(Sq, i_begin + share);
+            // fn(position, tile, record) for every instance of my share
+            auto walk = [&](auto fn) {
+                if (i_begin >= i_end) return;
+                int lo = 0, hi = TPB - 1;                              // the first position whose inclusive prefix exceeds i_begin
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cpre[mid] > i_begin) hi = mid; else lo = mid + 1; }
+                uint32_t upto = cpre[lo];
+                uint4 o = s_lane[lo >> 6][lo & 63];                   // {rectangle, block box, surfel, -}
+                int ptx = (int)(o.x & 511u), pnc = (int)((o.x >> 9) & 1023u);
+                const uint32_t k = i_begin - (lo > 0 ? cpre[lo - 1] : 0u);      // my first instance: its k-th among the pass's rows
+                const uint32_t ky = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)pnc));     // (k / ncols: see the rounds)
+                int kx = (int)(k - ky * (uint32_t)pnc);
+                int ty = max(ra, (int)((o.x >> 19) & 63u)) + (int)ky;
+                int tx = ptx + kx;
+                if (tx >= GX) tx -= GX;
+                // ONE loop over the share (the same trip count in every lane); a lane whose surfel is used up moves on to
+                // the next position that has instances in this pass and starts its rows from the left
+                for (uint32_t i = i_begin; i < i_end; ++i) {
+                    if (i >= upto) {
+                        do { ++lo; upto = cpre[lo]; } while (upto <= i);
+                        o = s_lane[lo >> 6][lo & 63];
+                        ptx = (int)(o.x & 511u); pnc = (int)((o.x >> 9) & 1023u);
+                        kx = 0; ty = max(ra, (int)((o.x >> 19) & 63u)); tx = ptx;
+                    }
+                    const int tile = ty * GX + tx;
+                    if (tile >= t_lo && tile < t_hi) fn(lo, tile, o);     // (a tile row may straddle two passes)
+                    ++kx; ++tx;
+                    if (tx == GX) tx = 0;
+                    if (kx == pnc) { kx = 0; ++ty; tx = ptx; }
+                }
+            };
+            walk([&](int pp, int tile, const uint4 &) {
+                atomicOr((unsigned long long *)&Mq[(pp >> 6) * QT + (tile - t_lo)], 1ull << (pp & 63));
+            });
+            __syncthreads();
+            if (tid < t_hi - t_lo) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int k = 0; k < WAVES; ++k) { pre[k * QT + tid] = run; run += (uint32_t)__popcll(Mq[k * QT + tid]); }
+            }
+            __syncthreads();
+            walk([&](int pp, int tile, const uint4 &o) {
+                const int tl = tile - t_lo, pw = pp >> 6;
+                const uint32_t place = s_pre[tile] + pre[pw * QT + tl] + (uint32_t)__popcll(Mq[pw * QT + tl] & ((1ull << (pp & 63)) - 1ull));
+                if (place < cap) {
+                    if (PAIRS) bm.out[place] = make_uint2(o.z, block_mask_of(bm, (uint32_t)tile, o.y));
+                    else vals_out[place] = o.z;
+                }
+            });
+            __syncthreads();
+        }
+        SLS_BT(4);
+        return;
+    }
     uint32_t *const cur = s_cur + w * BINS;
     uint32_t carry = 0u;                          // (owner of the slot before this round) + 1
     const bool long_wave = S >= 1024u;            // (a wave of far surfels never meets the case below: spare it the test)
@@ -1654,18 +1775,15 @@ int launch_bin_direct(const DevCam &cam, int N, uint32_t cap, const DirectBin &d
     }
     {
         ScopedTimer tm(T_BIN_DIRECT, st);
-        // (SLS_BIN_SPLIT=2|4: that many workgroups per chunk, for A/B runs.  Measured, profiles/r04f_bin_trace.txt: a wave never has
-        //  more than 8 rounds at BASELINE config 3 — the launch is its chain of phases, not its heaviest chunk — and
-        //  the sub-chunks' extra loads and counts cost more than the split gives: 24.8 / 24.0 / 26.6 us with 1 / 2 / 4)
-        static const int split_env = getenv("SLS_BIN_SPLIT") ? atoi(getenv("SLS_BIN_SPLIT")) : 1;
-        const int split = (split_env == 2 || split_env == 4) ? split_env : 1;
-#define SLS_DIRECT3(B_, P_, S_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_, S_>), dim3(db.nchunks * S_), dim3(kDirectChunk / S_), 0, st, N, cam.GX, db, \
+        // (every chunk split over 2 / 4 workgroups was measured in round 4 — 24.0 / 26.6 against 24.8 us, profiles/r04f_bin_trace.txt:
+        //  the launch is its chain of phases, not its heaviest chunk — the template keeps the parameter, nothing launches it;
+        //  what IS split, since round 6, are the heavy chunks at the front of the depth order: the helper workgroups)
+        const int nhelp = (db.nchunks < kHeavyChunks ? db.nchunks : kHeavyChunks) * (kHeavyParts - 1);
+#define SLS_DIRECT(B_, P_) hipLaunchKernelGGL((bin_direct_kernel<B_, P_, 1>), dim3(nhelp + db.nchunks), dim3(kDirectChunk), 0, st, N, cam.GX, db, \
                                order, (const uint2 *)erec_box, (const int4 *)rect, sbox, cap, vals_out, bm, (uint2 *)ranges, T, \
                                total_out, overflow, resort_windows, resort_edges, overflow, status_mirror)
-#define SLS_DIRECT(B_, P_) do { if (split == 1) SLS_DIRECT3(B_, P_, 1); else if (split == 2) SLS_DIRECT3(B_, P_, 2); else SLS_DIRECT3(B_, P_, 4); } while (0)
         if (db.bins == 256) { if (bm.out) SLS_DIRECT(8, true); else SLS_DIRECT(8, false); }
         else { if (bm.out) SLS_DIRECT(9, true); else SLS_DIRECT(9, false); }
-#undef SLS_DIRECT3
 #undef SLS_DIRECT
         SLS_LAUNCH_CHECK("bin_direct_kernel");
     }

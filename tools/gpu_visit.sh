@@ -2,17 +2,9 @@
 TAG=${1:-r06x}
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
+R=$PWD
 mkdir -p gpurun_out
-for i in 1 2 3; do
-timeout 600 python bench_extras.py dropin 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())['dropin']
-for k,v in d.items():
-    if isinstance(v,dict) and 'all_planes' in v:
-        print('$i',k,'fwd',v['all_planes']['rasterizer_fwd_ms'],'fwd+bwd',v['all_planes']['rasterizer_fwd_bwd_ms'],'lean',v['lean_allmap']['rasterizer_fwd_bwd_ms'],'staged',v.get('staged_all_planes',{}).get('rasterizer_fwd_bwd_ms'),'hooked',v.get('hooked_mapper'))
-    elif k=='pinned_to_four_cores':
-        for kk,vv in v.items():
-            if isinstance(vv,dict): print('$i pinned',kk,'fwd',vv['all_planes']['rasterizer_fwd_ms'],'fwd+bwd',vv['all_planes']['rasterizer_fwd_bwd_ms'],'lean',vv['lean_allmap']['rasterizer_fwd_bwd_ms'])
-    else: print('$i',k,v)
-"
-done | tee gpurun_out/${TAG}_dropin.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_timed_path.py -m gpu -q -x 2>&1 | tail -4 | tee gpurun_out/${TAG}_pytest.log
+rm -rf /tmp/prof && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-timing > /tmp/prof.log 2>&1)
+find /tmp/prof -name "*kernel_trace.csv" -exec cp {} /tmp/${TAG}_kernel_trace.csv \;
+python tools/bin_tail.py /tmp/${TAG}_kernel_trace.csv > gpurun_out/${TAG}_bin_tail.txt 2>/dev/null; head -11 gpurun_out/${TAG}_bin_tail.txt
