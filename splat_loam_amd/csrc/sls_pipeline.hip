@@ -355,7 +355,7 @@ int sls_forward_ws(const SlsCamera *cam, int N, const float *means3D, const floa
     uint32_t *okeys, *ovals, *n_dev;
     uint32_t *order = depth_order ? depth_order : w.order;
     depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
-    static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
+    constexpr bool no_merge = false;
     const bool merged_sort = reuse_rounds >= 1 && !no_merge;
     DirectBin db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, reuse_rounds >= 1, true);
     // (as in sls_mapping_step: the direct binning reads the emission records only)
@@ -495,8 +495,8 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     // With the default backward kernel and depth_ratio = 0 the consumer's second kernel is folded into the
     // backward tile kernel: every pixel block computes its dL/dallmap from kernel B's planes itself ...
     const bool fuse_c = debug_state().bwd_variant == 3 && cfg->depth_ratio == 0.0f;
-    // ... and with the keyframe's launch-order buffer kernel B's work too (SLS_NO_FUSED_B=1: never, for A/B runs)
-    static const bool no_fused_b = getenv("SLS_NO_FUSED_B") && getenv("SLS_NO_FUSED_B")[0] == '1';
+    // ... and with the keyframe's launch-order buffer kernel B's work too
+    constexpr bool no_fused_b = false;
     const bool fuse_b = fuse_c && cfg->block_order != nullptr && !no_fused_b;
     // the backward's blocks are launched most expensive first (cost recorded by the forward, sorted per XCD by eight
     // passenger workgroups — of the consumer's launch, or with fuse_b of the previous iteration's last launch): 8x2
@@ -520,21 +520,20 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         uint32_t *order = cfg->depth_order ? cfg->depth_order : w.order;
         depth_order_key_buffers(N, w.order_scratch, order, &okeys, &ovals, &n_dev);
         // Repairing the previous order: its first step (sorting windows of the old order by the new keys) rides in the
-        // preprocess launch — it needs nothing the preprocess produces (SLS_NO_MERGED_SORT=1: two launches, for A/B runs)
-        static const bool no_merge = getenv("SLS_NO_MERGED_SORT") && getenv("SLS_NO_MERGED_SORT")[0] == '1';
+        // preprocess launch — it needs nothing the preprocess produces
+        constexpr bool no_merge = false;
         const bool merged_sort = cfg->reuse_depth_order >= 1 && !no_merge;
         // Direct binning (sls_sort.hip) where it applies: no unsorted instance array, no scan of tiles_touched; the preprocess
         // then leaves the emission records in the form its first kernel gathers (rectangle + block box)
         const bool direct = bin_direct_possible(dc, N, cap);
-        // (SLS_NO_COARSE_BIN=1: the count table's rows are scanned by their own launch, as in the staged API; A/B)
-        static const bool no_coarse = getenv("SLS_NO_COARSE_BIN") && getenv("SLS_NO_COARSE_BIN")[0] == '1';
+        // (the staged API scans the count table's rows with a launch of its own instead)
+        constexpr bool no_coarse = false;
         DirectBin db;
         if (direct) db = make_direct_bin(dc, N, w.sort_scratch, (uint2 *)w.serec, cfg->reuse_depth_order >= 1, !no_coarse);
         // (the direct binning reads the emission records only — not the rectangles, the tile counts, the depths or the
         //  block boxes as arrays of their own; a repair whose window sort rides in the preprocess launch computes its
-        //  keys itself: 32 bytes per surfel that are not written.  SLS_FULL_PREPROCESS=1: all of them, A/B)
-        static const bool full_pre = getenv("SLS_FULL_PREPROCESS") && getenv("SLS_FULL_PREPROCESS")[0] == '1';
-        const bool trim = direct && !full_pre;
+        //  keys itself: 32 bytes per surfel that are not written)
+        const bool trim = direct;
         int rc = launch_preprocess_fwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, w.reg_accum, N, xyz,
                                        scaling_raw, rotation_raw, opacity_raw, w.rec, w.radii, trim ? nullptr : w.rect,
                                        trim ? nullptr : w.tiles, trim ? nullptr : w.depth,

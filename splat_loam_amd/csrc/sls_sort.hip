@@ -1620,9 +1620,9 @@ int launch_bin_sort(const DevCam &cam, int N, const uint32_t *count_ptr, uint32_
     const int idx_bits = bits_for((uint32_t)(N - 1)) > 0 ? bits_for((uint32_t)(N - 1)) : 1;
     const bool packed = fused_ranges && tile_bits + idx_bits <= 32;
     // The emission's workgroups as the chunks of the (single) sort pass: they count their instances' tiles themselves,
-    // the pass is row scan + scatter — one dependent launch less (SLS_NO_EMIT_HIST=1: the three-launch pass, A/B).
+    // the pass is row scan + scatter — one dependent launch less.
     // Needs the count table (tiles x workgroups) and the chunk starts to fit the sort's scratch.
-    static const bool no_emit_hist = getenv("SLS_NO_EMIT_HIST") != nullptr && getenv("SLS_NO_EMIT_HIST")[0] == '1';
+    constexpr bool no_emit_hist = false;
     // Only while the count table (tiles x chunks words, written, scanned and read back as scattered words) stays small:
     // at 500 k surfels / 64 x 2048 its 512 x 1954 words cost 14 us more than the launch saves, and chunks of 512
     // positions (half the table) make the scatter's waves too few and too long (+16 us); measured gains: -3.3 us per
@@ -1703,7 +1703,7 @@ static int direct_bins(const DevCam &cam)
     return 1 << (tb < 8 ? 8 : tb);
 }
 // Can the direct binning serve this camera / size / capacity?  (tiles <= 512, D10 off, 16-bit rectangle fields, the
-// count table inside the sort's scratch; SLS_NO_DIRECT_BIN=1: never — the emission + radix pass, for A/B runs)
+// count table inside the sort's scratch; otherwise the emission + radix pass)
 // words per row of the count table that serve either chunking, with or without the coarse table
 static size_t direct_max_stride(int N)
 {
@@ -1712,8 +1712,7 @@ static size_t direct_max_stride(int N)
 }
 bool bin_direct_possible(const DevCam &cam, int N, uint32_t cap)
 {
-    static const bool off = getenv("SLS_NO_DIRECT_BIN") != nullptr && getenv("SLS_NO_DIRECT_BIN")[0] == '1';
-    if (off || N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX > 512 || cam.GY > 64) return false;    // (pack_rect32's fields)
+    if (N <= 0 || cap == 0 || cam.tile_cull != 0 || cam.GX > 512 || cam.GY > 64) return false;    // (pack_rect32's fields)
     if (cam.GX * cam.GY > kDirectMaxBins) return false;
     // (its emission records carry the surfel's block box: images the box can describe)
     if (!block_box_fits(cam.GX * kTileW, cam.H)) return false;

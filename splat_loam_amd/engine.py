@@ -116,9 +116,9 @@ class MappingEngine:
         # With the status mirror (the iteration's last kernel stores the status block into pinned host memory, word 7
         # last) the host needs no event to know that an iteration has finished: it arms words 0 and 7 of the slot with a
         # value the device never writes and polls them — no event record on the stream, no event wait
-        # (SLS_NO_STATUS_POLL=1: events, for A/B runs)
+        # (status_poll = False: events; kept as an attribute for the equality tests, its verdict is in HISTORY.md)
         self._lag_np = self._lag_host.numpy()
-        self.status_poll = os.environ.get("SLS_NO_STATUS_POLL", "0") != "1"
+        self.status_poll = True
         self._lag_polled = [False, False]
         self._group = None
         self._lag_ready = []              # statuses of finished iterations not handed out yet (lagged mode)
@@ -128,8 +128,7 @@ class MappingEngine:
         # instead of recomputed when the next iteration renders the same keyframe (reuse_depth_order)
         self.reuse_depth_order = True
         # the loss stage inside the tile backward (no launch of its own; the backward's launch order then comes from the
-        # keyframe's previous iteration): same gradients bit for bit.  SLS_NO_FUSED_B=1 in the library's environment
-        # switches it off as well (A/B runs)
+        # keyframe's previous iteration): same gradients bit for bit
         self.inline_loss_stage = True
         self.repair_span = 256            # iterations an extra repair round stays on after a repair that did not reach
         self._repair_rounds, self._repair_until = 1, 0
@@ -139,7 +138,7 @@ class MappingEngine:
         self._ws_ready = False
         self._ws_hw = None
         self._ws_det = None
-        self.status_mirror = os.environ.get("SLS_NO_STATUS_MIRROR", "0") != "1"   # (A/B switch, lagged mode)
+        self.status_mirror = True          # (False: the status through a device -> host copy; lagged mode)
         # one depth-order buffer per keyframe (the mapper samples keyframes at random, slam/mapper.py:152-156):
         # id(camera) -> [order tensor, iteration it was last written, weak reference to the camera (an id can be
         # reused by a new object once the old keyframe is gone)]; an order older than max_order_age
@@ -168,6 +167,8 @@ class MappingEngine:
         # sparse scheme only: overlap the exchange with what does not need it — the bitmaps are all-gathered on a side
         # stream while the projection's backward runs (SlsMappingConfig.phase), the union's rows are reduced while Adam
         # updates the surfels outside the union (sls_adam_step_sparse part 1 / 2).  Same parameters to the bit.
+        # (on one GPU in a one-rank group the overlapped form costs +100 us per iteration against +50 serial, HISTORY #64: an
+        #  option for a measured multi-GPU run, not a default; the environment variable is how the tests' spawned ranks get it)
         self.overlap = os.environ.get("SLS_DP_OVERLAP", "0") == "1"
         self._side = None                 # the side stream the collectives are issued from
         self._last_call = None            # (arguments, config) of the last sls_mapping_step: phase 2 repeats them
@@ -241,13 +242,12 @@ class MappingEngine:
         at 500 k surfels (4 / 12 / 48; looser values fail repairs, each costs a void iteration + a rebuild) and at
         170 k / 50 k (12 / 32 / 200 without a failure, -1.5 % / -2.5 % per iteration with the mapper's keyframe
         sampling), hence the scale with 500 k / N, capped at 3.  A further repair round costs 9 us, the radix sort 90.
-        SLS_ORDER_AGE_ROUND2 / _ROUND3 / _ROUND4 / _EXTRA override."""
+        (The four ages are plain attributes; what other values cost is in HISTORY.md #44, #50, #51.)"""
         scale = min(max(500000.0 / max(self.N, 1), 1.0), 3.0)
-        env = os.environ.get
-        self.max_order_age = int(env("SLS_ORDER_AGE_ROUND2", str(int(4 * scale))))
-        self.order_age_round3 = int(env("SLS_ORDER_AGE_ROUND3", str(int(12 * scale))))
-        self.max_order_age_extra = int(env("SLS_ORDER_AGE_EXTRA", str(int(48 * scale))))
-        self.order_age_round4 = int(env("SLS_ORDER_AGE_ROUND4", "1000000"))
+        self.max_order_age = int(4 * scale)
+        self.order_age_round3 = int(12 * scale)
+        self.max_order_age_extra = int(48 * scale)
+        self.order_age_round4 = 1000000
 
     def _params(self):
         m = self.model

@@ -101,8 +101,8 @@ def get_camera(settings: GaussianRasterizationSettings, device: torch.device) ->
     off = getattr(settings, "pix_offset", None)
     off = pix_offset() if off is None else (float(off[0]), float(off[1]))
     tcm = getattr(settings, "tile_cull_min", None)
-    if tcm is None:        # A/B switches: SLS_NO_TILE_CULL=1 — D10 off (whole rectangles); SLS_TILE_CULL_MIN=k — threshold
-        tcm = 1 if os.environ.get("SLS_NO_TILE_CULL", "0") == "1" else int(os.environ.get("SLS_TILE_CULL_MIN", "0"))
+    if tcm is None:        # SLS_TILE_CULL_MIN=k: D10's threshold for every camera built here (0 / 1: off, the default)
+        tcm = int(os.environ.get("SLS_TILE_CULL_MIN", "0"))
     lean = getattr(settings, "lean_allmap", None)
     if lean is None:
         lean = os.environ.get("SLS_LEAN_ALLMAP", "0") == "1"
@@ -269,9 +269,9 @@ def rasterize_forward(settings: GaussianRasterizationSettings, means3D, opacitie
     Ra = max(R, 1)
     ssb = int(lib.sls_sort_scratch_bytes(R))
     # forward -> backward hand-over: 128 B per instance of capacity (room for every list entry in each of a tile's 16
-    # pixel blocks; only what contributes is written).  SLS_NO_HANDOVER=1 (memory-tight callers): no buffer, the
-    # backward culls the tiles' lists itself (about a third slower at the mapper's sizes).
-    hand_over = os.environ.get("SLS_NO_HANDOVER", "0") != "1"
+    # pixel blocks; only what contributes is written).  (Without it — block_masks = NULL at the C-ABI — the backward
+    # culls the tiles' lists itself, about a third slower at the mapper's sizes.)
+    hand_over = True
     allmap = s._views["allmap"] = torch.empty((7, H, W), dtype=torch.float32, device=dev)
     spec2 = [("ranges", "i32", (T, 2)), ("pix_state", "f32", (H * W, 4)),
              ("pix_contrib", "i32", (H * W, 2)), ("tile_consumed", "i32", (T,)),
@@ -491,7 +491,7 @@ def rasterize_forward_ws(settings: GaussianRasterizationSettings, means3D, opaci
     if e.rounds > 1 and e.calls >= e.rounds_until:
         e.rounds, e.rounds_until = e.rounds - 1, e.calls + 256
     reuse = 0
-    if age is not None and age <= int(48 * scale) and os.environ.get("SLS_NO_ORDER_REUSE", "0") != "1":
+    if age is not None and age <= int(48 * scale):
         reuse = min(e.rounds + (1 if age > int(4 * scale) else 0) + (1 if age > int(12 * scale) else 0), 4)
     radii = torch.empty((N,), dtype=torch.int32, device=dev)
     allmap = torch.empty((7, H, W), dtype=torch.float32, device=dev)
