@@ -146,3 +146,41 @@ def test_bound_render_serves_no_grad_callers(device, monkeypatch):
         assert float((a["surf_normal"] - b["surf_normal"].detach()).abs().max()) <= 2e-4
     finally:
         fused_render.uninstall()
+
+
+REAL_SCRIPT = """
+import os, sys, types
+sys.path.insert(0, {root!r}); sys.path.insert(0, "/root/reference")
+os.environ["SLS_FUSED_RENDER"] = "1"
+for name in ("plyfile", "rerun"):                       # (imports of the checkout that the image lacks; nothing render() runs)
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["rerun"].__path__ = []
+sys.modules["rerun.blueprint"] = sys.modules["rerun"].blueprint = types.ModuleType("rerun.blueprint")
+sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+try:
+    import omegaconf
+except ImportError:
+    oc = types.ModuleType("omegaconf"); oc.OmegaConf = type("OmegaConf", (), {{}}); sys.modules["omegaconf"] = oc
+import slam.mapper as sm                                 # holds `render` as `from gaussian_renderer import render` left it
+import gaussian_renderer
+from splat_loam_amd import fused_render
+held = sm.render
+code_before = held.__code__
+assert held is gaussian_renderer.render and fused_render._PATCHED is None
+try:
+    gaussian_renderer.GaussianRasterizer(raster_settings=None)      # what the first render() does first
+finally:
+    print(fused_render._PATCHED is held, held.__code__ is not code_before, fused_render._ORIGINAL.__code__ is code_before,
+          held.__defaults__, held.__code__.co_varnames[:3])
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gaussian_renderer"), reason="needs the Splat-LOAM checkout (build container only)")
+def test_binding_installs_on_the_reference_checkout():
+    """Against the reference's OWN gaussian_renderer/__init__.py (read where it lies, nothing copied): its `render` is the
+    plain three-argument function the binding was written for; the first GaussianRasterizer() exchanges the code of the very
+    object slam/mapper.py imported, and the reference's code lives on in `_ORIGINAL`."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", REAL_SCRIPT.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "True True True (0.0,) ('camera', 'model', 'depth_ratio')", out.stdout
