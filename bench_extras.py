@@ -5,6 +5,7 @@ object.  Every figure is a whole mapping iteration (or what its key says) on the
 unless stated otherwise.
 
   single_keyframe      one keyframe re-rendered every iteration (rounds 1-2's headline)
+  uniform_keyframes    the window's keyframes drawn uniformly (prob_view_last_keyframe: null, as half the reference's configs)
   full_sort            depth order sorted from scratch every iteration
   iterations_400_800   400 timed iterations after 400 un-timed ones (the optimisation changes the workload)
   deterministic        integer accumulation of the gradient records: two launches / one launch with predicted scales
@@ -53,6 +54,18 @@ def _timed(dev, fn, n_w, n_t):
 def single_keyframe(c):
     m, e = c.fresh()
     d, _ = c.run(m, e, [c.cams[0]], c.args.warmup * c.ips, c.n_iters)
+    return {"ms_per_iteration": round(d / c.n_iters * 1e3, 4), "Msplats_per_s": round(c.N / (d / c.n_iters) / 1e6, 1),
+            "repeated_iterations": dict(e.stats)}
+
+
+def uniform_keyframes(c):
+    """The window's keyframes drawn UNIFORMLY — `prob_view_last_keyframe: null`, which half of the reference's configs set
+    (configs/kitti/kitti-00-odom.yaml:14, ncd/quad-easy-*.yaml:14; slam/mapper.py:142-149) — instead of the geometric
+    draw of kitti.yaml / ncd.yaml the headline uses: every keyframe's depth order is ~8 iterations old when it is visited
+    again, and the window's far end (surfels next to the sensor: the heavy keyframes) is visited as often as its near end."""
+    m, e = c.fresh()
+    pick = np.random.default_rng(4).integers(0, c.n_kf, size=(c.args.warmup * c.ips + c.n_iters) * 2) if c.n_kf > 1 else None
+    d, _ = c.run(m, e, c.window, c.args.warmup * c.ips, c.n_iters, pick=pick)
     return {"ms_per_iteration": round(d / c.n_iters * 1e3, 4), "Msplats_per_s": round(c.N / (d / c.n_iters) / 1e6, 1),
             "repeated_iterations": dict(e.stats)}
 
@@ -359,7 +372,7 @@ def update_model(c, n0=150_000, h2=128, w2=1024, n_kf=8, new_keyframes=4, num_it
             "wall_over_iterations": round(mean_wall / ((num_iterations + 1) * it_ms), 4)}
 
 
-ALL = {"single_keyframe": single_keyframe, "full_sort": full_sort, "iterations_400_800": iterations_400_800,
+ALL = {"single_keyframe": single_keyframe, "uniform_keyframes": uniform_keyframes, "full_sort": full_sort, "iterations_400_800": iterations_400_800,
        "deterministic": deterministic, "real_sizes": real_sizes, "sparse_union": sparse_union, "dropin": dropin,
        "dp_world1": dp_world1, "update_model": update_model}
 
