@@ -180,6 +180,50 @@ __device__ __forceinline__ void count_rect_tiles_wave(uint32_t r32, int GX, uint
     }
 }
 
+// Counting a whole workgroup's rectangles through per-row DIFFERENCE counts (the counting merge and gather_count: one
+// histogram per workgroup).  A rectangle row of ncols >= kDiffCols tiles is two LDS atomics — +1 where it begins, -1
+// behind its end (three when it wraps) — instead of ncols; narrower rows add to their tiles directly.  A surfel within a
+// metre of the sensor has rows of 30 ... 128 tiles, and a chunk at the front of the depth order holds 70 k instances of
+// them (profiles/r05a_bin_tail.txt): the merge took 25-33 us at the bench window's last keyframes against 13 at its first.
+// s_diff: (GX + 1) words per tile row, zeroed by the caller; diff_finish() turns them into counts and adds them to s_hist.
+// Tile rows must be whole waves of the finishing loop: GX % 64 == 0 (else the callers count the old way).
+constexpr int kDiffCols = 8;
+// (*s_wide, zeroed by the caller: set where a row went into the difference counts — a workgroup of far surfels, whose
+//  rectangles are one to three tiles wide, then skips diff_finish and its barrier)
+__device__ __forceinline__ void count_rect_rows_diff(uint32_t r32, int GX, uint32_t *s_hist, int *s_diff, int *s_wide)
+{
+    const int txlo = (int)(r32 & 511u), ncols = (int)((r32 >> 9) & 1023u), tylo = (int)((r32 >> 19) & 63u), nrows = (int)(r32 >> 25);
+    if (ncols < kDiffCols) { count_rect_tiles(r32, GX, s_hist); return; }
+    *s_wide = 1;
+    const int end = txlo + ncols;
+    for (int y = 0; y < nrows; ++y) {
+        int *row = s_diff + (tylo + y) * (GX + 1);
+        atomicAdd(&row[txlo], 1);
+        if (end <= GX) atomicAdd(&row[end], -1);            // (slot GX: behind the row, never read)
+        else { atomicAdd(&row[0], 1); atomicAdd(&row[end - GX], -1); }
+    }
+}
+// every thread of the workgroup; bins = GY * GX tiles, threads a multiple of 64; between two __syncthreads of the caller
+__device__ __forceinline__ void diff_finish(int GX, int bins, uint32_t *s_hist, const int *s_diff, int tid, int nthreads)
+{
+    const int lane = tid & 63;
+    for (int d0 = (tid >> 6) * 64; d0 < bins; d0 += nthreads) {      // a wave takes 64 consecutive tiles of ONE row
+        const int d = d0 + lane, row = d0 / GX, x0 = d0 - row * GX;
+        const int *r = s_diff + row * (GX + 1);
+        int carry = 0;
+        for (int x = lane; x < x0; x += 64) carry += r[x];            // (the row's tiles in front of this wave's 64)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) carry += __shfl_xor(carry, off, 64);
+        int v = r[x0 + lane];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, off, 64);
+            if (lane >= off) v += u;
+        }
+        s_hist[d] += (uint32_t)(carry + v);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // step 1 of a pass: per-wave-chunk digit histogram -> cnt[digit][chunk]
 // ---------------------------------------------------------------------------
@@ -696,9 +740,14 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     __shared__ __attribute__((aligned(16))) ulonglong2 s_pairs[kResortThreads];
     __shared__ uint32_t s_part[4][2];          // [256-block of the window][wave inside it]
     __shared__ uint32_t s_hist[DIRECT ? kDirectMaxBins : 1];
+    __shared__ int s_diff[DIRECT ? kDirectMaxBins + 64 : 1];      // per tile row GX + 1 difference counts (count_rect_rows_diff)
+    __shared__ int s_wide;
     __shared__ uint64_t s_win[PRE ? 2 * kResortWindow : 1];
+    const bool use_diff = DIRECT && GX % 64 == 0 && db.bins % GX == 0 && db.bins / GX <= 64;
     if (DIRECT) {
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) s_hist[d] = 0u;   // (the network's barriers come before its use)
+        for (int d = threadIdx.x; d < kDirectMaxBins + 64; d += kResortThreads) s_diff[d] = 0;
+        if (threadIdx.x == 0) s_wide = 0;
     }
     const int base = blockIdx.x * kResortWindow - kResortWindow / 2, o0 = 2 * (int)threadIdx.x;
     SLS_MT(0);
@@ -760,7 +809,8 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
         for (int q = 0; q < 2; ++q) {
             const int pos = base + o0 + q;
             if (pos >= 0 && pos < N) db.serec[pos] = er[q];
-            count_rect_tiles_wave(er[q].x, GX, s_hist);
+            if (use_diff) count_rect_rows_diff(er[q].x, GX, s_hist, s_diff, &s_wide);
+            else count_rect_tiles_wave(er[q].x, GX, s_hist);
         }
     } else {
 #pragma unroll
@@ -785,6 +835,10 @@ __global__ __launch_bounds__(kResortThreads) void resort_merge_kernel(int N, con
     }
     __syncthreads();
     SLS_MT(2);
+    if (DIRECT && use_diff && s_wide) {          // (workgroup-uniform: read behind the barrier)
+        diff_finish(GX, db.bins, s_hist, s_diff, (int)threadIdx.x, kResortThreads);
+        __syncthreads();
+    }
     if (DIRECT) {
         for (int d = threadIdx.x; d < db.bins; d += kResortThreads) {
             const uint32_t c = s_hist[d];
@@ -806,7 +860,12 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
                                                                     const uint32_t *__restrict__ sbox, DirectBin db)
 {
     __shared__ uint32_t s_hist[kDirectMaxBins];
+    __shared__ int s_diff[kDirectMaxBins + 64];
+    __shared__ int s_wide;
+    const bool use_diff = GX % 64 == 0 && db.bins % GX == 0 && db.bins / GX <= 64;
     if ((int)threadIdx.x < db.bins) s_hist[threadIdx.x] = 0u;
+    for (int d = threadIdx.x; d < kDirectMaxBins + 64; d += kDirectChunk) s_diff[d] = 0;
+    if (threadIdx.x == 0) s_wide = 0;
     __syncthreads();
     const int pos = blockIdx.x * kDirectChunk + (int)threadIdx.x;
     uint2 er = make_uint2(0u, 0u);
@@ -814,8 +873,13 @@ __global__ __launch_bounds__(kDirectChunk) void gather_count_kernel(int N, int G
         er = load_emit_record(erec_box, rect, sbox, order[pos]);
         if (db.serec) db.serec[pos] = er;
     }
-    count_rect_tiles_wave(er.x, GX, s_hist);
+    if (use_diff) count_rect_rows_diff(er.x, GX, s_hist, s_diff, &s_wide);
+    else count_rect_tiles_wave(er.x, GX, s_hist);
     __syncthreads();
+    if (use_diff && s_wide) {
+        diff_finish(GX, db.bins, s_hist, s_diff, (int)threadIdx.x, kDirectChunk);
+        __syncthreads();
+    }
     if ((int)threadIdx.x < db.bins) {
         const uint32_t c = s_hist[threadIdx.x];
         db.cnt[(size_t)threadIdx.x * db.stride + blockIdx.x] = c;
