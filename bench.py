@@ -64,8 +64,6 @@ def main(extras_only=None):
     ap.add_argument("--full-sort", action="store_true", help="sort the depth order from scratch every iteration")
     ap.add_argument("--dp-mode", choices=("auto", "rs_ag", "allreduce", "sparse"), default=os.environ.get("SLS_DP_MODE", "auto"),
                     help="N > 1: the gradient exchange (DESIGN.md section 6); auto: time all three un-timed, take the fastest")
-    ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("SLS_DP_OVERLAP", "0") == "1",
-                    help="N > 1, sparse: collectives on a side stream (MappingEngine.overlap)")
     ap.add_argument("--iters-per-step", type=int, default=10,
                     help="mapping iterations inside ONE bench step (--steps 20 then times 200 iterations; 20 alone are "
                          "4 ms of GPU time); ms_per_step is a whole step, config.ms_per_iteration one iteration")
@@ -146,7 +144,6 @@ def main(extras_only=None):
             engine.reuse_depth_order = not full_sort
             if dp_mode:
                 engine.dp_mode = dp_mode
-            engine.overlap = bool(args.dp_overlap)
         return model, engine
 
     def barrier():
@@ -346,7 +343,7 @@ def main(extras_only=None):
                                    else "sorted from scratch"),
                    "repeated_iterations": dict(engine.stats) if engine is not None else None},
         "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,
-        "dp_mode": (comm["mode"] if comm else dp_mode), "dp_overlap": bool(args.dp_overlap) if world > 1 else None,
+        "dp_mode": (comm["mode"] if comm else dp_mode), "dp_overlap": None,
         "dp_calibration_ms": dp_cal,
         "allreduce_us": comm["exchange_us"] if comm else None, "adam_us": comm["adam_us"] if comm else None,
         "comm": comm,

@@ -302,10 +302,9 @@ def dp_world1(c):
     dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=c.dev)
     out = {"single_gpu_ms_per_iteration": round(c.ms_per_iter, 4)}
     try:
-        for name, mode, overlap in (("sparse", "sparse", False), ("sparse_overlapped", "sparse", True),
-                                    ("allreduce", "allreduce", False), ("rs_ag", "rs_ag", False)):
+        for name, mode in (("sparse", "sparse"), ("allreduce", "allreduce"), ("rs_ag", "rs_ag")):
             m, e = c.fresh(dp_mode=mode)
-            e.exchange_at_world_1, e.overlap = True, overlap
+            e.exchange_at_world_1 = True
             d, _ = c.run(m, e, c.window, c.args.warmup * c.ips, c.n_iters, pick=c.pick_rank)
             out[name + "_ms_per_iteration"] = round(d / c.n_iters * 1e3, 4)
             out[name + "_bytes_per_rank"] = int(e.exchanged_bytes)

@@ -376,11 +376,23 @@ typedef struct SlsMappingConfig {
                               * has no launch of its own: the tile backward computes the per-pixel loss terms and their
                               * gradient itself (default 8x2 kernel, depth_ratio = 0; otherwise the buffer is ignored).
                               * Same gradients bit for bit; loss_sums are added up in another order (last bits) */
+    const uint64_t *union_bitmap;  /* phase 2 of the touched-set exchange (below; apply_adam = 1, N even): the OR of the ranks'
+                              * bitmaps (sls_grad_union's output).  The backward of the projection then WRITES the gradient
+                              * row of every surfel of the union into its slot of `grad_compact` (no flat bucket, no packing
+                              * launch) and leaves its parameters alone; every other surfel — zero gradient on every rank —
+                              * gets its Adam update right there, as on one GPU.  After the SUM of the rows,
+                              * sls_adam_step_union updates the union's surfels.  A non-zero gradient outside
+                              * the union (a bitmap that was no superset) sets bit 5 of status.overflow. */
+    const uint32_t *union_prefix;  /* sls_grad_union's word_prefix */
+    float *grad_compact;     /* capacity x 10 floats */
+    uint32_t *grad_compact_index;  /* capacity uint32: the surfel of every slot (for sls_adam_step_union) */
+    uint32_t grad_compact_capacity;
+    uint32_t reserved2;
 } SlsMappingConfig;
 typedef struct SlsMappingStatus {
     uint32_t R;           /* tile instances of this iteration */
     uint32_t overflow;    /* bit 0: R > R_capacity; bit 1: depth-order repair failed (reuse_depth_order); bit 2: the
-                           * sparse exchange's compact buffer was too small (sls_grad_compact); bit 3: a predicted scale
+                           * sparse exchange's compact buffer was too small (sls_grad_union / sls_grad_compact); bit 3: a predicted scale
                            * of the one-pass deterministic accumulation was off (deterministic = 2: repeat with 1).
                            * Non-zero: results of this iteration are void, Adam was skipped */
     float loss_sums[4];   /* sums of the three pixel terms, pixel-loss total */
@@ -504,12 +516,29 @@ int sls_adam_step_reduced(const SlsAdamGroup *groups_host, int ngroups, double b
  *        rotation 4]; status->exchange_count = K = size of the union; K > capacity sets bit 2 of
  *        status->overflow (void: repeat with more room); status->overflow = the group's verdict
  *   all-reduce(compact[0 .. 10 * K_send), SUM)                   K_send <= capacity chosen by the host
+ *        (grads_flat / compact null: the union and its prefix only — sls_grad_union)
  *   sls_adam_step_sparse(...)                                    Adam on every surfel, gradient from its slot or 0;
  *        skipped when the iteration is void; copies the status block to status_mirror (HOST-visible) if given.
  *        `part`: 0 = every surfel in one launch; 1 = only the surfels OUTSIDE the union (their gradient is zero on
  *        every rank: their update needs nothing from the collective, so this launch can run while the rows are being
  *        reduced); 2 = only the union's surfels (after the reduction; mirrors the status) — 1 then 2 give the bits of 0.
  * word_prefix: DEVICE scratch of (N + 63) / 64 uint32. */
+/* The form MappingEngine runs (dp_mode "sparse"): the rows never exist as a flat bucket.
+ *   sls_mapping_step(apply_adam = 0, grad_bitmap = B, phase = 1)  up to the tile backward; B = the surfels it reached or
+ *                                                                 the regulariser may push on (a superset) + the verdict
+ *   all-gather(B);  sls_grad_union(N, bitmaps, G, U, capacity, prefix, status)      U, prefix, K, the group's verdict
+ *   sls_mapping_step(apply_adam = 1, phase = 2, union_bitmap = U, union_prefix = prefix, grad_compact = compact,
+ *                    grad_compact_capacity = capacity)            rows of the union -> their slots; Adam everywhere else
+ *   all-reduce(compact[0 .. 10 * K_send), SUM);  sls_adam_step_union(...)           Adam on the union; mirrors the status */
+int sls_grad_union(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *union_bitmap, uint32_t capacity,
+                   uint32_t *word_prefix, struct SlsMappingStatus *status_dev, void *stream);
+/* Adam on the union's surfels only, a thread per slot (compact_index[slot] = the surfel; status->exchange_count slots
+ * are live); skipped when the iteration is void; copies the status block to status_mirror (HOST-visible) if given. */
+int sls_adam_step_union(int N, float *xyz, float *opacity_raw, float *scaling_raw, float *rotation_raw,
+                        const uint32_t *compact_index, const float *compact_reduced, uint32_t capacity, float *exp_avg,
+                        float *exp_avg_sq, float lr_xyz, float lr_opacity, float lr_scaling, float lr_rotation, double beta1,
+                        double beta2, double eps, int64_t step, struct SlsMappingStatus *status_dev,
+                        struct SlsMappingStatus *status_mirror, void *stream);
 size_t sls_grad_bitmap_words(int N);
 int sls_grad_compact(int N, const uint64_t *bitmaps, int n_bitmaps, uint64_t *union_bitmap, const float *grads_flat,
                      float *compact, uint32_t capacity, uint32_t *word_prefix, struct SlsMappingStatus *status_dev,

@@ -42,6 +42,8 @@ class SlsMappingConfig(C.Structure):
         ("det_prev", C.c_void_p),
         ("phase", C.c_int32), ("reserved", C.c_int32),
         ("block_order", C.c_void_p),
+        ("union_bitmap", C.c_void_p), ("union_prefix", C.c_void_p), ("grad_compact", C.c_void_p),
+        ("grad_compact_index", C.c_void_p), ("grad_compact_capacity", C.c_uint32), ("reserved2", C.c_uint32),
     ]
 
 
@@ -115,6 +117,8 @@ _PROTOS = {
     "sls_adam_step_reduced": (C.c_int, [C.POINTER(SlsAdamGroup), C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_int64, _VP, _VP, _VP, _VP]),
     "sls_grad_bitmap_words": (C.c_size_t, [C.c_int]),
+    "sls_grad_union": (C.c_int, [C.c_int, _VP, C.c_int, _VP, C.c_uint32, _VP, _VP, _VP]),
+    "sls_adam_step_union": (C.c_int, [C.c_int] + [_VP] * 6 + [C.c_uint32, _VP, _VP] + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, _VP, _VP, _VP]),
     "sls_grad_compact": (C.c_int, [C.c_int, _VP, C.c_int, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
     "sls_adam_step_sparse": (C.c_int, [C.c_int] + [_VP] * 9 + [C.c_float] * 4 + [C.c_double] * 3 + [C.c_int64, C.c_int, _VP, _VP, _VP]),
     "sls_projector_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -369,6 +369,13 @@ struct AdamFuse {
     const uint32_t *order_cost;
     uint32_t *order_out;
     int publisher;          // set by launch_preprocess_bwd: a workgroup of its own does the status duties above
+    // touched-set exchange, second half (SlsMappingConfig.union_bitmap): a surfel of the union writes its 10 gradient values
+    // into its slot of `compact` and keeps its parameters; every other surfel takes the fused Adam update (enabled = 1)
+    const uint64_t *union_bitmap;
+    const uint32_t *union_prefix;
+    float *compact;
+    uint32_t *compact_idx;
+    uint32_t compact_cap;
 };
 
 // Copy of an iteration's finished status block (8 words) into its pinned host mirror, by ONE lane.  The host polls

@@ -468,8 +468,12 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
     SLS_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     // (every argument check before the first launch: an argument error must not leave half an iteration on the stream)
     SLS_REQUIRE(cfg->phase >= 0 && cfg->phase <= 2, "phase: 0 whole iteration, 1 up to the tile backward, 2 the rest");
-    SLS_REQUIRE(!cfg->grad_bitmap || (!cfg->apply_adam && !cfg->grad_chunk),
+    SLS_REQUIRE(!cfg->grad_bitmap || ((!cfg->apply_adam || cfg->union_bitmap) && !cfg->grad_chunk),
                 "the gradient bitmap belongs to apply_adam = 0 with the flat bucket");
+    SLS_REQUIRE(!cfg->union_bitmap || (cfg->phase == 2 && cfg->apply_adam && cfg->union_prefix && cfg->grad_compact && cfg->grad_compact_index &&
+                                       !cfg->grad_chunk && !cfg->keep_grads && (N % 2) == 0 &&
+                                       ((((uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0)),
+                "union_bitmap: phase 2 with apply_adam = 1, the union's prefix and row buffer, even N, 16-byte aligned moments");
     SLS_REQUIRE(!cfg->grad_chunk ||
                     (!cfg->apply_adam && cfg->grad_ranks >= 1 && (cfg->grad_chunk % 4u) == 0 && (N % 2) == 0 &&
                      (uint64_t)cfg->grad_chunk * cfg->grad_ranks >= (uint64_t)10 * (uint64_t)N &&
@@ -653,6 +657,10 @@ int sls_mapping_step(const SlsCamera *cam, int N, float *xyz, float *scaling_raw
         fuse.lr_scaling = cfg->lr_scaling; fuse.lr_rotation = cfg->lr_rotation;
         fuse.exp_avg = exp_avg; fuse.exp_avg_sq = exp_avg_sq;
         fuse.skip_flag = &status_dev->overflow;
+    }
+    if (cfg->union_bitmap) {
+        fuse.union_bitmap = cfg->union_bitmap; fuse.union_prefix = cfg->union_prefix;
+        fuse.compact = cfg->grad_compact; fuse.compact_idx = cfg->grad_compact_index; fuse.compact_cap = cfg->grad_compact_capacity;
     }
     rc = launch_preprocess_bwd(dc, 1, cfg->scaling_max, cfg->scaling_max_penalty, N, xyz, scaling_raw, rotation_raw,
                                opacity_raw, w.radii, w.grec, g_xyz, g_sc, g_rot, g_op, st, &fuse);

@@ -710,6 +710,27 @@ __global__ __launch_bounds__(256) void preprocess_bwd_kernel(
         drots[i] = dq;
         dopac[i] = dop;
     }
+    if (af.union_bitmap) {
+        // keyframe-parallel, touched-set exchange: the union's surfels hand their rows to the collective (slot = rank of
+        // the surfel inside the union, the same on every rank); the others have a zero gradient on EVERY rank and are
+        // updated below like any surfel of the one-GPU iteration
+        const uint64_t word = af.union_bitmap[i >> 6];
+        const int b = i & 63;
+        if ((word >> b) & 1ull) {
+            const uint32_t slot = af.union_prefix[i >> 6] + (uint32_t)__popcll(word & ((1ull << b) - 1ull));
+            if (slot < af.compact_cap) {
+                float *o = af.compact + (size_t)slot * 10;
+                o[0] = dm[0]; o[1] = dm[1]; o[2] = dm[2]; o[3] = dop; o[4] = ds.x; o[5] = ds.y;
+                o[6] = dq.x; o[7] = dq.y; o[8] = dq.z; o[9] = dq.w;
+                af.compact_idx[slot] = (uint32_t)i;
+            }
+            return;
+        }
+        // (the early bitmap is a superset of the non-zero gradients by construction: say so if it ever is not)
+        if (dm[0] != 0.0f || dm[1] != 0.0f || dm[2] != 0.0f || dop != 0.0f || ds.x != 0.0f || ds.y != 0.0f ||
+            dq.x != 0.0f || dq.y != 0.0f || dq.z != 0.0f || dq.w != 0.0f)
+            if (af.status_src) atomicOr(af.status_src + 1, 32u);
+    }
     if (af.enabled && *af.skip_flag == 0u) {
         // moments in the bucket layout [xyz 3N | opacity N | scaling 2N | rotation 4N]
         const size_t n = (size_t)N, ix = 3 * (size_t)i, io = 3 * n + i, is = 4 * n + 2 * (size_t)i, ir = 6 * n + 4 * (size_t)i;

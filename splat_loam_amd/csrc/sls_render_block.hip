@@ -501,6 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
     bool wave_done = wave_all(done);
     uint32_t st_staged = 0, st_pass = 0, st_steps = 0, st_lanes = 0, st_slots = 0, st_geom = 0;   // diagnostics only
     uint32_t ccnt = 0;                            // entries of this block's compact list so far
+    uint32_t hs_n = 0, hs_l = 0, hs_r = 0, hs_q[4] = { 0, 0, 0, 0 };   // diagnostics only
 
     const BlockCone cone = make_block_cone(cam, (float)x0 + 0.5f * (float)(BW - 1), (float)y0 + 0.5f * (float)(BH - 1),
                                            0.5f * (float)(BW - 1), 0.5f * (float)(BH - 1));
@@ -657,6 +658,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
                 Tr = I3;
             }
             if (blk_mask && upd) s_flag[j] = 1u;   // (same value from every lane: plain LDS store)
+            if (DBG) {     // what finer blocks would save: entries that reach only one 4x2 half / one 2x2 quarter of the block
+                const uint64_t ub = wave_ballot(upd);
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t m = (ub >> q) & 0x1111111111111111ull;
+                    if (!m) continue;
+                    ++hs_n;
+                    hs_l += (m & 0x0000FFFF0000FFFFull) ? 1u : 0u; hs_r += (m & 0xFFFF0000FFFF0000ull) ? 1u : 0u;
+                    for (int c = 0; c < 4; ++c) hs_q[c] += (m & (0x000000FF000000FFull << (8 * c))) ? 1u : 0u;
+                }
+            }
             // (w = 0 where the lane does not take part and the depth of an evaluated pair is finite: no select needed;
             //  the distortion's 1 / depth below wants a harmless value there)
             const float dep = LEAN ? e.depth : (upd ? e.depth : 1.0f);
@@ -728,6 +739,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
         uint32_t *st = dbg_cycles + (size_t)T * kPerTile;
         atomicAdd(&st[0], st_staged); atomicAdd(&st[1], st_pass);
         atomicAdd(&st[2], st_steps); atomicAdd(&st[3], st_lanes); atomicAdd(&st[4], st_slots); atomicAdd(&st[5], st_geom);
+        const uint32_t qmax = max(max(hs_q[0], hs_q[1]), max(hs_q[2], hs_q[3]));
+        atomicAdd(&st[6], hs_n); atomicAdd(&st[7], hs_l + hs_r); atomicAdd(&st[8], hs_q[0] + hs_q[1] + hs_q[2] + hs_q[3]);
+        atomicAdd(&st[9], (hs_n + 3u) / 4u); atomicAdd(&st[10], (max(hs_l, hs_r) + 3u) / 4u); atomicAdd(&st[11], (qmax + 3u) / 4u);
+        atomicMax(&st[12], (hs_n + 3u) / 4u); atomicMax(&st[13], (max(hs_l, hs_r) + 3u) / 4u); atomicMax(&st[14], (qmax + 3u) / 4u);
     }
 }
 

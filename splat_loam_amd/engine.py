@@ -20,13 +20,18 @@ with the same replicated model.  Two exchange schemes (`dp_mode`):
       replicas identical by construction;
   "allreduce": the flat 10*N bucket (+2 void words) is all-reduced in one RCCL
       collective and every rank applies the same guarded Adam update;
-  "sparse": only the TOUCHED set travels (a keyframe reaches ~10 % of the surfels):
-      the ranks' gradient bitmaps are OR-reduced (N/8 bytes), the union's 40-byte
-      gradient rows are packed in surfel order (sls_grad_compact) and SUM-reduced,
-      sls_adam_step_sparse updates every surfel from its slot or with a zero
-      gradient.  The collective's size is a host-side capacity that follows the
-      union's measured size; a union larger than it voids the iteration on every
-      rank (bit 2 of the status word) and it is repeated with more room.
+  "sparse" (even N): only the TOUCHED set travels (a keyframe reaches ~10 % of the
+      surfels).  Behind the tile backward every rank knows which surfels CAN have a
+      gradient (reached by its keyframe, or pushed by the scale regulariser): these
+      bitmaps are all-gathered (N/8 bytes each) and OR-ed (sls_grad_union); the
+      projection's backward then writes the union's 40-byte rows straight into their
+      slots of the collective's buffer and applies Adam to every surfel OUTSIDE the
+      union right there (zero gradient on every rank: the one-GPU update); the rows
+      are SUM-reduced and sls_adam_step_sparse(part 2) updates the union.  No flat
+      bucket, no packing launch, no second pass over the whole model.  The
+      collective's size is a host-side capacity that follows the union's measured
+      size; a union larger than it voids the iteration on every rank (bit 2 of the
+      status word) and it is repeated with more room.
 """
 from __future__ import annotations
 
@@ -164,13 +169,6 @@ class MappingEngine:
         self.exchanged_bytes = 0          # bytes this rank handed to collectives in the last keyframe-parallel step
         self.exchange_at_world_1 = False  # take the keyframe-parallel path (collectives + separate Adam) in a 1-rank group too
         self.comm_events = None           # list -> (start, after exchange, after Adam[, after all-gather]) events per step
-        # sparse scheme only: overlap the exchange with what does not need it — the bitmaps are all-gathered on a side
-        # stream while the projection's backward runs (SlsMappingConfig.phase), the union's rows are reduced while Adam
-        # updates the surfels outside the union (sls_adam_step_sparse part 1 / 2).  Same parameters to the bit.
-        # (on one GPU in a one-rank group the overlapped form costs +100 us per iteration against +50 serial, HISTORY #64: an
-        #  option for a measured multi-GPU run, not a default; the environment variable is how the tests' spawned ranks get it)
-        self.overlap = os.environ.get("SLS_DP_OVERLAP", "0") == "1"
-        self._side = None                 # the side stream the collectives are issued from
         self._last_call = None            # (arguments, config) of the last sls_mapping_step: phase 2 repeats them
 
     # views of the flat gradient bucket in the optimiser's group order (single GPU: only filled
@@ -256,12 +254,6 @@ class MappingEngine:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.shape[0] != self.N:
                 raise RuntimeError("model parameters must stay contiguous float32 of the engine's size")
         return ps
-
-    def _enqueue_rest(self):
-        """Phase 2 of the iteration _enqueue(..., phase=1) started: the projection's backward, same arguments."""
-        args, cfg = self._last_call
-        cfg.phase, cfg.workspace_ready = 2, 1
-        _abi.check(_abi.lib().sls_mapping_step(*args), "sls_mapping_step (phase 2)")
 
     def _enqueue(self, camera, apply_adam, with_regulariser, status=None, mirror=None, allow_reuse=True, phase=0):
         lib = _abi.lib()
@@ -360,6 +352,9 @@ class MappingEngine:
         # with the same parameters and the same predictions would mispredict again, for ever.
         if st["overflow"] and self.deterministic == 2:
             self._det_two_pass_next = True            # (and with it the defaults' refresh)
+        if st.get("outside_union"):
+            raise RuntimeError("a surfel outside the agreed union of the touched sets had a non-zero gradient: the early "
+                               "gradient bitmap was no superset (sparse exchange) — the iteration's update is void")
         if st.get("handover_mismatch"):
             raise RuntimeError("the tile backward found a forward -> backward hand-over written by another tile-kernel variant "
                                "(sls_debug_variant switched between the two launches): the iteration's gradients are void")
@@ -376,7 +371,8 @@ class MappingEngine:
         # instance buffers were too small, bit 1 = the repaired depth order was not exact
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
                 "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
-                "handover_mismatch": bool(flags & 16), "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
+                "handover_mismatch": bool(flags & 16), "outside_union": bool(flags & 32),
+                "exchange_count": int(h[7].item()) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
@@ -388,7 +384,8 @@ class MappingEngine:
         R, flags = int(h[0]) & 0xFFFFFFFF, int(h[1])
         return {"R": R, "overflow": bool(flags), "too_small": bool(flags & 1), "resort_failed": bool(flags & 2),
                 "exchange_too_small": bool(flags & 4), "det_mispredicted": bool(flags & 8),
-                "handover_mismatch": bool(flags & 16), "exchange_count": int(h[7]) & 0xFFFFFFFF,
+                "handover_mismatch": bool(flags & 16), "outside_union": bool(flags & 32),
+                "exchange_count": int(h[7]) & 0xFFFFFFFF,
                 "loss_pixel": float(f[5]), "loss_reg": float(f[6]),
                 "loss": float(f[5]) + float(f[6]), "sums": [float(f[2]), float(f[3]), float(f[4])]}
 
@@ -571,7 +568,9 @@ class MappingEngine:
             # SLS_DP_MODE / N agree everywhere — MIN and MAX of a mode code (sparse 2, rs_ag 1, allreduce 0; a rank
             # that cannot shard asks for allreduce): sparse only if EVERY rank asks for it, a mix of sparse and a
             # dense scheme is an error on every rank (different collectives would hang), rs_ag needs all ranks able
-            want = 2 if self.dp_mode == "sparse" else (1 if (self.dp_mode == "rs_ag" and N % 2 == 0 and 10 * N < 2 ** 32) else 0)
+            # (the sparse scheme's fused Adam and the reduce-scatter layout both need an even N: an odd model falls back
+            #  to the all-reduce on every rank alike — N is the same everywhere)
+            want = (2 if N % 2 == 0 else 0) if self.dp_mode == "sparse" else (1 if (self.dp_mode == "rs_ag" and N % 2 == 0 and 10 * N < 2 ** 32) else 0)
             t = torch.tensor([want, -want], dtype=torch.int32, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             lo, hi = int(t[0].item()), -int(t[1].item())
@@ -593,6 +592,7 @@ class MappingEngine:
                             "all": torch.zeros((G * nw,), dtype=torch.int64, device=self.dev),      # every rank's
                             "prefix": torch.zeros((nw,), dtype=torch.int32, device=self.dev),
                             "compact": torch.zeros((10 * N,), dtype=torch.float32, device=self.dev),
+                            "index": torch.zeros((N,), dtype=torch.int32, device=self.dev),     # the surfel of every slot
                             "send": N,          # slots handed to the SUM collective: all of them until the union's size is known
                             "G": G, "rank": rank}
             return
@@ -615,79 +615,40 @@ class MappingEngine:
                     "gshard": torch.zeros((C + 4,), dtype=torch.float32, device=self.dev)}
 
     def _phase_for_exchange(self):
-        """1 = the native step stops after the tile backward (the overlapped sparse exchange runs the rest itself)"""
-        return 1 if (self.overlap and self._sx is not None) else 0
-
-    def _exchange_overlapped(self, group, status, mirror):
-        """dp_mode "sparse" with the collectives off the critical path (self.overlap).  Stream picture:
-            main:  ... tile backward | early bitmap |  projection's backward   | compact |  Adam outside the union  | Adam on the union
-            side:                                   |  all-gather of bitmaps   |         |  all-reduce of the rows  |
-        The early bitmap is a superset of the non-zero gradients (touched by the tile backward, or within a margin of
-        the regulariser's threshold): the union carries some all-zero rows, no sum changes, the parameters are those of
-        the serial exchange to the bit."""
-        lib, sx, N = _abi.lib(), self._sx, self.N
-        main = torch.cuda.current_stream(self.dev)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        side = self._side
-        side.wait_stream(main)                          # the early bitmap is written
-        with torch.cuda.stream(side):
-            w1 = dist.all_gather_into_tensor(sx["all"], sx["mine"], group=group, async_op=True)
-        self._enqueue_rest()                            # main: the projection's backward fills the gradient bucket
-        w1.wait()                                       # (main waits for the gathered bitmaps)
-        main.wait_stream(side)
-        st = main.cuda_stream
-        G = int(sx["all"].numel() // sx["mine"].numel())
-        send = int(sx["send"])
-        _abi.check(lib.sls_grad_compact(N, sx["all"].data_ptr(), G, sx["bitmap"].data_ptr(), self.grads.data_ptr(),
-                                        sx["compact"].data_ptr(), send, sx["prefix"].data_ptr(), status.data_ptr(), st),
-                   "sls_grad_compact")
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            w2 = dist.all_reduce(sx["compact"][:10 * send], op=dist.ReduceOp.SUM, group=group, async_op=True)
-        xyz, scaling, rotation, opacity = self._params()
-
-        def adam(part, mir):
-            _abi.check(lib.sls_adam_step_sparse(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
-                                                rotation.data_ptr(), sx["bitmap"].data_ptr(), sx["prefix"].data_ptr(),
-                                                sx["compact"].data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2],
-                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1, part,
-                                                status.data_ptr(), mir, st), "sls_adam_step_sparse")
-        adam(1, None)                                   # main: the surfels no rank touched — while the rows travel
-        w2.wait()
-        main.wait_stream(side)
-        adam(2, mirror)                                 # the union's surfels; mirrors the status
-        self.exchanged_bytes = 8 * int(sx["mine"].numel()) + 40 * send
+        """1 = the native step stops behind the tile backward (sparse scheme: the union of the touched sets is agreed on
+        before the projection's backward runs, which then writes the rows where the collective reads them)"""
+        return 1 if self._sx is not None else 0
 
     def _exchange_and_adam(self, group, status, mirror):
-        if self._phase_for_exchange() == 1:
-            return self._exchange_overlapped(group, status, mirror)
         ev = None
         if self.comm_events is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
         if self._sx is not None:
-            # touched set only: OR of the bitmaps -> pack the union's rows -> SUM of the first `send` slots -> Adam
+            # touched set only: OR of the early bitmaps -> the projection's backward writes the union's rows into their
+            # slots and updates everything else -> SUM of the first `send` slots -> Adam on the union
             lib, sx, N = _abi.lib(), self._sx, self.N
             st = torch.cuda.current_stream(self.dev).cuda_stream
             # (RCCL offers no bitwise-OR reduction: the bitmaps are gathered, the library ORs them)
             dist.all_gather_into_tensor(sx["all"], sx["mine"], group=group)
             G = int(sx["all"].numel() // sx["mine"].numel())
             send = int(sx["send"])
-            _abi.check(lib.sls_grad_compact(N, sx["all"].data_ptr(), G, sx["bitmap"].data_ptr(), self.grads.data_ptr(),
-                                            sx["compact"].data_ptr(), send, sx["prefix"].data_ptr(), status.data_ptr(), st),
-                       "sls_grad_compact")
+            _abi.check(lib.sls_grad_union(N, sx["all"].data_ptr(), G, sx["bitmap"].data_ptr(), send, sx["prefix"].data_ptr(),
+                                          status.data_ptr(), st), "sls_grad_union")
+            args, cfg = self._last_call
+            cfg.phase, cfg.workspace_ready, cfg.apply_adam, cfg.keep_grads = 2, 1, 1, 0
+            cfg.union_bitmap, cfg.union_prefix = sx["bitmap"].data_ptr(), sx["prefix"].data_ptr()
+            cfg.grad_compact, cfg.grad_compact_index, cfg.grad_compact_capacity = sx["compact"].data_ptr(), sx["index"].data_ptr(), send
+            _abi.check(lib.sls_mapping_step(*args), "sls_mapping_step (phase 2)")
             dist.all_reduce(sx["compact"][:10 * send], op=dist.ReduceOp.SUM, group=group)
             if ev:
                 ev[1].record()
             xyz, scaling, rotation, opacity = self._params()
-            _abi.check(lib.sls_adam_step_sparse(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
-                                                rotation.data_ptr(), sx["bitmap"].data_ptr(), sx["prefix"].data_ptr(),
-                                                sx["compact"].data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2],
-                                                self.lrs[3], self.betas[0], self.betas[1], self.eps, self.t + 1, 0,
-                                                status.data_ptr(), mirror, st), "sls_adam_step_sparse")
+            _abi.check(lib.sls_adam_step_union(N, xyz.data_ptr(), opacity.data_ptr(), scaling.data_ptr(), rotation.data_ptr(),
+                                               sx["index"].data_ptr(), sx["compact"].data_ptr(), send, self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), self.lrs[0], self.lrs[1], self.lrs[2], self.lrs[3],
+                                               self.betas[0], self.betas[1], self.eps, self.t + 1, status.data_ptr(), mirror,
+                                               st), "sls_adam_step_union")
             if ev:
                 ev[2].record(); ev[3].record()
             self.exchanged_bytes = 8 * int(sx["mine"].numel()) + 40 * send

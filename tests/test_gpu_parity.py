@@ -1255,29 +1255,29 @@ def test_engine_keyframe_parallel_two_ranks(device, tmp_path, dp_mode):
     assert np.abs(reduced - total).max() <= 1e-5 * scale
 
 
-def test_engine_sparse_exchange_overlapped_two_ranks(device, tmp_path, monkeypatch):
-    """VERDICT r3 item 6b.  The sparse exchange with the collectives off the critical path — bitmaps all-gathered
-    while the projection's backward runs, the union's rows reduced while Adam updates the surfels outside the union
-    (MappingEngine.overlap) — against the serial exchange: two ranks (gloo, one GPU), lagged status read, one rank
-    overflowing its instance buffers so that an iteration is voided and repeated on both.  With deterministic
-    accumulation the parameters after four iterations are the serial path's to the bit, on both ranks."""
+def test_engine_sparse_exchange_equals_the_all_reduce_two_ranks(device, tmp_path, monkeypatch):
+    """VERDICT r05 item 4.  The touched-set exchange as the engine runs it since round 6 — early bitmaps all-gathered and
+    OR-ed behind the tile backward, the projection's backward writing the union's rows straight into the collective's
+    buffer and applying Adam to every surfel outside the union, one SUM of the rows, Adam on the union — against the
+    dense all-reduce: two ranks (gloo, one GPU), lagged status read, one rank overflowing its instance buffers so that
+    an iteration is voided and repeated on both.  With deterministic accumulation the parameters after four iterations
+    are the all-reduce path's to the bit, on both ranks."""
     import socket
     import torch.multiprocessing as mp
     monkeypatch.setenv("SLS_DETERMINISTIC", "1")
     out = {}
-    for tag, flag in (("serial", "0"), ("overlapped", "1")):
-        monkeypatch.setenv("SLS_DP_OVERLAP", flag)
+    for tag in ("allreduce", "sparse"):
         d = tmp_path / tag
         d.mkdir()
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        mp.spawn(_engine_rank, args=(2, port, str(d), "lagged", "sparse"), nprocs=2, join=True)
+        mp.spawn(_engine_rank, args=(2, port, str(d), "lagged", tag), nprocs=2, join=True)
         out[tag] = [np.load(d / "r0.npz"), np.load(d / "r1.npz")]
     for tag, (r0, r1) in out.items():
         assert int(r0["t"]) == int(r1["t"]) == 4
         for k in ("xyz", "rot", "sc", "op"):
             assert np.array_equal(r0[k], r1[k]), f"{tag}: replicas diverged: {k}"
     for k in ("xyz", "rot", "sc", "op"):
-        assert np.array_equal(out["serial"][0][k], out["overlapped"][0][k]), f"overlapped exchange changed the parameters: {k}"
+        assert np.array_equal(out["allreduce"][0][k], out["sparse"][0][k]), f"the touched-set exchange changed the parameters: {k}"
 
 
 def _engine_rccl_rank(rank, port, out_dir, dp_mode):
@@ -1378,7 +1378,7 @@ def test_one_launch_deterministic_mode_survives_a_misprediction(device, tmp_path
         assert np.abs(r[tag + "_xyz"] - r["single_xyz"]).max() <= 1e-6 * np.abs(r["single_xyz"]).max(), tag
 
 
-@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce", "sparse", "sparse-overlapped"])
+@pytest.mark.parametrize("dp_mode", ["rs_ag", "allreduce", "sparse"])
 def test_engine_exchange_through_rccl_world_1(device, tmp_path, dp_mode, monkeypatch):
     """The keyframe-parallel exchange executed by RCCL itself (backend "nccl", one rank, one GPU): reduce_scatter_tensor
     -> Adam on the shard -> all_gather_into_tensor in place (rs_ag), or all_reduce -> Adam (allreduce).  With one
@@ -1388,11 +1388,6 @@ def test_engine_exchange_through_rccl_world_1(device, tmp_path, dp_mode, monkeyp
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    if dp_mode == "sparse-overlapped":
-        # the collectives issued asynchronously from a side stream, the projection's backward and the Adam update of
-        # the surfels outside the union running meanwhile (MappingEngine.overlap): RCCL's own async path
-        monkeypatch.setenv("SLS_DP_OVERLAP", "1")
-        dp_mode = "sparse"
     mp.spawn(_engine_rccl_rank, args=(port, str(tmp_path), dp_mode), nprocs=1, join=True)
     r = np.load(tmp_path / "rccl.npz")
     assert str(r["backend"]) == "nccl" and int(r["t"]) == 4

@@ -33,3 +33,6 @@ staged, passed, steps, lanes, slots, geom = s
 print(f"N={N} {H}x{W}: R={st.R} staged {staged} passed-cull {passed} steps {steps} (x4 = {4*steps} entry slots)")
 print(f"  live lanes/step {lanes/steps:.1f} of 64; slots with a live lane {slots} ({slots/(4*steps):.2%} of slots, {slots/passed:.2%} of passed)")
 print(f"  slots with a geometric hit (finished pixels included) {geom} ({geom/passed:.2%} of passed); compact entries {counts.sum()}")
+h = fwd_c.cpu().numpy()[T * 16 + 6:T * 16 + 15].astype(np.int64)
+print(f"  finer blocks: contributing entries {h[0]}; (4x2 half, entry) pairs {h[1]} ({h[1]/h[0]:.2f} per entry), (2x2 quarter, entry) pairs {h[2]} ({h[2]/h[0]:.2f})")
+print(f"  steps of 4 entries per block, summed: 8x2 blocks {h[3]}; two half-waves in lockstep {h[4]} ({h[4]/h[3]:.2%}); four quarter-waves {h[5]} ({h[5]/h[3]:.2%}); longest block {h[6]} / {h[7]} / {h[8]}")
