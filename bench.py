@@ -125,7 +125,8 @@ def main(extras_only=None):
         _abi.check(lib.sls_debug_variant(args.variant[0], args.variant[1]), "sls_debug_variant")
     N, H, W = args.n, args.height, args.width
     scene = synth.make_scene(N, H, W, seed=0)
-    poses = synth.keyframe_poses(max(world, 8))
+    kf0 = int(os.environ.get("SLS_BENCH_FIRST_KEYFRAME", "0"))          # (experiments: the window starts at this keyframe of the row)
+    poses = synth.keyframe_poses(max(world, 8) + kf0)[kf0:]
     depth, valid = synth.make_targets(H, W, scene)
     cfg = MappingConfig()
     status_read = {"sync": True, "async": False, "lagged": "lagged"}["async" if args.async_steps else args.status_read]

@@ -235,11 +235,25 @@ __device__ __forceinline__ float block_reduce16_pk(const v2f (&x)[8], int lane)
     for (int i = 0; i < 4; ++i) permlane16_swap(b[i], b[i + 4]);
     const v2f z01 = mk2(b[0], b[1]) + mk2(b[4], b[5]), z23 = mk2(b[2], b[3]) + mk2(b[6], b[7]);
     const float z[4] = { z01.x, z01.y, z23.x, z23.y };
-    float w[2];
-    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) w[i] = (s3 ? z[i + 2] : z[i]) + dpp_mov0<0x128, 0xF>(s3 ? z[i] : z[i + 2]);   // row_ror:8
-    return (s2 ? w[1] : w[0]) + dpp_xor4(s2 ? w[0] : w[1]);
+    // The last two levels (partners lane ^ 8 and lane ^ 4 inside a row of 16): which half of its values a lane keeps is
+    // a property of its BANK (lanes 4b .. 4b + 3 of a row) — bit 3 of the lane is set in banks 2, 3, bit 2 in banks 1, 3 —
+    // so each level is two bank-masked DPP adds per output, `kept + partner's` written only where the bank keeps that
+    // value: 6 instructions for both levels where selects + DPP moves took 12 (the same sums, operands swapped at most).
+    // (ONE statement: a DPP operand written by one of the two instructions in front needs the wait states the s_nops
+    //  supply — the compiler does not see inside — and six separate statements cost eleven of them)
+    float w0 = z[0], w1 = z[1];
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"      // banks 0, 1 keep values 0, 1 ...
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"      // ... banks 2, 3 values 2, 3
+        "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"      // banks 0, 2 keep w0 (partner: lane + 4)
+        "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"           // banks 1, 3 keep w1 (partner: lane - 4)
+        : "+v"(w0), "+v"(w1) : "v"(z[2]), "v"(z[3]));
+    const float r = w0;
+    (void)lane;
+    return r;
 }
 
 // Bounding box (in lane coordinates of an 8x8 sub-tile, lane = y*8 + x) of the

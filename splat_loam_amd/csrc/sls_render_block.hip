@@ -788,8 +788,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SLS_FWD_WAVE
 #define SLS_ABL_PARAM
 #define SLS_ABL_ARG(v_)
 #endif
+#ifdef SLS_BWD_WAVES      // (experiment builds: a register cap for that many waves per SIMD; HISTORY #75)
+#define SLS_BWD_OCC __attribute__((amdgpu_waves_per_eu(SLS_BWD_WAVES, SLS_BWD_WAVES)))
+#else
+#define SLS_BWD_OCC
+#endif
 template <int BW, int BH, bool LEAN, int FUSED, int DET, bool DENSE>
-__global__ __launch_bounds__(64) void render_bwd_block_kernel(
+__global__ __launch_bounds__(64) SLS_BWD_OCC void render_bwd_block_kernel(
     DevCam cam, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ vals,
     const float4 *__restrict__ rec, const float2 *__restrict__ col_cs, const float2 *__restrict__ row_cs,
     const float4 *__restrict__ pix_state, const uint2 *__restrict__ pix_contrib,
@@ -982,7 +987,10 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
     float Tr = Tf, S = 0.0f;   // replicated over the quad
     // One step: the list entries in slots j (LDS record slot of my quad lane; 64 = the empty padding record) with
     // contributor numbers `contributor`, back to front: slot 0 of a quad holds the LAST entry of the four.
-    auto blend_step = [&](const int j, const uint32_t contributor) {
+    // (two halves: step_sums does everything up to the reduce-scatter — the chain over Tr and S runs through it — and
+    //  step_flush the atomics.  Two steps per loop iteration with both flushes behind them — one basic block of 252 VALU
+    //  instructions, 112 registers — changed nothing at any size: the compiler schedules them one after the other, HISTORY #77)
+    auto step_sums = [&](const int j, const uint32_t contributor) -> float {
         const float4 *sr = s_rec + __umul24((unsigned)j, (unsigned)kRec4);
         const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], q3 = sr[3], q4 = sr[4];
         Eval e;
@@ -1014,7 +1022,8 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             gdist = dDist * (M2 + m * m * Af - 2.0f * m * M1);
             ddist = dDist * 2.0f * (m * Af - M1) * dm_dd;
         }
-        const float gk = dD * dep + (dN01.x * q2.x + dN01.y * q2.y + dN2 * q2.z) + dA + gdist;
+        float gk = dD * dep + (dN01.x * q2.x + dN01.y * q2.y + dN2 * q2.z) + dA;
+        if (!LEAN) gk += gdist;             // (x + 0.0f is not x for the compiler: an instruction of its own)
         float Se, St;
         quad_excl_total(w * gk, k1, k2, k3, Se, St);
         const float dL_dalpha = act ? Ti * gk - (S + Se) * rom : 0.0f;
@@ -1044,7 +1053,9 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
         gl[5] = mk2(w * dN2 + dL_dnd * d2, dL_do);                      // fields 10, 11
         gl[6] = dL_dhuv;                                                // fields 12, 13
         gl[7] = lp * e.dxy;                                             // fields 14, 15
-        const float tot = block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
+        return block_reduce16_pk(gl, lane);  // field `field` of the surfel in my slot
+    };
+    auto step_flush = [&](const int j, const float tot) {
         const uint32_t gidx = s_gidx[j];
         // (the padding entry is never active: its sums are exact zeros)
         if (DET == 0) {
@@ -1070,6 +1081,7 @@ __global__ __launch_bounds__(64) void render_bwd_block_kernel(
             else atomicAdd(&det_acc[(size_t)gidx * kGrec + field], (unsigned long long)__float2ll_rn(scaled));
         }
     };
+    auto blend_step = [&](const int j, const uint32_t contributor) { step_flush(j, step_sums(j, contributor)); };
     if (DENSE) {
         // ---- rounds of 64 entries of the forward's compact list (every one of them reached a pixel of this block)
         const int n = (int)(range.y - range.x);
