@@ -140,3 +140,36 @@ def test_frame_from_precomp_inverts_the_reference_construction():
         assert float((q2.norm(dim=1) - 1).abs().max()) <= 1e-6
     with pytest.raises(ValueError):
         frame_from_precomp(torch.zeros(5, 6))
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """The Python side mirrors the header's structs by hand (splat_loam_amd/_abi.py): a field added on one side only moves
+    every later field silently.  A C program compiled against include/sls_abi.h prints size and field offsets; the ctypes
+    classes must agree field by field (names included)."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    from splat_loam_amd import _abi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    classes = ("SlsCamera", "SlsMappingConfig", "SlsMappingStatus", "SlsAlignerParams", "SlsAlignerResult", "SlsAdamGroup")
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "sls_abi.h"', "int main(void) {"]
+    for name in classes:
+        cls = getattr(_abi, name)
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for name in classes:
+        cls = getattr(_abi, name)
+        assert got[(name, "size")] == C.sizeof(cls), f"{name}: {got[(name, 'size')]} bytes in the header, {C.sizeof(cls)} in ctypes"
+        for field, _ in cls._fields_:
+            assert got[(name, field)] == getattr(cls, field).offset, f"{name}.{field}"
