@@ -23,7 +23,7 @@ T = ((H + 15) // 16) * ((W + 15) // 16)
 fwd_c = torch.zeros(T * 16 + 64, dtype=torch.int32, device=dev)
 lib = _abi.lib()
 lib.sls_debug_wave_cycles(C.c_void_p(fwd_c.data_ptr()), C.c_void_p(0))
-st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"])
+st = rasterize_forward(settings, t["means"], t["opac"], t["scales"], t["rots"], list_pairs=1)      # (dense rounds at every size: the counters live there)
 torch.cuda.synchronize()
 lib.sls_debug_wave_cycles(C.c_void_p(0), C.c_void_p(0))
 s = fwd_c.cpu().numpy()[T * 16:T * 16 + 6].astype(np.int64)
